@@ -1,0 +1,12 @@
+"""hevc-complexity-reduction_amd -- MI355X-native ETH-CNN CU-partition predictor.
+
+Host-side mirror (Python, as in the reference) of the one hot path this package replaces:
+/root/reference/HM-16.5_Test_AI/bin/{video_to_cu_depth.py, net_CNN.py}.  All compute is in
+lib/libethcnn.so (hand-written gfx950 kernels behind the C ABI of include/ethcnn.h).
+
+The directory name has a hyphen; import it with
+    importlib.import_module("hevc-complexity-reduction_amd")
+"""
+from . import ethcnn  # noqa: F401
+from .ethcnn import EthCnn, EthCnnError, load_library  # noqa: F401
+from . import net_CNN, video_to_cu_depth  # noqa: F401

@@ -1,0 +1,648 @@
+// ethcnn_api.cpp -- the C ABI of libethcnn.so (include/ethcnn.h): context, weights,
+// the per-pass kernel pipeline, host<->device staging and the YUV-file driver.
+//
+// Mirrors /root/reference/HM-16.5_Test_AI/bin/video_to_cu_depth.py (driver) around
+// net_CNN.py (network).  There is no CPU compute path in this library.
+#include <hip/hip_runtime.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cerrno>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ethcnn_kernels.h"
+#include "ethcnn_spec.h"
+
+using namespace ethcnn;
+
+struct ethcnn_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;   // compute
+    hipStream_t copy_in = nullptr;  // H2D of the next pass
+    hipStream_t copy_out = nullptr; // D2H of the previous pass
+    char devname[128] = {0};
+    std::string err;
+
+    bool have_weights = false;
+    std::vector<float> blob;
+    DeviceWeights dw;
+    float* dw_arena = nullptr;
+
+    float thr1 = 0.5f, thr2 = 0.5f;  // shipped Thr_info.txt: 0.5 x 6
+
+    Workspace ws;
+    int max_ctus = 131072;
+    int last_n = 0;  // CTUs of the last pass (debug_fetch)
+
+    bool profiling = false;
+    struct Ev { hipEvent_t a, b; int stage; };
+    std::vector<Ev> pending;
+    std::vector<hipEvent_t> ev_pool;
+    ethcnn_stage_times times{};
+
+    // staging for the host / file entry points (double buffered)
+    uint8_t* h_in[2] = {nullptr, nullptr};
+    float* h_out[2] = {nullptr, nullptr};
+    uint8_t* d_in[2] = {nullptr, nullptr};
+    float* d_out[2] = {nullptr, nullptr};
+    size_t in_cap = 0, out_cap = 0;
+};
+
+static thread_local std::string g_create_err;
+
+static int set_err(ethcnn_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    std::vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_err = buf;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                       \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return set_err((c), ETHCNN_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" const char* ethcnn_version(void) { return "ethcnn-mi355x 0.1 (gfx950)"; }
+
+extern "C" const char* ethcnn_last_error(const ethcnn_ctx* ctx) {
+    return ctx ? ctx->err.c_str() : g_create_err.c_str();
+}
+
+// ------------------------------------------------------------------ workspace -------
+static void free_workspace(ethcnn_ctx* c) {
+    Workspace& w = c->ws;
+    void* ptrs[] = {w.xs, w.xm, w.xl, w.feat, w.h1, w.h2, w.logits, w.raw, w.flags};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    w = Workspace();
+}
+
+static int ensure_workspace(ethcnn_ctx* c, int n, int chunks) {
+    Workspace& w = c->ws;
+    const int cap = (n + 15) / 16 * 16;
+    if (cap > w.cap) {
+        free_workspace(c);  // hipFree synchronises: nothing in flight still uses the old buffers
+        HIPCHK(c, hipMalloc((void**)&w.xs, (size_t)cap * 4096));
+        HIPCHK(c, hipMalloc((void**)&w.xm, (size_t)cap * 2048));
+        HIPCHK(c, hipMalloc((void**)&w.xl, (size_t)cap * 512));
+        HIPCHK(c, hipMalloc((void**)&w.feat, (size_t)cap * kNFeat * 4));
+        HIPCHK(c, hipMalloc((void**)&w.h1, (size_t)cap * kNVec * 4));
+        HIPCHK(c, hipMalloc((void**)&w.h2, (size_t)cap * kNFc2 * 4));
+        HIPCHK(c, hipMalloc((void**)&w.logits, (size_t)cap * kNOut * 4));
+        HIPCHK(c, hipMalloc((void**)&w.raw, (size_t)cap * kNOut * 4));
+        w.cap = cap;
+    }
+    if (chunks > w.flags_cap) {
+        if (w.flags) (void)hipFree(w.flags);
+        w.flags = nullptr;
+        HIPCHK(c, hipMalloc((void**)&w.flags, (size_t)chunks * 2 * sizeof(int)));
+        w.flags_cap = chunks;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------ lifecycle -------
+extern "C" int ethcnn_create(ethcnn_ctx** out, const ethcnn_options* opt) {
+    if (!out) return set_err(nullptr, ETHCNN_ERR_ARG, "ethcnn_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return set_err(nullptr, ETHCNN_ERR_DEVICE, "no HIP device available (%s): libethcnn has no CPU fallback",
+                       e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    const int dev = opt ? opt->device : 0;
+    if (dev < 0 || dev >= ndev) return set_err(nullptr, ETHCNN_ERR_ARG, "device %d out of range (0..%d)", dev, ndev - 1);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess)
+        return set_err(nullptr, ETHCNN_ERR_DEVICE, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return set_err(nullptr, ETHCNN_ERR_DEVICE, "device %d is %s; libethcnn is built for gfx950 only", dev, prop.gcnArchName);
+    ethcnn_ctx* c = new (std::nothrow) ethcnn_ctx();
+    if (!c) return set_err(nullptr, ETHCNN_ERR_NOMEM, "out of memory");
+    c->device = dev;
+    std::snprintf(c->devname, sizeof c->devname, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    if (opt && opt->max_ctus_per_pass > 0) c->max_ctus = std::max(1024, (opt->max_ctus_per_pass + 1023) / 1024 * 1024);
+    if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->copy_in, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->copy_out, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return set_err(nullptr, ETHCNN_ERR_DEVICE, "cannot create HIP streams on device %d", dev);
+    }
+    *out = c;
+    return ETHCNN_OK;
+}
+
+static void free_staging(ethcnn_ctx* c) {
+    for (int i = 0; i < 2; ++i) {
+        if (c->h_in[i]) (void)hipHostFree(c->h_in[i]);
+        if (c->h_out[i]) (void)hipHostFree(c->h_out[i]);
+        if (c->d_in[i]) (void)hipFree(c->d_in[i]);
+        if (c->d_out[i]) (void)hipFree(c->d_out[i]);
+        c->h_in[i] = nullptr; c->h_out[i] = nullptr; c->d_in[i] = nullptr; c->d_out[i] = nullptr;
+    }
+    c->in_cap = c->out_cap = 0;
+}
+
+extern "C" void ethcnn_destroy(ethcnn_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (auto& p : c->pending) { c->ev_pool.push_back(p.a); c->ev_pool.push_back(p.b); }
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+    free_workspace(c);
+    free_staging(c);
+    if (c->dw_arena) (void)hipFree(c->dw_arena);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->copy_in) (void)hipStreamDestroy(c->copy_in);
+    if (c->copy_out) (void)hipStreamDestroy(c->copy_out);
+    delete c;
+}
+
+extern "C" int ethcnn_device_name(const ethcnn_ctx* c, char* out, size_t cap) {
+    if (!c || !out || cap == 0) return ETHCNN_ERR_ARG;
+    std::snprintf(out, cap, "%s", c->devname);
+    return ETHCNN_OK;
+}
+
+// -------------------------------------------------------------------- weights -------
+static int upload_weights(ethcnn_ctx* c) {
+    HIPCHK(c, hipSetDevice(c->device));
+    // one arena: trunk_w | trunk_b | fc1_w | fc1_b | fc2 w,b x3 | fc3 w,b x3 (each 64-float aligned)
+    std::vector<size_t> sizes = {(size_t)3 * kTrunkWFrags * 64, (size_t)3 * kTrunkBFrags * 64,
+                                 (size_t)kNFeat * kNVec, (size_t)kNVec};
+    for (int h = 0; h < 3; ++h) { sizes.push_back((size_t)(kN1[h] + 1) * kN2[h]); sizes.push_back((size_t)kN2[h]); }
+    for (int h = 0; h < 3; ++h) { sizes.push_back((size_t)(kN2[h] + 1) * kN3[h]); sizes.push_back((size_t)kN3[h]); }
+    std::vector<size_t> offs;
+    size_t total = 0;
+    for (size_t s : sizes) { offs.push_back(total); total += (s + 63) / 64 * 64; }
+    std::vector<float> host(total, 0.0f);
+    const float* blob = c->blob.data();
+    pack_trunk_fragments(blob, host.data() + offs[0], host.data() + offs[1]);
+    pack_fc1(blob, host.data() + offs[2], host.data() + offs[3]);
+    for (int h = 0; h < 3; ++h) {
+        std::memcpy(host.data() + offs[4 + 2 * h], blob + kOffFc2W[h], sizes[4 + 2 * h] * 4);
+        std::memcpy(host.data() + offs[5 + 2 * h], blob + kOffFc2B[h], sizes[5 + 2 * h] * 4);
+        std::memcpy(host.data() + offs[10 + 2 * h], blob + kOffFc3W[h], sizes[10 + 2 * h] * 4);
+        std::memcpy(host.data() + offs[11 + 2 * h], blob + kOffFc3B[h], sizes[11 + 2 * h] * 4);
+    }
+    if (!c->dw_arena) HIPCHK(c, hipMalloc((void**)&c->dw_arena, total * 4));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(c->dw_arena, host.data(), total * 4, hipMemcpyHostToDevice));
+    DeviceWeights& d = c->dw;
+    d.trunk_w = c->dw_arena + offs[0];
+    d.trunk_b = c->dw_arena + offs[1];
+    d.fc1_w = c->dw_arena + offs[2];
+    d.fc1_b = c->dw_arena + offs[3];
+    for (int h = 0; h < 3; ++h) {
+        d.fc2_w[h] = c->dw_arena + offs[4 + 2 * h];
+        d.fc2_b[h] = c->dw_arena + offs[5 + 2 * h];
+        d.fc3_w[h] = c->dw_arena + offs[10 + 2 * h];
+        d.fc3_b[h] = c->dw_arena + offs[11 + 2 * h];
+    }
+    c->have_weights = true;
+    return ETHCNN_OK;
+}
+
+extern "C" int ethcnn_load_blob(ethcnn_ctx* c, const float* blob, size_t nfloats) {
+    if (!c || !blob) return ETHCNN_ERR_ARG;
+    if (nfloats != kBlobFloats) return set_err(c, ETHCNN_ERR_ARG, "blob must hold %zu floats, got %zu", kBlobFloats, nfloats);
+    c->blob.assign(blob, blob + nfloats);
+    return upload_weights(c);
+}
+
+extern "C" int ethcnn_load_synthetic(ethcnn_ctx* c, uint64_t seed, double head_gain) {
+    if (!c) return ETHCNN_ERR_ARG;
+    c->blob.resize(kBlobFloats);
+    synth_blob(seed, head_gain, c->blob.data());
+    return upload_weights(c);
+}
+
+extern "C" int ethcnn_load_checkpoint(ethcnn_ctx* c, const char* prefix) {
+    if (!c || !prefix) return ETHCNN_ERR_ARG;
+    std::vector<float> blob(kBlobFloats);
+    char err[400];
+    const int rc = ckpt_load_blob(prefix, blob.data(), err, sizeof err);
+    if (rc) return set_err(c, rc, "%s", err);
+    c->blob.swap(blob);
+    return upload_weights(c);
+}
+
+extern "C" int ethcnn_get_blob(const ethcnn_ctx* c, float* out, size_t nfloats) {
+    if (!c || !out || nfloats != kBlobFloats || !c->have_weights) return ETHCNN_ERR_ARG;
+    std::memcpy(out, c->blob.data(), nfloats * 4);
+    return ETHCNN_OK;
+}
+
+// ----------------------------------------------------------------- thresholds -------
+extern "C" int ethcnn_set_thresholds(ethcnn_ctx* c, float t1, float t2) {
+    if (!c) return ETHCNN_ERR_ARG;
+    c->thr1 = t1;
+    c->thr2 = t2;
+    return ETHCNN_OK;
+}
+extern "C" int ethcnn_get_thresholds(const ethcnn_ctx* c, float* t1, float* t2) {
+    if (!c || !t1 || !t2) return ETHCNN_ERR_ARG;
+    *t1 = c->thr1;
+    *t2 = c->thr2;
+    return ETHCNN_OK;
+}
+extern "C" int ethcnn_load_thresholds(ethcnn_ctx* c, const char* path) {
+    if (!c || !path) return ETHCNN_ERR_ARG;
+    char err[400];
+    float a, b;
+    const int rc = parse_thr_info(path, &a, &b, err, sizeof err);
+    if (rc) return set_err(c, rc, "%s", err);
+    c->thr1 = a;
+    c->thr2 = b;
+    return ETHCNN_OK;
+}
+
+// ------------------------------------------------------------------ profiling -------
+static hipEvent_t get_event(ethcnn_ctx* c) {
+    if (!c->ev_pool.empty()) {
+        hipEvent_t e = c->ev_pool.back();
+        c->ev_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+struct StageTimer {
+    ethcnn_ctx* c;
+    int stage;
+    hipEvent_t a = nullptr, b = nullptr;
+    StageTimer(ethcnn_ctx* c_, int st) : c(c_), stage(st) {
+        if (c->profiling) {
+            a = get_event(c);
+            b = get_event(c);
+            (void)hipEventRecord(a, c->stream);
+        }
+    }
+    ~StageTimer() {
+        if (c->profiling) {
+            (void)hipEventRecord(b, c->stream);
+            c->pending.push_back({a, b, stage});
+        }
+        c->times.launches[stage]++;
+    }
+};
+static void drain_events(ethcnn_ctx* c) {
+    for (auto& p : c->pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess)
+            c->times.ms[p.stage] += ms;
+        c->ev_pool.push_back(p.a);
+        c->ev_pool.push_back(p.b);
+    }
+    c->pending.clear();
+}
+extern "C" int ethcnn_set_profiling(ethcnn_ctx* c, int on) {
+    if (!c) return ETHCNN_ERR_ARG;
+    drain_events(c);
+    c->profiling = on != 0;
+    return ETHCNN_OK;
+}
+extern "C" int ethcnn_get_stage_times(ethcnn_ctx* c, ethcnn_stage_times* out) {
+    if (!c || !out) return ETHCNN_ERR_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    drain_events(c);
+    *out = c->times;
+    return ETHCNN_OK;
+}
+extern "C" int ethcnn_reset_stage_times(ethcnn_ctx* c) {
+    if (!c) return ETHCNN_ERR_ARG;
+    drain_events(c);
+    c->times = ethcnn_stage_times{};
+    return ETHCNN_OK;
+}
+
+// ------------------------------------------------------------------- pipeline -------
+static int make_geom(ethcnn_ctx* c, int w, int h, ptrdiff_t pitch, ptrdiff_t fstride, FrameGeom* g) {
+    if (w <= 0 || h <= 0) return set_err(c, ETHCNN_ERR_ARG, "bad frame size %dx%d", w, h);
+    if (pitch < w) return set_err(c, ETHCNN_ERR_ARG, "pitch %td < width %d", pitch, w);
+    g->width = w;
+    g->height = h;
+    g->pitch = (long)pitch;
+    g->frame_stride = (long)fstride;
+    g->cw = (w + 63) / 64;
+    g->ch = (h + 63) / 64;
+    g->nctu = g->cw * g->ch;
+    return 0;
+}
+
+// one pass over CTUs [ctu0, ctu0+n) of the sequence; ctu0 is sub-batch aligned
+static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, int qp,
+                    float* d_probs_pass) {
+    const int cpf = chunks_per_frame(g.nctu);
+    const long nchunks = (ctu0 + n - 1) / g.nctu * cpf + ((ctu0 + n - 1) % g.nctu) / kSubBatch + 1 -
+                         (ctu0 / g.nctu * cpf + (ctu0 % g.nctu) / kSubBatch);
+    int rc = ensure_workspace(c, n, (int)nchunks);
+    if (rc) return rc;
+    const float qn = (float)qp * (1.0f / 51.0f);  // net_CNN.py:106
+    HIPCHK(c, hipMemsetAsync(c->ws.flags, 0, (size_t)nchunks * 2 * sizeof(int), c->stream));
+    { StageTimer t(c, ETHCNN_STAGE_TILE); launch_tile(d_luma, g, ctu0, n, c->ws, c->stream); }
+    { StageTimer t(c, ETHCNN_STAGE_TRUNK); launch_trunk(c->ws, c->dw, n, false, c->stream); }
+    { StageTimer t(c, ETHCNN_STAGE_FC1); launch_fc1(c->ws, c->dw, n, c->ws.h1, c->stream); }
+    { StageTimer t(c, ETHCNN_STAGE_FC2); launch_fc2(c->ws, c->dw, n, qn, c->stream); }
+    { StageTimer t(c, ETHCNN_STAGE_HEAD); launch_head(c->ws, c->dw, n, qn, g.nctu, ctu0, c->thr1, c->thr2, d_probs_pass, c->stream); }
+    { StageTimer t(c, ETHCNN_STAGE_GATE); launch_gate(c->ws, n, g.nctu, ctu0, c->thr2, d_probs_pass, c->stream); }
+    HIPCHK(c, hipGetLastError());
+    c->times.ctus += n;
+    c->last_n = n;
+    return 0;
+}
+
+// split `total` CTUs (nframes * nctu) into passes: whole frames when a frame fits the
+// workspace, otherwise sub-batch-aligned pieces of one frame (gate scope stays intact).
+struct Pass { long ctu0; int n; };
+static std::vector<Pass> plan_passes(int nctu, int nframes, int max_ctus) {
+    std::vector<Pass> out;
+    if (nctu <= max_ctus) {
+        const int fpp = std::max(1, max_ctus / nctu);
+        for (int f = 0; f < nframes; f += fpp) {
+            const int nf = std::min(fpp, nframes - f);
+            out.push_back({(long)f * nctu, nf * nctu});
+        }
+    } else {
+        for (int f = 0; f < nframes; ++f)
+            for (int o = 0; o < nctu; o += max_ctus) out.push_back({(long)f * nctu + o, std::min(max_ctus, nctu - o)});
+    }
+    return out;
+}
+
+extern "C" int ethcnn_predict_luma_device(ethcnn_ctx* c, const uint8_t* d_luma, int w, int h, ptrdiff_t pitch,
+                                          ptrdiff_t fstride, int nframes, int qp, float* d_probs) {
+    if (!c || !d_luma || !d_probs || nframes < 0) return c ? set_err(c, ETHCNN_ERR_ARG, "null pointer / negative frame count") : ETHCNN_ERR_ARG;
+    if (!c->have_weights) return set_err(c, ETHCNN_ERR_NOWEIGHTS, "no weights loaded");
+    FrameGeom g;
+    int rc = make_geom(c, w, h, pitch, fstride, &g);
+    if (rc) return rc;
+    if (nframes == 0) return ETHCNN_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    for (const Pass& p : plan_passes(g.nctu, nframes, c->max_ctus)) {
+        rc = run_pass(c, d_luma, g, p.ctu0, p.n, qp, d_probs + (size_t)p.ctu0 * kNOut);
+        if (rc) return rc;
+    }
+    return ETHCNN_OK;
+}
+
+static int ensure_staging(ethcnn_ctx* c, size_t in_bytes, size_t out_bytes) {
+    if (in_bytes > c->in_cap || out_bytes > c->out_cap) {
+        HIPCHK(c, hipDeviceSynchronize());
+        const size_t ic = std::max(in_bytes, c->in_cap), oc = std::max(out_bytes, c->out_cap);
+        free_staging(c);
+        for (int i = 0; i < 2; ++i) {
+            HIPCHK(c, hipHostMalloc((void**)&c->h_in[i], ic, hipHostMallocDefault));
+            HIPCHK(c, hipHostMalloc((void**)&c->h_out[i], oc, hipHostMallocDefault));
+            HIPCHK(c, hipMalloc((void**)&c->d_in[i], ic));
+            HIPCHK(c, hipMalloc((void**)&c->d_out[i], oc));
+        }
+        c->in_cap = ic;
+        c->out_cap = oc;
+    }
+    return 0;
+}
+
+// Generic double-buffered host pipeline: for each group of frames, `fill(buf, f0, nf)` packs
+// luma planes tightly (pitch = width) into pinned memory, then H2D -> kernels -> D2H run on
+// three streams so the copy of group i+1 overlaps the compute of group i, and
+// `drain(buf, f0, nf)` consumes the pinned probabilities.
+template <typename Fill, typename Drain>
+static int host_pipeline(ethcnn_ctx* c, int w, int h, int nframes, int qp, Fill fill, Drain drain) {
+    FrameGeom g;
+    int rc = make_geom(c, w, h, w, (ptrdiff_t)w * h, &g);
+    if (rc) return rc;
+    if (!c->have_weights) return set_err(c, ETHCNN_ERR_NOWEIGHTS, "no weights loaded");
+    if (nframes == 0) return ETHCNN_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    // frames per group: whole frames up to max_ctus (a frame larger than the workspace is
+    // still one group; run_pass splits it)
+    const int fpg = std::max(1, std::min(nframes, c->max_ctus / g.nctu));
+    const size_t plane = (size_t)w * h;
+    rc = ensure_staging(c, plane * fpg, (size_t)fpg * g.nctu * kNOut * 4);
+    if (rc) return rc;
+    hipEvent_t in_done[2], comp_done[2], out_done[2];
+    for (int i = 0; i < 2; ++i) {
+        HIPCHK(c, hipEventCreateWithFlags(&in_done[i], hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&comp_done[i], hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&out_done[i], hipEventDisableTiming));
+    }
+    struct Group { int f0, nf; };
+    std::vector<Group> groups;
+    for (int f = 0; f < nframes; f += fpg) groups.push_back({f, std::min(fpg, nframes - f)});
+    int result = ETHCNN_OK;
+    auto body = [&]() -> int {
+        for (size_t gi = 0; gi <= groups.size(); ++gi) {
+            if (gi < groups.size()) {
+                const int b = (int)(gi & 1);
+                const Group& G = groups[gi];
+                if (gi >= 2) {  // buffer b was last used by group gi-2: its D2H must be done and drained
+                    HIPCHK(c, hipEventSynchronize(out_done[b]));
+                    int r = drain(c->h_out[b], groups[gi - 2].f0, groups[gi - 2].nf);
+                    if (r) return r;
+                }
+                int r = fill(c->h_in[b], G.f0, G.nf);
+                if (r) return r;
+                HIPCHK(c, hipMemcpyAsync(c->d_in[b], c->h_in[b], plane * G.nf, hipMemcpyHostToDevice, c->copy_in));
+                HIPCHK(c, hipEventRecord(in_done[b], c->copy_in));
+                HIPCHK(c, hipStreamWaitEvent(c->stream, in_done[b], 0));
+                FrameGeom gg = g;
+                for (const Pass& p : plan_passes(g.nctu, G.nf, c->max_ctus)) {
+                    r = run_pass(c, c->d_in[b], gg, p.ctu0, p.n, qp, c->d_out[b] + (size_t)p.ctu0 * kNOut);
+                    if (r) return r;
+                }
+                HIPCHK(c, hipEventRecord(comp_done[b], c->stream));
+                HIPCHK(c, hipStreamWaitEvent(c->copy_out, comp_done[b], 0));
+                HIPCHK(c, hipMemcpyAsync(c->h_out[b], c->d_out[b], (size_t)G.nf * g.nctu * kNOut * 4, hipMemcpyDeviceToHost, c->copy_out));
+                HIPCHK(c, hipEventRecord(out_done[b], c->copy_out));
+                // buffer reuse is safe without further stream waits: before group gi+2 touches
+                // buffer b again the host has synchronised on out_done[b] (above), which orders
+                // after this group's H2D, kernels and D2H.
+            }
+        }
+        // drain the last (up to) two groups in order
+        const size_t ng = groups.size();
+        for (size_t gi = (ng >= 2 ? ng - 2 : 0); gi < ng; ++gi) {
+            const int b = (int)(gi & 1);
+            HIPCHK(c, hipEventSynchronize(out_done[b]));
+            int r = drain(c->h_out[b], groups[gi].f0, groups[gi].nf);
+            if (r) return r;
+        }
+        return ETHCNN_OK;
+    };
+    result = body();
+    (void)hipStreamSynchronize(c->copy_in);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->copy_out);
+    for (int i = 0; i < 2; ++i) {
+        (void)hipEventDestroy(in_done[i]);
+        (void)hipEventDestroy(comp_done[i]);
+        (void)hipEventDestroy(out_done[i]);
+    }
+    return result;
+}
+
+extern "C" int ethcnn_predict_luma(ethcnn_ctx* c, const uint8_t* luma, int w, int h, ptrdiff_t pitch, ptrdiff_t fstride,
+                                   int nframes, int qp, float* probs) {
+    if (!c || !luma || !probs || nframes < 0) return c ? set_err(c, ETHCNN_ERR_ARG, "null pointer / negative frame count") : ETHCNN_ERR_ARG;
+    if (pitch < w) return set_err(c, ETHCNN_ERR_ARG, "pitch %td < width %d", pitch, w);
+    const int nctu = ((w + 63) / 64) * ((h + 63) / 64);
+    auto fill = [&](uint8_t* dst, int f0, int nf) -> int {
+        for (int f = 0; f < nf; ++f) {
+            const uint8_t* src = luma + (size_t)(f0 + f) * fstride;
+            uint8_t* d = dst + (size_t)f * w * h;
+            if (pitch == w) std::memcpy(d, src, (size_t)w * h);
+            else for (int y = 0; y < h; ++y) std::memcpy(d + (size_t)y * w, src + (size_t)y * pitch, (size_t)w);
+        }
+        return 0;
+    };
+    auto drain = [&](const float* src, int f0, int nf) -> int {
+        std::memcpy(probs + (size_t)f0 * nctu * kNOut, src, (size_t)nf * nctu * kNOut * 4);
+        return 0;
+    };
+    return host_pipeline(c, w, h, nframes, qp, fill, drain);
+}
+
+// video_to_cu_depth.py:120-145 minus argv/model selection (those live in the launcher).
+extern "C" int ethcnn_predict_yuv_file(ethcnn_ctx* c, const char* yuv, int w, int h, int qp, const char* out_path,
+                                       int64_t* nframes_out) {
+    if (!c || !yuv || !out_path) return c ? set_err(c, ETHCNN_ERR_ARG, "null path") : ETHCNN_ERR_ARG;
+    if (w <= 0 || h <= 0) return set_err(c, ETHCNN_ERR_ARG, "bad frame size %dx%d", w, h);
+    struct stat st;
+    if (stat(yuv, &st) != 0) return set_err(c, ETHCNN_ERR_IO, "cannot stat %s: %s", yuv, std::strerror(errno));
+    const int64_t frame_bytes = (int64_t)w * h * 3 / 2;  // :136  width * height * 3 // 2
+    if (frame_bytes == 0 || st.st_size % frame_bytes != 0)  // :137 assert(file_bytes % frame_bytes == 0)
+        return set_err(c, ETHCNN_ERR_FORMAT, "%s: size %lld is not a multiple of the %dx%d 4:2:0 frame size %lld", yuv,
+                       (long long)st.st_size, w, h, (long long)frame_bytes);
+    const int nframes = (int)(st.st_size / frame_bytes);
+    if (nframes_out) *nframes_out = nframes;
+    FILE* fin = std::fopen(yuv, "rb");
+    if (!fin) return set_err(c, ETHCNN_ERR_IO, "cannot open %s: %s", yuv, std::strerror(errno));
+    const std::string tmp = std::string(out_path) + ".tmp." + std::to_string((long)getpid());
+    FILE* fout = std::fopen(tmp.c_str(), "wb");
+    if (!fout) {
+        std::fclose(fin);
+        return set_err(c, ETHCNN_ERR_IO, "cannot create %s: %s", tmp.c_str(), std::strerror(errno));
+    }
+    const int nctu = ((w + 63) / 64) * ((h + 63) / 64);
+    const int fd = fileno(fin);
+    auto fill = [&](uint8_t* dst, int f0, int nf) -> int {
+        for (int f = 0; f < nf; ++f) {  // luma only; chroma (w*h/2 bytes) is never read (:47-48)
+            size_t got = 0;
+            const size_t want = (size_t)w * h;
+            const off_t off = (off_t)(f0 + f) * frame_bytes;
+            while (got < want) {
+                const ssize_t r = pread(fd, dst + (size_t)f * want + got, want - got, off + (off_t)got);
+                if (r <= 0) return set_err(c, ETHCNN_ERR_IO, "short read in %s (frame %d)", yuv, f0 + f);
+                got += (size_t)r;
+            }
+        }
+        return 0;
+    };
+    auto drain = [&](const float* src, int /*f0*/, int nf) -> int {
+        const size_t cnt = (size_t)nf * nctu * kNOut;
+        if (std::fwrite(src, 4, cnt, fout) != cnt) return set_err(c, ETHCNN_ERR_IO, "write to %s failed", tmp.c_str());
+        return 0;
+    };
+    int rc = host_pipeline(c, w, h, nframes, qp, fill, drain);
+    std::fclose(fin);
+    if (std::fclose(fout) != 0 && rc == 0) rc = set_err(c, ETHCNN_ERR_IO, "close of %s failed", tmp.c_str());
+    if (rc == 0 && std::rename(tmp.c_str(), out_path) != 0)
+        rc = set_err(c, ETHCNN_ERR_IO, "rename %s -> %s failed: %s", tmp.c_str(), out_path, std::strerror(errno));
+    if (rc != 0) std::remove(tmp.c_str());
+    return rc;
+}
+
+// -------------------------------------------------------------- config #5 -----------
+extern "C" int ethcnn_resi_vectors_device(ethcnn_ctx* c, const uint8_t* d_luma, int w, int h, ptrdiff_t pitch, float* d_vec) {
+    if (!c || !d_luma || !d_vec) return c ? set_err(c, ETHCNN_ERR_ARG, "null pointer") : ETHCNN_ERR_ARG;
+    if (!c->have_weights) return set_err(c, ETHCNN_ERR_NOWEIGHTS, "no weights loaded");
+    FrameGeom g;
+    int rc = make_geom(c, w, h, pitch, (ptrdiff_t)pitch * h, &g);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    for (int o = 0; o < g.nctu; o += c->max_ctus) {
+        const int n = std::min(c->max_ctus, g.nctu - o);
+        rc = ensure_workspace(c, n, 1);
+        if (rc) return rc;
+        { StageTimer t(c, ETHCNN_STAGE_TILE); launch_tile(d_luma, g, o, n, c->ws, c->stream); }
+        { StageTimer t(c, ETHCNN_STAGE_TRUNK); launch_trunk(c->ws, c->dw, n, true, c->stream); }
+        { StageTimer t(c, ETHCNN_STAGE_FC1); launch_fc1(c->ws, c->dw, n, d_vec + (size_t)o * kNVec, c->stream); }
+        HIPCHK(c, hipGetLastError());
+        c->times.ctus += n;
+        c->last_n = n;
+    }
+    return ETHCNN_OK;
+}
+
+extern "C" int ethcnn_resi_vectors(ethcnn_ctx* c, const uint8_t* luma, int w, int h, ptrdiff_t pitch, float* vec) {
+    if (!c || !luma || !vec) return c ? set_err(c, ETHCNN_ERR_ARG, "null pointer") : ETHCNN_ERR_ARG;
+    if (w <= 0 || h <= 0 || pitch < w) return set_err(c, ETHCNN_ERR_ARG, "bad geometry");
+    const int nctu = ((w + 63) / 64) * ((h + 63) / 64);
+    int rc = ensure_staging(c, (size_t)pitch * h, (size_t)nctu * kNVec * 4);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_in[0], luma, (size_t)pitch * h, hipMemcpyHostToDevice, c->stream));
+    rc = ethcnn_resi_vectors_device(c, c->d_in[0], w, h, pitch, c->d_out[0]);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(vec, c->d_out[0], (size_t)nctu * kNVec * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ETHCNN_OK;
+}
+
+// ------------------------------------------------------------ device plumbing -------
+extern "C" int ethcnn_device_alloc(ethcnn_ctx* c, size_t bytes, void** out) {
+    if (!c || !out) return ETHCNN_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMalloc(out, bytes ? bytes : 1));
+    return ETHCNN_OK;
+}
+extern "C" int ethcnn_device_free(ethcnn_ctx* c, void* p) {
+    if (!c) return ETHCNN_ERR_ARG;
+    if (p) HIPCHK(c, hipFree(p));
+    return ETHCNN_OK;
+}
+extern "C" int ethcnn_memcpy_h2d(ethcnn_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (!c || !dst || !src) return ETHCNN_ERR_ARG;
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ETHCNN_OK;
+}
+extern "C" int ethcnn_memcpy_d2h(ethcnn_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (!c || !dst || !src) return ETHCNN_ERR_ARG;
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ETHCNN_OK;
+}
+extern "C" int ethcnn_synchronize(ethcnn_ctx* c) {
+    if (!c) return ETHCNN_ERR_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ETHCNN_OK;
+}
+
+extern "C" int ethcnn_debug_fetch(ethcnn_ctx* c, int which, float* out, size_t nfloats) {
+    if (!c || !out) return ETHCNN_ERR_ARG;
+    const float* src = nullptr;
+    size_t per = 0;
+    switch (which) {
+        case ETHCNN_DBG_FEATURES: src = c->ws.feat; per = kNFeat; break;
+        case ETHCNN_DBG_FC1: src = c->ws.h1; per = kNVec; break;
+        case ETHCNN_DBG_FC2: src = c->ws.h2; per = kNFc2; break;
+        case ETHCNN_DBG_LOGITS: src = c->ws.logits; per = kNOut; break;
+        case ETHCNN_DBG_RAW_PROBS: src = c->ws.raw; per = kNOut; break;
+        default: return set_err(c, ETHCNN_ERR_ARG, "unknown debug tensor %d", which);
+    }
+    if (!src || nfloats > (size_t)c->last_n * per) return set_err(c, ETHCNN_ERR_ARG, "debug_fetch: last pass had %d CTUs", c->last_n);
+    return ethcnn_memcpy_d2h(c, out, src, nfloats * 4);
+}

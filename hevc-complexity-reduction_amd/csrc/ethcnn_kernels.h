@@ -1,0 +1,47 @@
+// ethcnn_kernels.h -- launch interface of the gfx950 kernels (ethcnn_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "ethcnn_spec.h"
+
+namespace ethcnn {
+
+// per-pass device workspace (sized for `cap` CTUs, rounded up to 16)
+struct Workspace {
+    int cap = 0;
+    uint4* xs = nullptr;     // [cap][4][64]      u8 CTU pixels in trunk-lane order (S branch)
+    uint4* xm = nullptr;     // [cap/4][8][64]    u16 2x2 pooled sums (M branch)
+    uint4* xl = nullptr;     // [cap/16][8][64]   u16 4x4 pooled sums (L branch)
+    float* feat = nullptr;   // [cap][2688]
+    float* h1 = nullptr;     // [cap][448]
+    float* h2 = nullptr;     // [cap][336]
+    float* logits = nullptr; // [cap][21]
+    float* raw = nullptr;    // [cap][21] ungated probabilities
+    int* flags = nullptr;    // [chunks][2]
+    int flags_cap = 0;
+};
+
+struct FrameGeom {
+    int width, height;
+    long pitch, frame_stride;
+    int cw, ch, nctu;  // CTUs per row / column / frame
+};
+
+// k0: luma frames -> xs/xm/xl for CTUs [ctu0, ctu0 + n) of the frame sequence
+void launch_tile(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, const Workspace& ws, hipStream_t s);
+// k1: xs/xm/xl -> feat
+void launch_trunk(const Workspace& ws, const DeviceWeights& w, int n, bool resi, hipStream_t s);
+// k2: feat -> h1 (bias + leaky-ReLU fused); out may be ws.h1 or a caller buffer (resi vectors)
+void launch_fc1(const Workspace& ws, const DeviceWeights& w, int n, float* out, hipStream_t s);
+// k3: h1 -> h2 (three heads, qp row + bias + leaky-ReLU fused)
+void launch_fc2(const Workspace& ws, const DeviceWeights& w, int n, float qn, hipStream_t s);
+// k4: h2 -> logits, raw probs, probs (ungated) and per-chunk gate flags
+void launch_head(const Workspace& ws, const DeviceWeights& w, int n, float qn, int nctu_per_frame,
+                 long ctu0, float thr1, float thr2, float* d_probs, hipStream_t s);
+// k5: apply the batch gates in place on d_probs
+void launch_gate(const Workspace& ws, int n, int nctu_per_frame, long ctu0, float thr2, float* d_probs,
+                 hipStream_t s);
+
+int chunks_per_frame(int nctu);
+
+}  // namespace ethcnn

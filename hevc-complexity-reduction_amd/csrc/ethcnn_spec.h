@@ -1,0 +1,100 @@
+// ethcnn_spec.h -- shapes, checkpoint layout and packed-weight layouts shared by the host
+// code and the HIP kernels of libethcnn.so.
+//
+// Network: /root/reference/HM-16.5_Test_AI/bin/net_CNN.py:103-195.
+// Checkpoint tensor table: the .index files next to it.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+#include "../../include/ethcnn.h"
+
+namespace ethcnn {
+
+constexpr int kCtu = 64;
+constexpr int kNOut = 21;
+constexpr int kNFeat = 2688;
+constexpr int kNVec = 448;   // FC1 outputs: 64 | 128 | 256
+constexpr int kNFc2 = 336;   // FC2 outputs: 48 | 96 | 192
+constexpr int kSubBatch = 1024;
+constexpr size_t kBlobFloats = 1288210;
+
+// branches in feature order S, M, L (net_CNN.py:150 concat order)
+enum Branch { kS = 0, kM = 1, kL = 2 };
+
+struct TensorDesc {
+    const char* name;
+    int rank;
+    int shape[4];
+    size_t offset_bytes;  // into the TF-V2 .data payload
+    size_t count() const {
+        size_t n = 1;
+        for (int i = 0; i < rank; ++i) n *= (size_t)shape[i];
+        return n;
+    }
+};
+constexpr int kNumTensors = 36;
+extern const TensorDesc kTensors[kNumTensors];  // bundle (sorted-key) order
+
+// float offsets into the blob ------------------------------------------------------------
+// conv variables are unnamed: L = Variable.._5, M = _6.._11, S = _12.._17 (creation order,
+// net_CNN.py:126-141)
+constexpr size_t kOffConvW[3][3] = {{13504 / 4, 14592 / 4, 20832 / 4},
+                                    {51904 / 4, 52992 / 4, 1088 / 4},
+                                    {0 / 4, 33248 / 4, 39488 / 4}};
+constexpr size_t kOffConvB[3][3] = {{14528 / 4, 20736 / 4, 33120 / 4},
+                                    {52928 / 4, 59136 / 4, 13376 / 4},
+                                    {1024 / 4, 39392 / 4, 51776 / 4}};
+// heads in output order 64, 32, 16
+constexpr int kN1[3] = {64, 128, 256}, kN2[3] = {48, 96, 192}, kN3[3] = {1, 4, 16};
+constexpr int kO1[3] = {0, 64, 192}, kO2[3] = {0, 48, 144}, kO3[3] = {0, 1, 5};
+constexpr size_t kOffFc1W[3] = {4189792 / 4, 2813280 / 4, 60256 / 4};
+constexpr size_t kOffFc1B[3] = {4189536 / 4, 2812768 / 4, 59232 / 4};
+constexpr size_t kOffFc2W[3] = {5126176 / 4, 5076448 / 4, 4878688 / 4};
+constexpr size_t kOffFc2B[3] = {5125984 / 4, 5076064 / 4, 4877920 / 4};
+constexpr size_t kOffFc3W[3] = {5152644 / 4, 5151088 / 4, 5138720 / 4};
+constexpr size_t kOffFc3B[3] = {5152640 / 4, 5151072 / 4, 5138656 / 4};
+
+// feature-vector map
+constexpr int kOff3[3] = {0, 512, 640};       // conv3 S, M, L
+constexpr int kOff2[3] = {672, 2208, 2592};   // conv2 S, M, L
+constexpr int kNb[3] = {4, 2, 1};             // units per CTU side
+
+// ---- device-side packed weights ---------------------------------------------------------
+// Trunk (k1): per branch, MFMA A-operand fragments, one float per lane per k-step:
+//   [0..3]    conv1  A1[s]       = W1[ky=g][kx=s][co=col]
+//   [4..35]   conv2  A2[t][s2]   s2 = 4*q1 + r, ci = 4g + r, co = 16t + col (0 if co >= 24)
+//   [36..83]  conv3  A3[t][s]    s<16: q2 = s>>2, r = s&3, ci = 4g+r
+//                                s>=16: j = (s-16)>>2, r = (s-16)&3, q2 = 2j + (g>>1), ci = 16 + 4(g&1) + r
+// with lane = col + 16 g.  Bias fragments (value for C-layout row 4g + r):
+//   [0..3] conv1, [4..11] conv2 [t][r] (0 for co >= 24), [12..19] conv3 [t][r]
+constexpr int kTrunkWFrags = 84, kTrunkBFrags = 20;
+
+struct DeviceWeights {
+    float* trunk_w = nullptr;  // [3][84][64]
+    float* trunk_b = nullptr;  // [3][20][64]
+    float* fc1_w = nullptr;    // [2688][448]  columns = 64 | 128 | 256
+    float* fc1_b = nullptr;    // [448]
+    float* fc2_w[3] = {nullptr, nullptr, nullptr};  // [n1+1][n2] (last row = qp row)
+    float* fc2_b[3] = {nullptr, nullptr, nullptr};
+    float* fc3_w[3] = {nullptr, nullptr, nullptr};  // [n2+1][n3]
+    float* fc3_b[3] = {nullptr, nullptr, nullptr};
+};
+
+// host-side packing (ethcnn_weights.cpp)
+void pack_trunk_fragments(const float* blob, float* w_out /*[3][84][64]*/, float* b_out /*[3][20][64]*/);
+void pack_fc1(const float* blob, float* w_out /*[2688][448]*/, float* b_out /*[448]*/);
+void synth_blob(uint64_t seed, double head_gain, float* blob_out /*[kBlobFloats]*/);
+
+// TF-V2 checkpoint bundle reader (tf_ckpt_v2.cpp).  Returns 0 or a negative ETHCNN_ERR_*;
+// on error `err` holds the message.
+using CkptEntry = ::ethcnn_ckpt_entry;
+int ckpt_read_index(const char* index_path, CkptEntry* entries, int cap, int* n_out, char* err, size_t errcap);
+int ckpt_load_blob(const char* prefix, float* blob_out /*[kBlobFloats]*/, char* err, size_t errcap);
+uint32_t crc32c(const void* data, size_t n);
+uint32_t crc32c_mask(uint32_t crc);
+
+// Thr_info.txt / model name (ethcnn_io.cpp)
+int parse_thr_info(const char* path, float* thr_l1_lower, float* thr_l2_lower, char* err, size_t errcap);
+
+}  // namespace ethcnn

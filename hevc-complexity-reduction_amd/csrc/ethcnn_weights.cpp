@@ -1,0 +1,144 @@
+// ethcnn_weights.cpp -- checkpoint tensor table, synthetic weights, device packing.
+//
+// Tensor table == the key/shape/offset table of the reference's TF-V2 checkpoints
+// (/root/reference/HM-16.5_Test_AI/bin/model_2000000_qp*.dat.index).
+#include <cmath>
+#include <cstring>
+
+#include "ethcnn_spec.h"
+
+namespace ethcnn {
+
+const TensorDesc kTensors[kNumTensors] = {
+    {"Variable", 4, {4, 4, 1, 16}, 0},
+    {"Variable_1", 1, {16, 0, 0, 0}, 1024},
+    {"Variable_10", 4, {2, 2, 24, 32}, 1088},
+    {"Variable_11", 1, {32, 0, 0, 0}, 13376},
+    {"Variable_12", 4, {4, 4, 1, 16}, 13504},
+    {"Variable_13", 1, {16, 0, 0, 0}, 14528},
+    {"Variable_14", 4, {2, 2, 16, 24}, 14592},
+    {"Variable_15", 1, {24, 0, 0, 0}, 20736},
+    {"Variable_16", 4, {2, 2, 24, 32}, 20832},
+    {"Variable_17", 1, {32, 0, 0, 0}, 33120},
+    {"Variable_2", 4, {2, 2, 16, 24}, 33248},
+    {"Variable_3", 1, {24, 0, 0, 0}, 39392},
+    {"Variable_4", 4, {2, 2, 24, 32}, 39488},
+    {"Variable_5", 1, {32, 0, 0, 0}, 51776},
+    {"Variable_6", 4, {4, 4, 1, 16}, 51904},
+    {"Variable_7", 1, {16, 0, 0, 0}, 52928},
+    {"Variable_8", 4, {2, 2, 16, 24}, 52992},
+    {"Variable_9", 1, {24, 0, 0, 0}, 59136},
+    {"h_fc1__16__b", 1, {256, 0, 0, 0}, 59232},
+    {"h_fc1__16__w", 2, {2688, 256, 0, 0}, 60256},
+    {"h_fc1__32__b", 1, {128, 0, 0, 0}, 2812768},
+    {"h_fc1__32__w", 2, {2688, 128, 0, 0}, 2813280},
+    {"h_fc1__64__b", 1, {64, 0, 0, 0}, 4189536},
+    {"h_fc1__64__w", 2, {2688, 64, 0, 0}, 4189792},
+    {"h_fc2__16__b", 1, {192, 0, 0, 0}, 4877920},
+    {"h_fc2__16__w", 2, {257, 192, 0, 0}, 4878688},
+    {"h_fc2__32__b", 1, {96, 0, 0, 0}, 5076064},
+    {"h_fc2__32__w", 2, {129, 96, 0, 0}, 5076448},
+    {"h_fc2__64__b", 1, {48, 0, 0, 0}, 5125984},
+    {"h_fc2__64__w", 2, {65, 48, 0, 0}, 5126176},
+    {"y_conv_flat__16__b", 1, {16, 0, 0, 0}, 5138656},
+    {"y_conv_flat__16__w", 2, {193, 16, 0, 0}, 5138720},
+    {"y_conv_flat__32__b", 1, {4, 0, 0, 0}, 5151072},
+    {"y_conv_flat__32__w", 2, {97, 4, 0, 0}, 5151088},
+    {"y_conv_flat__64__b", 1, {1, 0, 0, 0}, 5152640},
+    {"y_conv_flat__64__w", 2, {49, 1, 0, 0}, 5152644},
+};
+
+// ---------------------------------------------------------------- synthetic weights ---
+// The trained blobs are absent from the reference (.MISSING_LARGE_BLOBS); every test and
+// benchmark runs on this seeded generator (same function in oracle/ethcnn_np.py::synth_blob
+// for the test side).
+static inline uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+void synth_blob(uint64_t seed, double head_gain, float* blob) {
+    for (int t = 0; t < kNumTensors; ++t) {
+        const TensorDesc& d = kTensors[t];
+        const size_t n = d.count();
+        const uint64_t key = splitmix64(seed ^ (0xD6E8FEB86659FD93ull * (uint64_t)(t + 1)));
+        double scale;
+        if (d.rank == 1) {
+            scale = 0.1;
+        } else {
+            double fan_in = 1.0;
+            for (int i = 0; i + 1 < d.rank; ++i) fan_in *= (double)d.shape[i];
+            scale = std::sqrt(3.0 / fan_in);
+            if (std::strncmp(d.name, "h_fc2", 5) == 0 || std::strncmp(d.name, "y_conv", 6) == 0)
+                scale = scale * head_gain;
+        }
+        float* out = blob + d.offset_bytes / 4;
+        for (size_t i = 0; i < n; ++i) {
+            const uint64_t h = splitmix64(key + (uint64_t)i);
+            const double u = (double)(h >> 40);
+            const double val = (u + 0.5) * (1.0 / 8388608.0) - 1.0;
+            out[i] = (float)(val * scale);
+        }
+    }
+}
+
+// ------------------------------------------------------------------- device packing ---
+// MFMA v_mfma_f32_16x16x4_f32 operand layout: lane l holds A[i = l & 15][k = l >> 4].
+// The trunk runs "transposed" (rows = output channels, columns = 16 units), so the
+// weights are the A operand and the accumulator of one layer is directly the B operand
+// of the next (see ethcnn_kernels.hip, k1_trunk).
+void pack_trunk_fragments(const float* blob, float* w_out, float* b_out) {
+    for (int br = 0; br < 3; ++br) {
+        const float* W1 = blob + kOffConvW[br][0];  // [4][4][1][16]
+        const float* W2 = blob + kOffConvW[br][1];  // [2][2][16][24]
+        const float* W3 = blob + kOffConvW[br][2];  // [2][2][24][32]
+        const float* B1 = blob + kOffConvB[br][0];
+        const float* B2 = blob + kOffConvB[br][1];
+        const float* B3 = blob + kOffConvB[br][2];
+        float* w = w_out + (size_t)br * kTrunkWFrags * 64;
+        float* b = b_out + (size_t)br * kTrunkBFrags * 64;
+        for (int lane = 0; lane < 64; ++lane) {
+            const int col = lane & 15, g = lane >> 4;
+            for (int s = 0; s < 4; ++s) w[(0 + s) * 64 + lane] = W1[(g * 4 + s) * 16 + col];
+            for (int t = 0; t < 2; ++t)
+                for (int s2 = 0; s2 < 16; ++s2) {
+                    const int q1 = s2 >> 2, r = s2 & 3, ci = 4 * g + r, co = 16 * t + col;
+                    w[(4 + t * 16 + s2) * 64 + lane] = (co < 24) ? W2[(q1 * 16 + ci) * 24 + co] : 0.0f;
+                }
+            for (int t = 0; t < 2; ++t)
+                for (int s = 0; s < 24; ++s) {
+                    int q2, ci;
+                    if (s < 16) {
+                        q2 = s >> 2;
+                        ci = 4 * g + (s & 3);
+                    } else {
+                        const int j = (s - 16) >> 2, r = (s - 16) & 3;
+                        q2 = 2 * j + (g >> 1);
+                        ci = 16 + 4 * (g & 1) + r;
+                    }
+                    w[(36 + t * 24 + s) * 64 + lane] = W3[(q2 * 24 + ci) * 32 + 16 * t + col];
+                }
+            for (int r = 0; r < 4; ++r) b[(0 + r) * 64 + lane] = B1[4 * g + r];
+            for (int t = 0; t < 2; ++t)
+                for (int r = 0; r < 4; ++r) {
+                    const int co = 16 * t + 4 * g + r;
+                    b[(4 + t * 4 + r) * 64 + lane] = (co < 24) ? B2[co] : 0.0f;
+                    b[(12 + t * 4 + r) * 64 + lane] = B3[co];
+                }
+        }
+    }
+}
+
+void pack_fc1(const float* blob, float* w_out, float* b_out) {
+    for (int h = 0; h < 3; ++h) {
+        const float* W = blob + kOffFc1W[h];
+        const int n1 = kN1[h];
+        for (int k = 0; k < kNFeat; ++k)
+            std::memcpy(w_out + (size_t)k * kNVec + kO1[h], W + (size_t)k * n1, sizeof(float) * n1);
+        std::memcpy(b_out + kO1[h], blob + kOffFc1B[h], sizeof(float) * n1);
+    }
+}
+
+}  // namespace ethcnn

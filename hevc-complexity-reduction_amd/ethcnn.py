@@ -1,0 +1,297 @@
+"""ctypes binding of libethcnn.so (include/ethcnn.h) -- the only way Python reaches the
+HIP kernels.  No torch, no numpy math: numpy is used for buffers only.
+
+There is deliberately no fallback: if the shared library is missing, or no gfx950 device
+is usable, construction raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libethcnn.so")
+
+NOUT, NFEAT, NVEC, NFC2, SUB_BATCH = 21, 2688, 448, 336, 1024
+BLOB_FLOATS = 1288210
+
+STAGES = ("tile", "trunk", "fc1", "fc2", "head", "gate")
+DBG_FEATURES, DBG_FC1, DBG_FC2, DBG_LOGITS, DBG_RAW_PROBS = range(5)
+_DBG_WIDTH = {DBG_FEATURES: NFEAT, DBG_FC1: NVEC, DBG_FC2: NFC2, DBG_LOGITS: NOUT, DBG_RAW_PROBS: NOUT}
+
+
+class EthCnnError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, "libethcnn error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Options(ctypes.Structure):
+    _fields_ = [("device", ctypes.c_int), ("max_ctus_per_pass", ctypes.c_int), ("reserved", ctypes.c_int * 6)]
+
+
+class StageTimes(ctypes.Structure):
+    _fields_ = [("ms", ctypes.c_double * 6), ("launches", ctypes.c_int64 * 6), ("ctus", ctypes.c_int64)]
+
+
+class CkptEntry(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 64), ("dtype", ctypes.c_int), ("rank", ctypes.c_int),
+                ("shape", ctypes.c_int64 * 4), ("shard", ctypes.c_int), ("offset", ctypes.c_int64),
+                ("size", ctypes.c_int64), ("crc32c", ctypes.c_uint32)]
+
+
+# every symbol include/ethcnn.h declares: name -> (restype, argtypes)
+_vp, _cp, _i, _sz = ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_size_t
+_fp, _pd = ctypes.POINTER(ctypes.c_float), ctypes.c_ssize_t
+SIGNATURES = {
+    "ethcnn_create": (_i, [ctypes.POINTER(_vp), ctypes.POINTER(Options)]),
+    "ethcnn_destroy": (None, [_vp]),
+    "ethcnn_last_error": (_cp, [_vp]),
+    "ethcnn_version": (_cp, []),
+    "ethcnn_load_checkpoint": (_i, [_vp, _cp]),
+    "ethcnn_load_blob": (_i, [_vp, _fp, _sz]),
+    "ethcnn_load_synthetic": (_i, [_vp, ctypes.c_uint64, ctypes.c_double]),
+    "ethcnn_get_blob": (_i, [_vp, _fp, _sz]),
+    "ethcnn_model_name_for_qp": (_i, [_i, ctypes.c_char_p, _sz]),
+    "ethcnn_load_thresholds": (_i, [_vp, _cp]),
+    "ethcnn_parse_thresholds": (_i, [_cp, _fp, _fp]),
+    "ethcnn_set_thresholds": (_i, [_vp, ctypes.c_float, ctypes.c_float]),
+    "ethcnn_get_thresholds": (_i, [_vp, _fp, _fp]),
+    "ethcnn_predict_luma_device": (_i, [_vp, _vp, _i, _i, _pd, _pd, _i, _i, _vp]),
+    "ethcnn_predict_luma": (_i, [_vp, _vp, _i, _i, _pd, _pd, _i, _i, _fp]),
+    "ethcnn_predict_yuv_file": (_i, [_vp, _cp, _i, _i, _i, _cp, ctypes.POINTER(ctypes.c_int64)]),
+    "ethcnn_resi_vectors_device": (_i, [_vp, _vp, _i, _i, _pd, _vp]),
+    "ethcnn_resi_vectors": (_i, [_vp, _vp, _i, _i, _pd, _fp]),
+    "ethcnn_device_alloc": (_i, [_vp, _sz, ctypes.POINTER(_vp)]),
+    "ethcnn_device_free": (_i, [_vp, _vp]),
+    "ethcnn_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz]),
+    "ethcnn_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz]),
+    "ethcnn_synchronize": (_i, [_vp]),
+    "ethcnn_device_name": (_i, [_vp, ctypes.c_char_p, _sz]),
+    "ethcnn_set_profiling": (_i, [_vp, _i]),
+    "ethcnn_get_stage_times": (_i, [_vp, ctypes.POINTER(StageTimes)]),
+    "ethcnn_reset_stage_times": (_i, [_vp]),
+    "ethcnn_debug_fetch": (_i, [_vp, _i, _fp, _sz]),
+    "ethcnn_ckpt_read_index": (_i, [_cp, ctypes.POINTER(CkptEntry), _i, ctypes.POINTER(_i), ctypes.c_char_p, _sz]),
+    "ethcnn_crc32c_masked": (ctypes.c_uint32, [_vp, _sz]),
+}
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen libethcnn.so and type every entry point.  Raises if it is not built."""
+    global _lib
+    if _lib is None or path is not None:
+        p = path or LIB_PATH
+        if not os.path.exists(p):
+            raise OSError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no fallback implementation)" % p)
+        lib = ctypes.CDLL(p)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        if path is not None:
+            return lib
+        _lib = lib
+    return _lib
+
+
+def model_name_for_qp(qp):
+    buf = ctypes.create_string_buffer(64)
+    rc = load_library().ethcnn_model_name_for_qp(int(qp), buf, 64)
+    if rc:
+        raise EthCnnError(rc, "model_name_for_qp")
+    return buf.value.decode()
+
+
+def parse_thresholds(thr_info_path):
+    a, b = ctypes.c_float(), ctypes.c_float()
+    rc = load_library().ethcnn_parse_thresholds(os.fsencode(thr_info_path), ctypes.byref(a), ctypes.byref(b))
+    if rc:
+        raise EthCnnError(rc, "cannot parse %s" % thr_info_path)
+    return a.value, b.value
+
+
+def read_ckpt_index(index_path):
+    """[(name, dtype, shape, shard, offset, size, masked_crc32c)] of a TF-V2 .index file."""
+    lib = load_library()
+    ents = (CkptEntry * 256)()
+    n = ctypes.c_int(0)
+    err = ctypes.create_string_buffer(400)
+    rc = lib.ethcnn_ckpt_read_index(index_path.encode(), ents, 256, ctypes.byref(n), err, 400)
+    if rc:
+        raise EthCnnError(rc, err.value.decode())
+    return [(e.name.decode(), e.dtype, tuple(e.shape[i] for i in range(e.rank)), e.shard, e.offset, e.size, e.crc32c)
+            for e in ents[: n.value]]
+
+
+def crc32c_masked(data):
+    b = bytes(data)
+    return load_library().ethcnn_crc32c_masked(b, len(b))
+
+
+def ctus_per_frame(width, height):
+    return ((width + 63) // 64) * ((height + 63) // 64)
+
+
+class DeviceBuffer(object):
+    """HBM allocation owned by a context (ethcnn_device_alloc)."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        p = ctypes.c_void_p()
+        ctx._chk(ctx.lib.ethcnn_device_alloc(ctx.h, self.nbytes, ctypes.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        self.ctx._chk(self.ctx.lib.ethcnn_memcpy_h2d(self.ctx.h, self.ptr, arr.ctypes.data, arr.nbytes))
+
+    def download(self, dtype, count):
+        out = np.empty(int(count), dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        self.ctx._chk(self.ctx.lib.ethcnn_memcpy_d2h(self.ctx.h, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.ctx.lib.ethcnn_device_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+
+class EthCnn(object):
+    """One predictor context on one GPU (the reference's tf.Session + Saver + graph)."""
+
+    def __init__(self, device=0, max_ctus_per_pass=0):
+        self.lib = load_library()
+        opt = Options(device=int(device), max_ctus_per_pass=int(max_ctus_per_pass))
+        h = ctypes.c_void_p()
+        rc = self.lib.ethcnn_create(ctypes.byref(h), ctypes.byref(opt))
+        if rc:
+            raise EthCnnError(rc, self.lib.ethcnn_last_error(None).decode())
+        self.h = h
+
+    # -- plumbing
+    def _chk(self, rc):
+        if rc:
+            raise EthCnnError(rc, self.lib.ethcnn_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ethcnn_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def device_name(self):
+        buf = ctypes.create_string_buffer(128)
+        self._chk(self.lib.ethcnn_device_name(self.h, buf, 128))
+        return buf.value.decode()
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def synchronize(self):
+        self._chk(self.lib.ethcnn_synchronize(self.h))
+
+    # -- weights / thresholds
+    def load_checkpoint(self, prefix):
+        self._chk(self.lib.ethcnn_load_checkpoint(self.h, os.fsencode(prefix)))
+
+    def load_blob(self, blob):
+        blob = np.ascontiguousarray(blob, dtype=np.float32)
+        self._chk(self.lib.ethcnn_load_blob(self.h, blob.ctypes.data_as(_fp), blob.size))
+
+    def load_synthetic(self, seed=1, head_gain=1.0):
+        self._chk(self.lib.ethcnn_load_synthetic(self.h, int(seed), float(head_gain)))
+
+    def get_blob(self):
+        out = np.empty(BLOB_FLOATS, dtype=np.float32)
+        self._chk(self.lib.ethcnn_get_blob(self.h, out.ctypes.data_as(_fp), out.size))
+        return out
+
+    def load_thresholds(self, thr_info_path):
+        self._chk(self.lib.ethcnn_load_thresholds(self.h, os.fsencode(thr_info_path)))
+
+    def set_thresholds(self, thr_l1_lower, thr_l2_lower):
+        self._chk(self.lib.ethcnn_set_thresholds(self.h, thr_l1_lower, thr_l2_lower))
+
+    def get_thresholds(self):
+        a, b = ctypes.c_float(), ctypes.c_float()
+        self._chk(self.lib.ethcnn_get_thresholds(self.h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
+    # -- prediction
+    def predict_luma(self, luma, width, height, nframes, qp, pitch=None, frame_stride=None):
+        """Host luma planes (uint8 buffer) -> float32 [nframes*nctu, 21]."""
+        luma = np.ascontiguousarray(luma, dtype=np.uint8)
+        pitch = width if pitch is None else pitch
+        frame_stride = pitch * height if frame_stride is None else frame_stride
+        need = (nframes - 1) * frame_stride + (height - 1) * pitch + width if nframes else 0
+        if luma.size < need:
+            raise ValueError("luma buffer too small: %d < %d" % (luma.size, need))
+        out = np.empty((nframes * ctus_per_frame(width, height), NOUT), dtype=np.float32)
+        self._chk(self.lib.ethcnn_predict_luma(self.h, luma.ctypes.data, width, height, pitch, frame_stride,
+                                               nframes, int(qp), out.ctypes.data_as(_fp)))
+        return out
+
+    def predict_luma_device(self, d_luma, width, height, nframes, qp, d_probs, pitch=None, frame_stride=None):
+        """Both pointers already in HBM (ints or DeviceBuffer); asynchronous."""
+        pitch = width if pitch is None else pitch
+        frame_stride = pitch * height if frame_stride is None else frame_stride
+        src = d_luma.ptr if isinstance(d_luma, DeviceBuffer) else int(d_luma)
+        dst = d_probs.ptr if isinstance(d_probs, DeviceBuffer) else int(d_probs)
+        self._chk(self.lib.ethcnn_predict_luma_device(self.h, src, width, height, pitch, frame_stride, nframes,
+                                                      int(qp), dst))
+
+    def predict_ctus(self, ctus, qp):
+        """[n,64,64] uint8 CTUs -> [n,21]; gates per <=1024-CTU sub-batch exactly like
+        get_y_conv_on_large_data (video_to_cu_depth.py:61-73): a 64-wide, 64n-tall 'frame'."""
+        ctus = np.ascontiguousarray(ctus, dtype=np.uint8).reshape(-1, 64, 64)
+        n = ctus.shape[0]
+        if n == 0:
+            return np.zeros((0, NOUT), dtype=np.float32)
+        return self.predict_luma(ctus.reshape(-1), 64, 64 * n, 1, qp)
+
+    def predict_yuv_file(self, yuv_path, width, height, qp, out_path):
+        nf = ctypes.c_int64(0)
+        self._chk(self.lib.ethcnn_predict_yuv_file(self.h, os.fsencode(yuv_path), width, height, int(qp),
+                                                   os.fsencode(out_path), ctypes.byref(nf)))
+        return nf.value
+
+    def resi_vectors(self, luma, width, height, pitch=None):
+        luma = np.ascontiguousarray(luma, dtype=np.uint8)
+        pitch = width if pitch is None else pitch
+        out = np.empty((ctus_per_frame(width, height), NVEC), dtype=np.float32)
+        self._chk(self.lib.ethcnn_resi_vectors(self.h, luma.ctypes.data, width, height, pitch, out.ctypes.data_as(_fp)))
+        return out
+
+    # -- measurement / introspection
+    def set_profiling(self, on=True):
+        self._chk(self.lib.ethcnn_set_profiling(self.h, 1 if on else 0))
+
+    def reset_stage_times(self):
+        self._chk(self.lib.ethcnn_reset_stage_times(self.h))
+
+    def stage_times(self):
+        st = StageTimes()
+        self._chk(self.lib.ethcnn_get_stage_times(self.h, ctypes.byref(st)))
+        return {"ms": dict(zip(STAGES, list(st.ms))), "launches": dict(zip(STAGES, list(st.launches))), "ctus": st.ctus}
+
+    def debug_fetch(self, which, n):
+        out = np.empty((n, _DBG_WIDTH[which]), dtype=np.float32)
+        self._chk(self.lib.ethcnn_debug_fetch(self.h, which, out.ctypes.data_as(_fp), out.size))
+        return out

@@ -1,0 +1,76 @@
+"""Host mirror of the reference's predictor driver
+(/root/reference/HM-16.5_Test_AI/bin/video_to_cu_depth.py): same command line, same files,
+same exit-status contract, so the unchanged HM hook
+(TAppEncCfg.cpp:2317-2321: system("python video_to_cu_depth.py <yuv> <w> <h> <qp>"))
+drives it.  Everything below the argument handling happens in libethcnn.so.
+
+Differences from the reference, all outside the numbers it produces:
+  * cu_depth.dat is written to a temp file and renamed (never a partial file);
+  * the YUV is streamed (luma only) instead of being tiled in Python;
+  * when the trained checkpoint blobs are absent (they are not in the reference repo),
+    ETHCNN_SYNTHETIC_SEED=<n> [ETHCNN_HEAD_GAIN=<g>] opts into seeded synthetic weights;
+    without it a missing checkpoint is an error (non-zero exit, HM aborts).
+"""
+from __future__ import print_function
+
+import os
+import sys
+import time
+
+from . import ethcnn as _e
+from . import net_CNN as nt
+
+NUM_CHANNELS = nt.NUM_CHANNELS
+NUM_EXT_FEATURES = nt.NUM_EXT_FEATURES
+NUM_LABEL_BYTES = nt.NUM_LABEL_BYTES
+IMAGE_SIZE = nt.IMAGE_SIZE
+SAVE_FILE = 'cu_depth.dat'   # video_to_cu_depth.py:20
+THR_FILE = 'Thr_info.txt'    # net_CNN.py:47
+
+
+def get_file_size(path):
+    return os.path.getsize(path)
+
+
+def get_y_conv_on_large_data(ctx, input_image, qp_seq):
+    """video_to_cu_depth.py:61-73: [n,64,64,1] -> [n,21], gates per <=1024-CTU sub-batch."""
+    return ctx.predict_ctus(input_image, qp_seq)
+
+
+def get_prob(ctx, yuv_name, image_size, save_file, qp_seq, n_frames_start, n_frames_end, frame_width, frame_height):
+    """video_to_cu_depth.py:75-118.  The reference always passes start=0, end=all frames."""
+    assert image_size == IMAGE_SIZE
+    frame_bytes = frame_width * frame_height * 3 // 2
+    total = get_file_size(yuv_name) // frame_bytes
+    if n_frames_start != 0 or n_frames_end != total:
+        raise ValueError("get_prob: only the reference's own call (all frames from 0) is supported")
+    return ctx.predict_yuv_file(yuv_name, frame_width, frame_height, qp_seq, save_file)
+
+
+def restore_model(ctx, qp_seq, model_dir='.'):
+    """video_to_cu_depth.py:126-133: QP band -> checkpoint prefix -> saver.restore."""
+    prefix = os.path.join(model_dir, _e.model_name_for_qp(qp_seq))
+    seed = os.environ.get('ETHCNN_SYNTHETIC_SEED')
+    if os.path.exists(prefix + '.data-00000-of-00001') or seed is None:
+        ctx.load_checkpoint(prefix)
+        return prefix
+    ctx.load_synthetic(int(seed), float(os.environ.get('ETHCNN_HEAD_GAIN', '1.0')))
+    return 'synthetic(seed=%s)' % seed
+
+
+def main(argv=None):
+    argv = sys.argv if argv is None else argv
+    assert len(argv) == 5                      # :120
+    yuv_file = argv[1]
+    width, height, qp_seq = int(argv[2]), int(argv[3]), int(argv[4])
+    ctx = _e.EthCnn(device=int(os.environ.get('ETHCNN_DEVICE', '0')))
+    ctx.load_thresholds(THR_FILE)              # net_CNN.py:47 (cwd-relative, at import time there)
+    restore_model(ctx, qp_seq)
+    t1 = time.time()
+    n_frames = get_prob(ctx, yuv_file, IMAGE_SIZE, SAVE_FILE, qp_seq, 0,
+                        get_file_size(yuv_file) // (width * height * 3 // 2), width, height)
+    t2 = time.time()
+    print('%s  frame %d/%d  %dx%d' % (yuv_file, n_frames, n_frames, width, height))
+    print('--------\n\nPredicting Time: %.3f sec.\n\n--------' % float(t2 - t1))  # :145
+    ctx.close()
+    return 0

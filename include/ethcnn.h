@@ -1,0 +1,163 @@
+/*
+ * ethcnn.h -- C ABI of libethcnn.so: MI355X-native ETH-CNN CU-partition predictor.
+ *
+ * Drop-in boundary for the reference's predictor step (all paths relative to
+ * /root/reference):
+ *
+ *   HM-16.5_Test_AI/source/App/TAppEncoder/TAppEncCfg.cpp:2317-2321
+ *       system("python video_to_cu_depth.py <yuv> <w> <h> <qp>"), assert(status == 0)
+ *   HM-16.5_Test_AI/bin/video_to_cu_depth.py  (driver: read YUV, tile, sub-batch, write)
+ *   HM-16.5_Test_AI/bin/net_CNN.py            (ETH-CNN graph + batch gates)
+ *   HM-16.5_Test_AI/source/Lib/TLibEncoder/TEncCu.cpp:237-261  (consumer of cu_depth.dat)
+ *
+ * The reference's boundary is a process boundary with files; there is no FFI in it.  The
+ * functions below are what a binding for this path binds: one entry per reference
+ * function on the path (cited per function).  Conventions: plain C types only, caller
+ * owns every buffer, 0 = success, negative = error (ethcnn_last_error() has the text),
+ * no exceptions cross the ABI, a context is not thread-safe (one per thread / per GPU).
+ *
+ * There is NO CPU fallback: every compute entry point runs hand-written HIP kernels on a
+ * gfx950 device and fails with ETHCNN_ERR_DEVICE if none is usable.
+ */
+#ifndef ETHCNN_H
+#define ETHCNN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ethcnn_ctx ethcnn_ctx;
+
+enum {
+    ETHCNN_OK = 0,
+    ETHCNN_ERR_ARG = -1,       /* bad argument */
+    ETHCNN_ERR_IO = -2,        /* file open/read/write failed */
+    ETHCNN_ERR_FORMAT = -3,    /* malformed checkpoint / Thr_info.txt / YUV size */
+    ETHCNN_ERR_DEVICE = -4,    /* no usable gfx950 device or a HIP call failed */
+    ETHCNN_ERR_NOWEIGHTS = -5, /* predict called before any ethcnn_load_* */
+    ETHCNN_ERR_NOMEM = -6
+};
+
+/* Geometry constants of the path (net_CNN.py:8-36). */
+#define ETHCNN_CTU 64
+#define ETHCNN_NOUT 21          /* 1 + 4 + 16 split probabilities per CTU            */
+#define ETHCNN_NFEAT 2688       /* NUM_CONVLAYER_FLAT_FILTERS                        */
+#define ETHCNN_NVEC 448         /* 64 + 128 + 256 (FC1 outputs; LDP VECTOR_LENGTH)   */
+#define ETHCNN_SUB_BATCH 1024   /* video_to_cu_depth.py:64 sub_batch_size (gate scope)*/
+#define ETHCNN_BLOB_FLOATS 1288210 /* 5,152,840-byte TF-V2 .data payload, fp32        */
+
+typedef struct ethcnn_options {
+    int device;            /* HIP device ordinal (default 0)                                 */
+    int max_ctus_per_pass; /* workspace size in CTUs; 0 = default (131072). Frames are never
+                              split across passes unless a single frame exceeds it.          */
+    int reserved[6];
+} ethcnn_options;
+
+/* ---- lifecycle (replaces tf.Session()/Saver construction, video_to_cu_depth.py:22-29) */
+int ethcnn_create(ethcnn_ctx** out, const ethcnn_options* opt /* may be NULL */);
+void ethcnn_destroy(ethcnn_ctx* ctx);
+const char* ethcnn_last_error(const ethcnn_ctx* ctx); /* ctx may be NULL: create() errors */
+const char* ethcnn_version(void);
+
+/* ---- weights (replaces saver.restore(sess, 'model_2000000_qpXX~YY.dat'),
+ *      video_to_cu_depth.py:126-133).  The "blob" is the payload of a TF-V2
+ *      .data-00000-of-00001 file: 36 fp32 tensors back to back in key order. */
+int ethcnn_load_checkpoint(ethcnn_ctx* ctx, const char* prefix); /* prefix.index + prefix.data-00000-of-00001, crc32c-checked */
+int ethcnn_load_blob(ethcnn_ctx* ctx, const float* blob, size_t nfloats);
+int ethcnn_load_synthetic(ethcnn_ctx* ctx, uint64_t seed, double head_gain); /* trained blobs are absent from the reference */
+int ethcnn_get_blob(const ethcnn_ctx* ctx, float* blob_out, size_t nfloats);
+/* QP band -> checkpoint prefix (qp<25, <30, <35, else): video_to_cu_depth.py:126-133. */
+int ethcnn_model_name_for_qp(int qp, char* out, size_t cap);
+
+/* ---- thresholds (replaces net_CNN.get_thresholds('Thr_info.txt'), net_CNN.py:38-47:
+ *      tokens [1] and [3] of the first line split on single spaces). */
+int ethcnn_load_thresholds(ethcnn_ctx* ctx, const char* thr_info_path);
+int ethcnn_parse_thresholds(const char* thr_info_path, float* thr_l1_lower, float* thr_l2_lower); /* no context / device needed */
+int ethcnn_set_thresholds(ethcnn_ctx* ctx, float thr_l1_lower, float thr_l2_lower);
+int ethcnn_get_thresholds(const ethcnn_ctx* ctx, float* thr_l1_lower, float* thr_l2_lower);
+
+/* ---- prediction.  Replaces get_prob() (video_to_cu_depth.py:75-118) =
+ *      get_Y_for_one_frame (:46-59) + tiling loop (:88-106) + get_y_conv_on_large_data
+ *      (:61-73) + net_CNN.net (net_CNN.py:103-195).
+ *      luma: 8-bit planes, `pitch` bytes between rows, `frame_stride` bytes between frames
+ *      (w*h*3/2 when pointing into a 4:2:0 file image).  probs: float32
+ *      [nframes][ceil(h/64)*ceil(w/64)][21], CTUs in raster order, row = [p64,p32[4],p16[16]]
+ *      -- the cu_depth.dat layout TEncCu::compressCtu freads (TEncCu.cpp:237-261). */
+int ethcnn_predict_luma_device(ethcnn_ctx* ctx, const uint8_t* d_luma, int width, int height,
+                               ptrdiff_t pitch, ptrdiff_t frame_stride, int nframes, int qp,
+                               float* d_probs); /* both pointers in HBM; asynchronous on the ctx stream */
+int ethcnn_predict_luma(ethcnn_ctx* ctx, const uint8_t* luma, int width, int height,
+                        ptrdiff_t pitch, ptrdiff_t frame_stride, int nframes, int qp,
+                        float* probs); /* host pointers; synchronous */
+/* Whole driver: all frames of the file from frame 0 (:135-140), writes `out_path`
+ * (temp file + rename: never a partial cu_depth.dat).  *nframes_out may be NULL. */
+int ethcnn_predict_yuv_file(ethcnn_ctx* ctx, const char* yuv_path, int width, int height, int qp,
+                            const char* out_path, int64_t* nframes_out);
+
+/* ---- config #5 front-end: resi_cnn (HM-16.5_Test_LDP/bin/net_CNN_LSTM_one_step.py:151-199)
+ *      fed as in resi_to_cu_depth_LDP.py:72-101.  One frame; vec = float32 [nctu][448]. */
+int ethcnn_resi_vectors_device(ethcnn_ctx* ctx, const uint8_t* d_luma, int width, int height,
+                               ptrdiff_t pitch, float* d_vec);
+int ethcnn_resi_vectors(ethcnn_ctx* ctx, const uint8_t* luma, int width, int height,
+                        ptrdiff_t pitch, float* vec);
+
+/* ---- device plumbing for callers without a HIP binding (ctypes, cgo, JNI ...) */
+int ethcnn_device_alloc(ethcnn_ctx* ctx, size_t bytes, void** out);
+int ethcnn_device_free(ethcnn_ctx* ctx, void* p);
+int ethcnn_memcpy_h2d(ethcnn_ctx* ctx, void* dst, const void* src, size_t bytes);
+int ethcnn_memcpy_d2h(ethcnn_ctx* ctx, void* dst, const void* src, size_t bytes);
+int ethcnn_synchronize(ethcnn_ctx* ctx);
+int ethcnn_device_name(const ethcnn_ctx* ctx, char* out, size_t cap);
+
+/* ---- measurement: per-stage kernel time from HIP events recorded on the ctx stream
+ *      (replaces the reference's only instrument, the 'Predicting Time' wall clock,
+ *      video_to_cu_depth.py:142-145). */
+enum {
+    ETHCNN_STAGE_TILE = 0,  /* k0: CTU load + zero-pad tiling + integer pooling (HBM-bound) */
+    ETHCNN_STAGE_TRUNK = 1, /* k1: mean removal + 3 conv stages x 21 units (MFMA)          */
+    ETHCNN_STAGE_FC1 = 2,   /* k2: [N,2688]x[2688,448] (MFMA) -- dominant kernel           */
+    ETHCNN_STAGE_FC2 = 3,   /* k3: three qp-conditioned FC2 layers (MFMA)                  */
+    ETHCNN_STAGE_HEAD = 4,  /* k4: FC3 + sigmoid + gate flags                              */
+    ETHCNN_STAGE_GATE = 5,  /* k5: batch-level gates (zero fill)                           */
+    ETHCNN_NSTAGES = 6
+};
+typedef struct ethcnn_stage_times {
+    double ms[ETHCNN_NSTAGES];       /* accumulated kernel time per stage since reset */
+    int64_t launches[ETHCNN_NSTAGES];
+    int64_t ctus;                    /* CTUs processed since reset */
+} ethcnn_stage_times;
+int ethcnn_set_profiling(ethcnn_ctx* ctx, int on); /* on: events around every launch */
+int ethcnn_get_stage_times(ethcnn_ctx* ctx, ethcnn_stage_times* out); /* synchronizes */
+int ethcnn_reset_stage_times(ethcnn_ctx* ctx);
+
+/* ---- parity-test introspection: intermediates of the LAST pass, copied to host. */
+enum {
+    ETHCNN_DBG_FEATURES = 0, /* [n][2688] h_conv_flat (net_CNN.py:150)          */
+    ETHCNN_DBG_FC1 = 1,      /* [n][448]  h_fc1_64|32|16 after leaky-ReLU       */
+    ETHCNN_DBG_FC2 = 2,      /* [n][336]  h_fc2_64|32|16 after leaky-ReLU       */
+    ETHCNN_DBG_LOGITS = 3,   /* [n][21]   pre-sigmoid                           */
+    ETHCNN_DBG_RAW_PROBS = 4 /* [n][21]   before the gates                      */
+};
+int ethcnn_debug_fetch(ethcnn_ctx* ctx, int which, float* host_out, size_t nfloats);
+
+/* ---- checkpoint introspection (the TF-V2 bundle reader on its own; used by the loader
+ *      above and by the known-answer tests against the reference's .index files). */
+typedef struct ethcnn_ckpt_entry {
+    char name[64];
+    int dtype, rank;       /* dtype 1 = DT_FLOAT */
+    int64_t shape[4];
+    int shard;
+    int64_t offset, size;  /* bytes, into <prefix>.data-<shard>-of-<n> */
+    uint32_t crc32c;       /* masked, as stored */
+} ethcnn_ckpt_entry;
+int ethcnn_ckpt_read_index(const char* index_path, ethcnn_ckpt_entry* entries, int cap, int* n_out,
+                           char* err, size_t errcap);
+uint32_t ethcnn_crc32c_masked(const void* data, size_t nbytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ETHCNN_H */

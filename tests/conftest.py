@@ -1,0 +1,45 @@
+import importlib
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+REFERENCE = "/root/reference"  # exists only in the build container, never on the GPU box
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    """The product package (hyphenated directory name -> importlib)."""
+    import __graft_entry__ as ge
+    lib = os.path.join(ROOT, "hevc-complexity-reduction_amd", "lib", "libethcnn.so")
+    if not os.path.exists(lib):
+        ge.build()
+    return importlib.import_module("hevc-complexity-reduction_amd")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import ethcnn_np
+    ethcnn_np.lib()  # builds oracle/_build/libethcnn_oracle.so if missing
+    return ethcnn_np
+
+
+@pytest.fixture(scope="session")
+def ctx(pkg):
+    """A GPU context; fails loudly (no fallback) when the HIP library or device is missing."""
+    c = pkg.EthCnn(device=0)
+    yield c
+    c.close()
+
+
+def have_reference():
+    return os.path.isdir(os.path.join(REFERENCE, "HM-16.5_Test_AI", "bin"))

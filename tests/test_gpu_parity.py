@@ -1,0 +1,144 @@
+"""-m gpu: the HIP path (through the C ABI) against the CPU oracle's canonical mode.
+Bar: bit-exact features / FC outputs / logits / probabilities / decisions (the kernels and
+the oracle share one summation order), and <= 1e-4 against the float64 restatement."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _mixed_ctus(rng, n):
+    ctus = rng.integers(0, 256, size=(n, 64, 64), dtype=np.uint8)
+    yy, xx = np.mgrid[0:64, 0:64]
+    k = n // 4
+    ctus[:k] = ((yy * 2 + xx)[None] + rng.integers(0, 8, size=(k, 64, 64))).clip(0, 255).astype(np.uint8)
+    ctus[k:2 * k] = rng.integers(0, 256, size=(k, 1, 1), dtype=np.uint8)  # flat blocks
+    if n > 3:
+        ctus[2 * k] = 0
+        ctus[2 * k + 1] = 255
+    return ctus
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("n,gain,qp", [(1, 1.0, 32), (37, 8.0, 22), (64, 1.0, 37), (333, 8.0, 27)])
+def test_stages_bit_exact(pkg, ctx, oracle, n, gain, qp):
+    e = pkg.ethcnn
+    rng = np.random.default_rng(100 + n)
+    blob = oracle.synth_blob(11, gain)
+    ctx.load_blob(blob)
+    ctx.set_thresholds(0.5, 0.5)
+    ctus = _mixed_ctus(rng, n)
+    got = ctx.predict_ctus(ctus, qp)
+    F = oracle.features(blob, ctus, mode=0)
+    H1 = oracle.fc1(blob, F)
+    P, Z = oracle.heads(blob, H1, qp)
+    gF = ctx.debug_fetch(e.DBG_FEATURES, n)
+    assert np.array_equal(_bits(gF), _bits(F)), "features: max |d| = %g" % np.abs(gF - F).max()
+    gH1 = ctx.debug_fetch(e.DBG_FC1, n)
+    assert np.array_equal(_bits(gH1), _bits(H1)), "fc1: max |d| = %g" % np.abs(gH1 - H1).max()
+    gZ = ctx.debug_fetch(e.DBG_LOGITS, n)
+    assert np.array_equal(_bits(gZ), _bits(Z)), "logits: max |d| = %g" % np.abs(gZ - Z).max()
+    gP = ctx.debug_fetch(e.DBG_RAW_PROBS, n)
+    assert np.array_equal(_bits(gP), _bits(P)), "probs: max |d| = %g" % np.abs(gP - P).max()
+    want = oracle.gates(P, 0.5, 0.5)
+    assert np.array_equal(_bits(got), _bits(want))
+    # tolerance the north star states (1e-4) against the independent float64 restatement
+    r = oracle.forward64(blob, ctus, qp)
+    assert np.abs(gP - r["probs"]).max() <= 1e-4
+    for thr in (0.5, 0.4, 0.6, 0.3, 0.7, 0.2, 0.8):  # Thr_info.txt values shipped by the reference
+        assert np.array_equal(gP > thr, P > thr)
+
+
+@pytest.mark.parametrize("w,h,frames", [(768, 512, 1), (200, 136, 2), (1920, 1080, 2), (72, 72, 1), (64, 64, 1), (4928, 3264, 1)])
+def test_frames_bit_exact(ctx, oracle, w, h, frames):
+    """Zero-padded raster tiling + per-frame 1024-CTU gate scope (4928x3264: 3927 CTUs =
+    3x1024 + 855; 72x72: every CTU ragged)."""
+    rng = np.random.default_rng(w * 7 + h)
+    blob = oracle.synth_blob(5, 8.0)
+    ctx.load_blob(blob)
+    ctx.set_thresholds(0.5, 0.5)
+    luma = rng.integers(0, 256, size=(frames, h, w), dtype=np.uint8)
+    luma[:, : h // 2] = (luma[:, : h // 2] // 32 + 90).astype(np.uint8)
+    got = ctx.predict_luma(luma, w, h, frames, 32)
+    want = oracle.predict_frames(blob, luma, w, h, frames, 32, 0.5, 0.5, mode=0)
+    assert np.array_equal(_bits(got), _bits(want)), "max |d| = %g" % np.abs(got - want).max()
+
+
+def test_unaligned_width_and_pitch(ctx, oracle):
+    """Width not a multiple of 16 and a padded pitch take the byte-wise load path."""
+    rng = np.random.default_rng(9)
+    blob = oracle.synth_blob(5, 1.0)
+    ctx.load_blob(blob)
+    w, h, pitch = 203, 77, 211
+    buf = rng.integers(0, 256, size=(h, pitch), dtype=np.uint8)
+    got = ctx.predict_luma(buf, w, h, 1, 30, pitch=pitch)
+    want = oracle.predict_frames(blob, buf, w, h, 1, 30, 0.5, 0.5, mode=0, pitch=pitch)
+    assert np.array_equal(_bits(got), _bits(want))
+
+
+@pytest.mark.parametrize("thr1,thr2", [(0.999999, 0.5), (0.0, 0.999999), (0.999999, -1.0), (0.5, 0.5)])
+def test_gates(ctx, oracle, thr1, thr2):
+    """Closed L1 gate, closed L2 gate, and the negative-threshold corner where a closed L1
+    gate still leaves L2 open (zeros > thr2)."""
+    rng = np.random.default_rng(21)
+    blob = oracle.synth_blob(2, 1.0)
+    ctx.load_blob(blob)
+    ctx.set_thresholds(thr1, thr2)
+    w, h = 64 * 40, 64 * 30  # 1200 CTUs: two sub-batches
+    luma = rng.integers(0, 256, size=(h, w), dtype=np.uint8)
+    got = ctx.predict_luma(luma, w, h, 1, 32)
+    want = oracle.predict_frames(blob, luma, w, h, 1, 32, thr1, thr2, mode=0)
+    assert np.array_equal(_bits(got), _bits(want))
+    if thr1 > 0.99:
+        assert not got[:, 1:5].any()
+    ctx.set_thresholds(0.5, 0.5)
+
+
+def test_resi_vectors(ctx, oracle):
+    """config #5 front-end (resi_cnn): residual preprocess, FC1 only."""
+    rng = np.random.default_rng(33)
+    blob = oracle.synth_blob(8, 1.0)
+    ctx.load_blob(blob)
+    w, h = 1920, 1080
+    resi = np.clip(np.rint(128 + rng.laplace(0, 6, size=(h, w))), 0, 255).astype(np.uint8)
+    got = ctx.resi_vectors(resi, w, h)
+    want = oracle.resi_vectors(blob, resi, w, h, mode=0)
+    assert np.array_equal(_bits(got), _bits(want)), "max |d| = %g" % np.abs(got - want).max()
+
+
+def test_multi_pass_and_device_entry(pkg, oracle):
+    """A small workspace forces several passes (frame groups, and a frame split on
+    sub-batch boundaries); results must not depend on the pass plan."""
+    rng = np.random.default_rng(44)
+    blob = oracle.synth_blob(6, 8.0)
+    w, h, frames = 64 * 45, 64 * 30, 3  # 1350 CTUs per frame > 1024
+    luma = rng.integers(0, 256, size=(frames, h, w), dtype=np.uint8)
+    want = oracle.predict_frames(blob, luma, w, h, frames, 32, 0.5, 0.5, mode=0)
+    for cap in (1024, 2048, 0):
+        c = pkg.EthCnn(device=0, max_ctus_per_pass=cap)
+        c.load_blob(blob)
+        d_in = c.alloc(luma.nbytes)
+        d_out = c.alloc(want.nbytes)
+        d_in.upload(luma)
+        c.predict_luma_device(d_in, w, h, frames, 32, d_out)
+        c.synchronize()
+        got = d_out.download(np.float32, want.size).reshape(want.shape)
+        assert np.array_equal(_bits(got), _bits(want)), "cap=%d" % cap
+        d_in.free()
+        d_out.free()
+        c.close()
+
+
+def test_synthetic_generator_matches_python(ctx, oracle):
+    ctx.load_synthetic(1234, 8.0)
+    assert np.array_equal(_bits(ctx.get_blob()), _bits(oracle.synth_blob(1234, 8.0)))
+
+
+def test_errors_are_loud(pkg, ctx):
+    with pytest.raises(pkg.EthCnnError):
+        pkg.EthCnn(device=0).predict_luma(np.zeros((64, 64), np.uint8), 64, 64, 1, 32)  # no weights
+    with pytest.raises(pkg.EthCnnError):
+        ctx.load_blob(np.zeros(10, np.float32))

@@ -1,0 +1,19 @@
+#!/usr/bin/env python
+"""Drop-in launcher: copy or symlink this file into HM's bin/ directory (next to
+TAppEncoderStatic, Thr_info.txt and the model files).  HM's unchanged hook runs
+`python video_to_cu_depth.py <yuv> <w> <h> <qp>` there (TAppEncCfg.cpp:2317-2321).
+Set ETHCNN_HOME to the repository root if this file is copied rather than symlinked."""
+import importlib
+import os
+import sys
+
+_home = os.environ.get("ETHCNN_HOME") or os.path.dirname(os.path.realpath(__file__))
+sys.path.insert(0, _home)
+try:
+    _pkg = importlib.import_module("hevc-complexity-reduction_amd")
+    sys.exit(_pkg.video_to_cu_depth.main(sys.argv))
+except SystemExit:
+    raise
+except BaseException as exc:  # any failure must reach HM as a non-zero exit status
+    sys.stderr.write("video_to_cu_depth: %s: %s\n" % (type(exc).__name__, exc))
+    sys.exit(1)
