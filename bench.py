@@ -1,0 +1,203 @@
+#!/usr/bin/env python
+"""bench.py -- CTUs/sec of ETH-CNN inference (BASELINE.json metric) on N MI355X GPUs.
+
+A "step" = one pass of the whole hot path (k0 tile -> k1 trunk -> FC1 -> FC2 -> head ->
+gates) over one batch of synthetic luma frames ALREADY RESIDENT IN HBM, producing the
+cu_depth.dat payload in HBM.  Default workload = BASELINE.json configs[1]
+("All-Intra 1920x1080 QP32, 50 frames synthetic YUV"); --workload picks another config.
+N > 1: frames shard across ranks with no data-path collective (weak scaling: every rank
+runs the same per-GPU workload on its own frames); torch.distributed is used only for the
+timing barrier and the max-over-ranks reduction.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      dominant kernel = FC1 (77.6 % of the MACs): algorithmic FLOP / HIP-event
+                kernel time vs the fp32-MFMA peak of MI355X_MICROARCH.md (157.3 TFLOP/s)
+  cpu_baseline  the CPU oracle (a port of the reference's TF-CPU path; TensorFlow itself
+                cannot run here) timed on the host cores on a bounded sample
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {  # BASELINE.json configs
+    "c1": dict(width=768, height=512, frames=1, qp=32, name="All-Intra 768x512 QP32, 1 frame"),
+    "c2": dict(width=1920, height=1080, frames=50, qp=32, name="All-Intra 1920x1080 QP32, 50 frames synthetic YUV"),
+    "c3": dict(width=3840, height=2160, frames=50, qp=32, name="All-Intra 3840x2160 QP32, 50 frames synthetic YUV"),
+    "c4": dict(width=4928, height=3264, frames=54, qp=27, name="All-Intra 4928x3264 QP27, 54 frames (one GPU's 1/8 share of 425)"),
+}
+MAC_PER_CTU = 1552149          # conv 279,552 + FC1 1,204,224 + FC2 64,848 + FC3 3,525
+FC1_FLOP_PER_CTU = 2 * 1204224
+ALG_BYTES_PER_CTU = 4096 + 84  # u8 luma in + 21 fp32 out
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32
+PEAK_HBM_GBPS = 8000.0
+
+
+def synth_luma(width, height, frames, seed):
+    """Seeded synthetic 8-bit luma: 256x256 macro-tiles cycling smooth gradient / blurred
+    noise / flat blocks / full-range noise, so CTUs span easy -> hard."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    out = np.empty((frames, height, width), dtype=np.uint8)
+    yy, xx = np.mgrid[0:height, 0:width]
+    kind = ((yy // 256) + (xx // 256)) % 4
+    grad = ((yy * 3 + xx * 2) // 8) % 256
+    flat = (((yy // 16) * 31 + (xx // 16) * 17) % 200 + 20)
+    for f in range(frames):
+        noise = rng.integers(0, 256, size=(height, width), dtype=np.uint8)
+        blur = noise.astype(np.uint16)
+        blur = (blur + np.roll(blur, 1, 0) + np.roll(blur, 1, 1) + np.roll(np.roll(blur, 1, 0), 1, 1)) // 4
+        frame = np.where(kind == 0, (grad + f) % 256, np.where(kind == 1, blur, np.where(kind == 2, flat, noise)))
+        out[f] = frame.astype(np.uint8)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch  # first: both torch and libethcnn bind libamdhip64.so.7 -> one HIP runtime in the process
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (libethcnn has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize()
+
+    pkg = importlib.import_module("hevc-complexity-reduction_amd")
+    wl = WORKLOADS[args.workload]
+    W, H, NF, QP = wl["width"], wl["height"], wl["frames"], wl["qp"]
+    nctu = pkg.ethcnn.ctus_per_frame(W, H)
+    ctus_per_step = nctu * NF
+
+    ctx = pkg.EthCnn(device=local_rank)
+    ctx.load_synthetic(seed=1, head_gain=8.0)
+    ctx.set_thresholds(0.5, 0.5)  # shipped Thr_info.txt
+    luma = synth_luma(W, H, NF, seed=0xE7C00000 + 2 + 1000 * rank)
+    d_in = ctx.alloc(luma.nbytes)
+    d_out = ctx.alloc(ctus_per_step * 21 * 4)
+    d_in.upload(luma)
+
+    def step():
+        ctx.predict_luma_device(d_in, W, H, NF, QP, d_out)
+
+    for _ in range(args.warmup):
+        step()
+    ctx.synchronize()
+    ctx.set_profiling(True)
+    ctx.reset_stage_times()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    st = ctx.stage_times()
+    ctx.set_profiling(False)
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    result = None
+    if rank == 0:
+        total_ctus = ctus_per_step * args.steps * world
+        value = total_ctus / elapsed
+        fc1_ms = st["ms"]["fc1"] / max(1, st["launches"]["fc1"])
+        ctus_per_launch = st["ctus"] / max(1, st["launches"]["fc1"])
+        fc1_tflops = FC1_FLOP_PER_CTU * ctus_per_launch / (fc1_ms * 1e-3) / 1e12 if fc1_ms > 0 else 0.0
+        tile_ms = st["ms"]["tile"] / max(1, st["launches"]["tile"])
+        tile_gbps = 4096.0 * ctus_per_launch / (tile_ms * 1e-3) / 1e9 if tile_ms > 0 else 0.0
+        kernel_ms = sum(st["ms"].values()) / args.steps
+        result = {
+            "metric": "CTUs/sec (ETH-CNN inference)", "value": value, "unit": "CTU/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (seeded luma frames resident in HBM; seeded synthetic weights -- trained blobs absent from the reference)",
+            "config": {"workload": wl["name"], "width": W, "height": H, "frames_per_gpu": NF, "qp": QP,
+                       "ctus_per_step_per_gpu": ctus_per_step, "sharding": "frame ranges, no collective",
+                       "device": ctx.device_name},
+            "roofline": {"kernel": "k_dense<4,7,1,4,16> (FC1 [N,2688]x[2688,448], v_mfma_f32_16x16x4_f32)",
+                         "bound": "mfma", "achieved": fc1_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": fc1_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "avg_launch_ms": fc1_ms, "ctus_per_launch": ctus_per_launch,
+                         "flop_per_ctu": FC1_FLOP_PER_CTU},
+            "stages_ms_per_step": {k: v / args.steps for k, v in st["ms"].items()},
+            "kernel_ms_per_step": kernel_ms,
+            "whole_path_tflops": 2.0 * MAC_PER_CTU * ctus_per_step / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0,
+            "ctu_load_stage": {"kernel": "k0_tile", "bound": "hbm", "achieved": tile_gbps, "peak": PEAK_HBM_GBPS,
+                               "unit": "GB/s", "frac": tile_gbps / PEAK_HBM_GBPS, "avg_launch_ms": tile_ms,
+                               "algorithmic_bytes_per_ctu": 4096},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(luma, W, H, QP, args.cpu_seconds)
+        # sanity: the benchmark output is the real thing (first frame vs oracle), outside the timed region
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import ethcnn_np as oracle
+            got = d_out.download(np.float32, nctu * 21).reshape(nctu, 21)
+            want = oracle.predict_frames(ctx.get_blob(), luma[0], W, H, 1, QP, 0.5, 0.5, mode=0)
+            result["parity_first_frame_bit_exact"] = bool(np.array_equal(got.view(np.uint32), want.view(np.uint32)))
+        except Exception as exc:  # the oracle is a checker only; never fatal for the measurement
+            result["parity_first_frame_bit_exact"] = "unchecked: %s" % exc
+        print(json.dumps(result))
+        sys.stdout.flush()
+    d_in.free()
+    d_out.free()
+    ctx.close()
+    if dist is not None:
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+    return 0
+
+
+def cpu_baseline(luma, W, H, QP, target_seconds):
+    """The oracle (C port of the reference's CPU path, OpenMP over CTUs) on the host cores:
+    same scope as the GPU step (frames in memory -> probabilities in memory)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ethcnn_np as oracle
+    cores = os.cpu_count() or 1
+    blob = oracle.synth_blob(1, 8.0)
+    nctu = ((W + 63) // 64) * ((H + 63) // 64)
+    t0 = time.perf_counter()
+    oracle.predict_frames(blob, luma[0], W, H, 1, QP, 0.5, 0.5, mode=0)
+    one = time.perf_counter() - t0
+    nf = int(max(1, min(luma.shape[0], round(target_seconds / max(one, 1e-6)))))
+    t0 = time.perf_counter()
+    oracle.predict_frames(blob, luma[:nf], W, H, nf, QP, 0.5, 0.5, mode=0)
+    dt = time.perf_counter() - t0
+    return {"value": nf * nctu / dt, "unit": "CTU/s", "cores": cores, "kind": "port",
+            "sample": "%d frame(s) of the same %dx%d workload (%d CTUs), oracle/ethcnn_oracle.c canonical mode, "
+                      "OpenMP over CTUs, %.1f s" % (nf, W, H, nf * nctu, dt)}
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -21,6 +21,8 @@
 // -ffp-contract=off: the operation sequence below is the contract.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "ethcnn_kernels.h"
 
 namespace ethcnn {
@@ -362,26 +364,43 @@ void launch_trunk(const Workspace& ws, const DeviceWeights& w, int n, bool resi,
 // ====================================================================== k_dense ======
 // out[m][n] = lrelu( sum_k A[m][k] W[k][n]  (+ qn * W[K][n])  + bias[n] )
 // Block = WM x WN waves; wave tile = (16 MS) x (16 NS); block tile BM = 16 MS WM rows,
-// BN = 16 NS WN columns (== all columns of the layer).  K is consumed in BK-wide chunks
-// staged through LDS (register-staged double buffer, one barrier per chunk); each
-// accumulator is ONE ascending-k MFMA chain (no split-K), which is the canonical order.
-template <int MS, int NS, int WM, int WN, int BK, bool QP>
+// BN = 16 NS WN columns.  NSPLIT blocks share one M tile, each owning BN of the layer's
+// NSPLIT*BN columns; the column block is blockIdx.x % NSPLIT, so (dispatcher places block b
+// on XCD b % 8) every XCD only ever touches 1/NSPLIT of W and that slice stays resident in
+// its private 4 MiB L2 (the full FC1 matrix, 4.8 MB, does not fit).  Speed only: results do
+// not depend on placement.  K is consumed in BK-wide chunks staged through LDS
+// (register-staged double buffer, one barrier per chunk); each accumulator is ONE
+// ascending-k MFMA chain (no split-K), which is the canonical order.
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+template <int MS, int NS, int WM, int WN, int BK, int NSPLIT, bool QP>
 __global__ __launch_bounds__(64 * WM * WN) void k_dense(const float* __restrict__ A, int lda, int K,
                                                         const float* __restrict__ W, const float* __restrict__ bias,
                                                         float qn, float* __restrict__ out, int ldo, int M) {
-    constexpr int NT = 64 * WM * WN;
+    constexpr int NW = WM * WN, NT = 64 * NW;
     constexpr int BM = 16 * MS * WM, BN = 16 * NS * WN;
-    constexpr int AP = BK + 1;    // A tile row pitch (floats): conflict-free column reads
-    constexpr int BP = BN + 16;   // B tile row pitch: k-groups g=0,1 land on different bank halves
-    constexpr int A_F4 = BM * BK / 4, B_F4 = BK * BN / 4;
-    constexpr int A_PER = (A_F4 + NT - 1) / NT, B_PER = (B_F4 + NT - 1) / NT;
-    __shared__ float As[2][BM * AP];
-    __shared__ float Bs[2][BK * BP];
+    constexpr int LDW = BN * NSPLIT;  // row stride of W == number of columns of the layer
+    constexpr int AP = BK + 1;        // A tile row pitch (floats): conflict-free column reads
+    // B tile: LINEAR [BK][BN] image (what global_load_lds writes: wave-uniform base + 16 B x
+    // lane).  When BN % 32 == 0 the two k-groups of a 32-lane half (g = 0,1) would hit the
+    // same banks, so odd k rows are stored with adjacent 16-column groups swapped: the
+    // permutation is applied to the per-lane GLOBAL address and undone on the ds_read.
+    constexpr bool SWZ = (BN % 32 == 0);
+    constexpr int A_F4 = BM * BK / 4, A_PER = (A_F4 + NT - 1) / NT;
+    constexpr int B_INST = BK * BN / 256;               // 1 KiB wave-instructions per B tile
+    constexpr int B_PER = (B_INST + NW - 1) / NW;       // per wave
+    constexpr int A_FLOATS = BM * AP, B_FLOATS = BK * BN;
+    constexpr int BUF = (A_FLOATS + B_FLOATS + 3) / 4 * 4;
+    // one LDS object only (a second __shared__ array makes hipcc drain vmcnt before every ds_read)
+    __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm = wv / WN, wn = wv % WN;
     const int col = lane & 15, g = lane >> 4;
-    const int m0 = blockIdx.x * BM;
+    const int nb = (NSPLIT > 1) ? (int)(blockIdx.x % NSPLIT) : 0;
+    const int m0 = (int)(blockIdx.x / NSPLIT) * BM;
+    const int n0 = nb * BN;
 
     f32x4 acc[MS][NS];
 #pragma unroll
@@ -389,78 +408,88 @@ __global__ __launch_bounds__(64 * WM * WN) void k_dense(const float* __restrict_
 #pragma unroll
         for (int j = 0; j < NS; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    float4 ra[A_PER], rb[B_PER];
-    auto gload = [&](int kc) {
+    // A tile: register staged (rows beyond M clamp to M-1: loaded, never stored)
+    float4 ra[A_PER];
+    const float* a_src[A_PER];
 #pragma unroll
-        for (int i = 0; i < A_PER; ++i) {
-            const int e = tid + i * NT;
-            ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < A_F4) {
-                const int row = e / (BK / 4), k4 = e % (BK / 4);
-                if (m0 + row < M) ra[i] = *reinterpret_cast<const float4*>(A + (size_t)(m0 + row) * lda + kc * BK + k4 * 4);
-            }
-        }
+    for (int i = 0; i < A_PER; ++i) {
+        const int e = tid + i * NT;
+        const int row = (e / (BK / 4)) % BM, k4 = e % (BK / 4);
+        a_src[i] = A + (size_t)min(m0 + row, M - 1) * lda + k4 * 4;
+    }
+    // B tile: wave wv issues instructions wv, wv + NW, ...; instruction q covers float4
+    // indices [64 q, 64 q + 63] of the linear tile
+    const float* b_src[B_PER];
 #pragma unroll
-        for (int i = 0; i < B_PER; ++i) {
-            const int e = tid + i * NT;
-            if (e < B_F4) {
-                const int row = e / (BN / 4), c4 = e % (BN / 4);
-                rb[i] = *reinterpret_cast<const float4*>(W + (size_t)(kc * BK + row) * BN + c4 * 4);
-            }
-        }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < A_PER; ++i) {
-            const int e = tid + i * NT;
-            if (e < A_F4) {
-                const int row = e / (BK / 4), k4 = e % (BK / 4);
-                float* d = &As[buf][row * AP + k4 * 4];
-                d[0] = ra[i].x; d[1] = ra[i].y; d[2] = ra[i].z; d[3] = ra[i].w;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < B_PER; ++i) {
-            const int e = tid + i * NT;
-            if (e < B_F4) {
-                const int row = e / (BN / 4), c4 = e % (BN / 4);
-                *reinterpret_cast<float4*>(&Bs[buf][row * BP + c4 * 4]) = rb[i];
-            }
-        }
-    };
+    for (int i = 0; i < B_PER; ++i) {
+        const int e = (wv + i * NW) * 64 + lane;  // float4 index in the tile
+        const int row = (e / (BN / 4)) % BK;
+        int c4 = e % (BN / 4);
+        if (SWZ) c4 ^= (row & 1) << 2;
+        b_src[i] = W + (size_t)row * LDW + n0 + c4 * 4;
+    }
+#define DENSE_GLOAD(kc, buf)                                                                          \
+    {                                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < A_PER; ++i)                                             \
+            ra[i] = *reinterpret_cast<const float4*>(a_src[i] + (size_t)(kc) * BK);                   \
+        _Pragma("unroll") for (int i = 0; i < B_PER; ++i) {                                           \
+            if ((i + 1) * NW <= B_INST || wv + i * NW < B_INST)                                       \
+                __builtin_amdgcn_global_load_lds((glb_void*)(b_src[i] + (size_t)(kc) * BK * LDW),     \
+                                                 (lds_void*)(smem + (buf) * BUF + A_FLOATS + (wv + i * NW) * 256), \
+                                                 16, 0, 0);                                           \
+        }                                                                                             \
+    }
+#define DENSE_ASTORE(buf)                                                                             \
+    {                                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < A_PER; ++i) {                                           \
+            const int e = tid + i * NT;                                                               \
+            if ((i + 1) * NT <= A_F4 || e < A_F4) {                                                   \
+                const int row = e / (BK / 4), k4 = e % (BK / 4);                                      \
+                float* d = smem + (buf) * BUF + row * AP + k4 * 4;                                    \
+                d[0] = ra[i].x; d[1] = ra[i].y; d[2] = ra[i].z; d[3] = ra[i].w;                       \
+            }                                                                                         \
+        }                                                                                             \
+    }
 
     const int nk = K / BK;
-    gload(0);
-    lstore(0);
-    __syncthreads();
+    DENSE_GLOAD(0, 0);
+    DENSE_ASTORE(0);
+    __syncthreads();  // (hipcc drains vmcnt here: the LDS-DMA of chunk 0 has landed)
+    const int b_col = wn * 16 * NS + col;
     for (int kc = 0; kc < nk; ++kc) {
         const int buf = kc & 1;
-        if (kc + 1 < nk) gload(kc + 1);
-        const float* as = &As[buf][(wm * 16 * MS + col) * AP + g];
-        const float* bs = &Bs[buf][g * BP + wn * 16 * NS + col];
+        if (kc + 1 < nk) DENSE_GLOAD(kc + 1, buf ^ 1);  // in flight during the MFMAs below
+        const float* as = smem + buf * BUF + (wm * 16 * MS + col) * AP + g;
+        const float* bs = smem + buf * BUF + A_FLOATS + g * BN;
 #pragma unroll
         for (int kq = 0; kq < BK / 4; ++kq) {
             float a[MS], b[NS];
 #pragma unroll
             for (int i = 0; i < MS; ++i) a[i] = as[i * 16 * AP + kq * 4];
 #pragma unroll
-            for (int j = 0; j < NS; ++j) b[j] = bs[kq * 4 * BP + j * 16];
+            for (int j = 0; j < NS; ++j) {
+                int c = b_col + j * 16;
+                if (SWZ) c ^= (g & 1) << 4;  // row k = 4 kq + g is odd iff g is odd
+                b[j] = bs[kq * 4 * BN + c];
+            }
 #pragma unroll
             for (int i = 0; i < MS; ++i)
 #pragma unroll
                 for (int j = 0; j < NS; ++j) acc[i][j] = MFMA16(a[i], b[j], acc[i][j]);
         }
-        if (kc + 1 < nk) lstore(buf ^ 1);
+        if (kc + 1 < nk) DENSE_ASTORE(buf ^ 1);
         __syncthreads();
     }
+#undef DENSE_GLOAD
+#undef DENSE_ASTORE
 
     // epilogue: C layout row = 4g + r, col = lane & 15
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
-        const int n = wn * 16 * NS + j * 16 + col;
+        const int n = n0 + wn * 16 * NS + j * 16 + col;
         const float bv = bias[n];
         float wq = 0.f;
-        if (QP) wq = W[(size_t)K * BN + n];
+        if (QP) wq = W[(size_t)K * LDW + n];
 #pragma unroll
         for (int i = 0; i < MS; ++i)
 #pragma unroll
@@ -474,20 +503,54 @@ __global__ __launch_bounds__(64 * WM * WN) void k_dense(const float* __restrict_
     }
 }
 
+template <int MS, int NS, int WM, int WN, int BK, int NSPLIT, bool QP>
+static void launch_dense(const float* A, int lda, int K, const float* W, const float* bias, float qn, float* out,
+                         int ldo, int M, hipStream_t s) {
+    constexpr int BM = 16 * MS * WM;
+    hipLaunchKernelGGL((k_dense<MS, NS, WM, WN, BK, NSPLIT, QP>), dim3(((M + BM - 1) / BM) * NSPLIT),
+                       dim3(64 * WM * WN), 0, s, A, lda, K, W, bias, qn, out, ldo, M);
+}
+
+static int fc1_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("ETHCNN_FC1_VARIANT");  // development knob: tile-shape A/B runs
+        v = e ? atoi(e) : 6;  // measured best on MI355X (profiles/r01_fc1_variants.txt)
+    }
+    return v;
+}
+
 void launch_fc1(const Workspace& ws, const DeviceWeights& w, int n, float* out, hipStream_t s) {
-    // BM = 64, BN = 448 (7 x 16 per wave x 4 waves), BK = 16: 66.6 KB LDS -> 2 blocks / CU
-    hipLaunchKernelGGL((k_dense<4, 7, 1, 4, 16, false>), dim3((n + 63) / 64), dim3(256), 0, s, ws.feat, kNFeat,
-                       kNFeat, w.fc1_w, w.fc1_b, 0.0f, out, kNVec, n);
+    const float* A = ws.feat;
+    switch (fc1_variant()) {
+        case 0:  // BM 64 x BN 448, BK 16, 4 waves
+            launch_dense<4, 7, 1, 4, 16, 1, false>(A, kNFeat, kNFeat, w.fc1_w, w.fc1_b, 0.f, out, kNVec, n, s);
+            break;
+        case 1:  // BM 128 x BN 224 (N split 2), 4 waves
+            launch_dense<4, 7, 2, 2, 16, 2, false>(A, kNFeat, kNFeat, w.fc1_w, w.fc1_b, 0.f, out, kNVec, n, s);
+            break;
+        case 2:  // BM 256 x BN 224 (N split 2), 8 waves
+            launch_dense<4, 7, 4, 2, 16, 2, false>(A, kNFeat, kNFeat, w.fc1_w, w.fc1_b, 0.f, out, kNVec, n, s);
+            break;
+        case 3:  // BM 256 x BN 112 (N split 4), 4 waves
+            launch_dense<4, 7, 4, 1, 16, 4, false>(A, kNFeat, kNFeat, w.fc1_w, w.fc1_b, 0.f, out, kNVec, n, s);
+            break;
+        case 4:  // BM 128 x BN 448, 8 waves
+            launch_dense<4, 7, 2, 4, 16, 1, false>(A, kNFeat, kNFeat, w.fc1_w, w.fc1_b, 0.f, out, kNVec, n, s);
+            break;
+        case 5:  // BM 128 x BN 224, BK 32
+            launch_dense<4, 7, 2, 2, 32, 2, false>(A, kNFeat, kNFeat, w.fc1_w, w.fc1_b, 0.f, out, kNVec, n, s);
+            break;
+        default:  // 6: BM 128 x BN 112 (N split 4), wave 32 x 112, 4 waves, ~4 blocks / CU
+            launch_dense<2, 7, 4, 1, 16, 4, false>(A, kNFeat, kNFeat, w.fc1_w, w.fc1_b, 0.f, out, kNVec, n, s);
+            break;
+    }
 }
 
 void launch_fc2(const Workspace& ws, const DeviceWeights& w, int n, float qn, hipStream_t s) {
-    const int gb = (n + 63) / 64;
-    hipLaunchKernelGGL((k_dense<1, 3, 4, 1, 16, true>), dim3(gb), dim3(256), 0, s, ws.h1 + kO1[0], kNVec, kN1[0],
-                       w.fc2_w[0], w.fc2_b[0], qn, ws.h2 + kO2[0], kNFc2, n);
-    hipLaunchKernelGGL((k_dense<2, 3, 2, 2, 16, true>), dim3(gb), dim3(256), 0, s, ws.h1 + kO1[1], kNVec, kN1[1],
-                       w.fc2_w[1], w.fc2_b[1], qn, ws.h2 + kO2[1], kNFc2, n);
-    hipLaunchKernelGGL((k_dense<4, 3, 1, 4, 16, true>), dim3(gb), dim3(256), 0, s, ws.h1 + kO1[2], kNVec, kN1[2],
-                       w.fc2_w[2], w.fc2_b[2], qn, ws.h2 + kO2[2], kNFc2, n);
+    launch_dense<1, 3, 4, 1, 16, 1, true>(ws.h1 + kO1[0], kNVec, kN1[0], w.fc2_w[0], w.fc2_b[0], qn, ws.h2 + kO2[0], kNFc2, n, s);
+    launch_dense<2, 3, 2, 2, 16, 1, true>(ws.h1 + kO1[1], kNVec, kN1[1], w.fc2_w[1], w.fc2_b[1], qn, ws.h2 + kO2[1], kNFc2, n, s);
+    launch_dense<4, 3, 1, 4, 16, 1, true>(ws.h1 + kO1[2], kNVec, kN1[2], w.fc2_w[2], w.fc2_b[2], qn, ws.h2 + kO2[2], kNFc2, n, s);
 }
 
 // =========================================================================== k4 ======
