@@ -554,7 +554,7 @@ void launch_fc2(const Workspace& ws, const DeviceWeights& w, int n, float qn, hi
 }
 
 // =========================================================================== k4 ======
-// FC3 + sigmoid.  One thread per (CTU, output j): 12 CTUs per 256-thread block.
+// FC3 + sigmoid + gate predicates.
 __device__ __forceinline__ float expf_canonical(float x) {
     x = fminf(x, 80.0f);
     x = fmaxf(x, -86.0f);
@@ -582,38 +582,63 @@ __device__ __forceinline__ long global_chunk(long gn, int nctu, int cpf) {
     return f * cpf + (gn - f * nctu) / kSubBatch;
 }
 
+// One wave = 16 CTUs.  Per head: D[ctu][j] = sum_k H2[ctu][k] W3[k][j] as one 16x16 MFMA
+// tile (n3 = 1 / 4 / 16 real columns, the rest zero), K = 48 / 96 / 192 ascending -- the
+// canonical chain -- then the qp column, bias and sigmoid in the epilogue.  The three
+// heads' chains are independent and interleaved.
 __global__ __launch_bounds__(256) void k4_head(const float* __restrict__ H2, HeadParams hp, float qn, int N,
                                                int nctu, int cpf, long ctu0, float thr1, float thr2,
                                                float* __restrict__ logits, float* __restrict__ raw,
                                                float* __restrict__ probs, int* __restrict__ flags) {
-    const int t = threadIdx.x;
-    const int i = blockIdx.x * 12 + t / kNOut, j = t % kNOut;
-    const bool active = (t < 12 * kNOut) && (i < N);
-    int which = -1;
-    long chunk = 0;
-    if (active) {
-        const int h = (j == 0) ? 0 : (j < 5 ? 1 : 2);
-        const int c = j - (h == 0 ? 0 : (h == 1 ? 1 : 5));
-        const int n2 = (h == 0) ? 48 : (h == 1 ? 96 : 192);
-        const int n3 = (h == 0) ? 1 : (h == 1 ? 4 : 16);
-        const int o2 = (h == 0) ? 0 : (h == 1 ? 48 : 144);
-        const float* x = H2 + (size_t)i * kNFc2 + o2;
-        const float* w = hp.w3[h];
-        float z = 0.0f;
-        for (int k = 0; k < n2; ++k) z = fmaf(x[k], w[k * n3 + c], z);
-        z = fmaf(qn, w[n2 * n3 + c], z) + hp.b3[h][c];
-        const float p = 1.0f / (1.0f + expf_canonical(-z));
-        logits[(size_t)i * kNOut + j] = z;
-        raw[(size_t)i * kNOut + j] = p;
-        probs[(size_t)i * kNOut + j] = p;
-        if (h == 0 && p > thr1) which = 0;            // any(y64 > THR_L1_LOWER)
-        else if (h == 1 && p > thr2) which = 1;       // any(y32_tmp > THR_L2_LOWER)
-        chunk = global_chunk(ctu0 + i, nctu, cpf) - global_chunk(ctu0, nctu, cpf);
+    const int lane = threadIdx.x & 63, col = lane & 15, g = lane >> 4;
+    const int group = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int base = group * 16;
+    if (base >= N) return;
+    const int arow = min(base + col, N - 1);  // A operand row (clamped: loaded, never stored)
+    const float* x = H2 + (size_t)arow * kNFc2 + g;
+    f32x4 acc[3] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    constexpr int N2[3] = {48, 96, 192}, N3[3] = {1, 4, 16}, O2[3] = {0, 48, 144}, O3[3] = {0, 1, 5};
+#pragma unroll 4
+    for (int s = 0; s < 48; ++s) {  // 48 k-steps cover head16; head32 uses the first 24, head64 the first 12
+        const int k = 4 * s + g;
+        {
+            const float b = hp.w3[2][k * 16 + col];
+            acc[2] = MFMA16(x[O2[2] + 4 * s], b, acc[2]);
+        }
+        if (s < 24) {
+            const float b = (col < 4) ? hp.w3[1][k * 4 + col] : 0.0f;
+            acc[1] = MFMA16(x[O2[1] + 4 * s], b, acc[1]);
+        }
+        if (s < 12) {
+            const float b = (col < 1) ? hp.w3[0][k] : 0.0f;
+            acc[0] = MFMA16(x[O2[0] + 4 * s], b, acc[0]);
+        }
     }
-    if (which >= 0) {
-        int* f = flags + 2 * chunk + which;
-        if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
-            __hip_atomic_store(f, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long chunk0 = global_chunk(ctu0, nctu, cpf);
+#pragma unroll
+    for (int h = 0; h < 3; ++h) {
+        if (col < N3[h]) {
+            const float wq = hp.w3[h][N2[h] * N3[h] + col], bv = hp.b3[h][col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = base + 4 * g + r;
+                if (i < N) {
+                    const float z = fmaf(qn, wq, acc[h][r]) + bv;
+                    const float p = 1.0f / (1.0f + expf_canonical(-z));
+                    const size_t o = (size_t)i * kNOut + O3[h] + col;
+                    logits[o] = z;
+                    raw[o] = p;
+                    probs[o] = p;
+                    // any(y64 > THR_L1_LOWER) / any(y32_tmp > THR_L2_LOWER) over the sub-batch
+                    const bool hit = (h == 0 && p > thr1) || (h == 1 && p > thr2);
+                    if (hit) {
+                        int* f = flags + 2 * (global_chunk(ctu0 + i, nctu, cpf) - chunk0) + h;
+                        if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+                            __hip_atomic_store(f, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+        }
     }
 }
 
@@ -624,7 +649,7 @@ void launch_head(const Workspace& ws, const DeviceWeights& w, int n, float qn, i
         hp.w3[h] = w.fc3_w[h];
         hp.b3[h] = w.fc3_b[h];
     }
-    hipLaunchKernelGGL(k4_head, dim3((n + 11) / 12), dim3(256), 0, s, ws.h2, hp, qn, n, nctu,
+    hipLaunchKernelGGL(k4_head, dim3((n + 63) / 64), dim3(256), 0, s, ws.h2, hp, qn, n, nctu,
                        chunks_per_frame(nctu), ctu0, thr1, thr2, ws.logits, ws.raw, d_probs, ws.flags);
 }
 
