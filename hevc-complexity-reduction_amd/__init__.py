@@ -9,4 +9,4 @@ The directory name has a hyphen; import it with
 """
 from . import ethcnn  # noqa: F401
 from .ethcnn import EthCnn, EthCnnError, load_library  # noqa: F401
-from . import net_CNN, video_to_cu_depth  # noqa: F401
+from . import net_CNN, sharding, video_to_cu_depth  # noqa: F401

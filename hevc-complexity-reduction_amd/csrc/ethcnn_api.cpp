@@ -516,9 +516,11 @@ extern "C" int ethcnn_predict_luma(ethcnn_ctx* c, const uint8_t* luma, int w, in
 }
 
 // video_to_cu_depth.py:120-145 minus argv/model selection (those live in the launcher).
-extern "C" int ethcnn_predict_yuv_file(ethcnn_ctx* c, const char* yuv, int w, int h, int qp, const char* out_path,
-                                       int64_t* nframes_out) {
-    if (!c || !yuv || !out_path) return c ? set_err(c, ETHCNN_ERR_ARG, "null path") : ETHCNN_ERR_ARG;
+// shard == false: frames [0, all) -> out_path via temp file + rename.
+// shard == true : frames [f0, f1) pwritten at f0 * nctu * 84 into the EXISTING, pre-sized
+//                 out_path (one worker per GPU, disjoint ranges, no collective).
+static int yuv_frames(ethcnn_ctx* c, const char* yuv, int w, int h, int qp, const char* out_path, bool shard,
+                      int64_t f0, int64_t f1, int64_t* nframes_out) {
     if (w <= 0 || h <= 0) return set_err(c, ETHCNN_ERR_ARG, "bad frame size %dx%d", w, h);
     struct stat st;
     if (stat(yuv, &st) != 0) return set_err(c, ETHCNN_ERR_IO, "cannot stat %s: %s", yuv, std::strerror(errno));
@@ -526,43 +528,65 @@ extern "C" int ethcnn_predict_yuv_file(ethcnn_ctx* c, const char* yuv, int w, in
     if (frame_bytes == 0 || st.st_size % frame_bytes != 0)  // :137 assert(file_bytes % frame_bytes == 0)
         return set_err(c, ETHCNN_ERR_FORMAT, "%s: size %lld is not a multiple of the %dx%d 4:2:0 frame size %lld", yuv,
                        (long long)st.st_size, w, h, (long long)frame_bytes);
-    const int nframes = (int)(st.st_size / frame_bytes);
-    if (nframes_out) *nframes_out = nframes;
+    const int64_t total = st.st_size / frame_bytes;
+    if (nframes_out) *nframes_out = total;
+    if (!shard) { f0 = 0; f1 = total; }
+    if (f0 < 0 || f1 < f0 || f1 > total) return set_err(c, ETHCNN_ERR_ARG, "frame range [%lld,%lld) outside 0..%lld", (long long)f0, (long long)f1, (long long)total);
+    const int nctu = ((w + 63) / 64) * ((h + 63) / 64);
     FILE* fin = std::fopen(yuv, "rb");
     if (!fin) return set_err(c, ETHCNN_ERR_IO, "cannot open %s: %s", yuv, std::strerror(errno));
     const std::string tmp = std::string(out_path) + ".tmp." + std::to_string((long)getpid());
-    FILE* fout = std::fopen(tmp.c_str(), "wb");
+    FILE* fout = shard ? std::fopen(out_path, "r+b") : std::fopen(tmp.c_str(), "wb");
     if (!fout) {
         std::fclose(fin);
-        return set_err(c, ETHCNN_ERR_IO, "cannot create %s: %s", tmp.c_str(), std::strerror(errno));
+        return set_err(c, ETHCNN_ERR_IO, "cannot open %s for writing: %s", shard ? out_path : tmp.c_str(), std::strerror(errno));
     }
-    const int nctu = ((w + 63) / 64) * ((h + 63) / 64);
-    const int fd = fileno(fin);
-    auto fill = [&](uint8_t* dst, int f0, int nf) -> int {
+    const int fd = fileno(fin), ofd = fileno(fout);
+    auto fill = [&](uint8_t* dst, int g0, int nf) -> int {
         for (int f = 0; f < nf; ++f) {  // luma only; chroma (w*h/2 bytes) is never read (:47-48)
             size_t got = 0;
             const size_t want = (size_t)w * h;
-            const off_t off = (off_t)(f0 + f) * frame_bytes;
+            const off_t off = (off_t)(f0 + g0 + f) * frame_bytes;
             while (got < want) {
                 const ssize_t r = pread(fd, dst + (size_t)f * want + got, want - got, off + (off_t)got);
-                if (r <= 0) return set_err(c, ETHCNN_ERR_IO, "short read in %s (frame %d)", yuv, f0 + f);
+                if (r <= 0) return set_err(c, ETHCNN_ERR_IO, "short read in %s (frame %lld)", yuv, (long long)(f0 + g0 + f));
                 got += (size_t)r;
             }
         }
         return 0;
     };
-    auto drain = [&](const float* src, int /*f0*/, int nf) -> int {
-        const size_t cnt = (size_t)nf * nctu * kNOut;
-        if (std::fwrite(src, 4, cnt, fout) != cnt) return set_err(c, ETHCNN_ERR_IO, "write to %s failed", tmp.c_str());
+    auto drain = [&](const float* src, int g0, int nf) -> int {
+        const size_t bytes = (size_t)nf * nctu * kNOut * 4;
+        const off_t off = (off_t)((shard ? f0 : 0) + g0) * nctu * kNOut * 4;
+        size_t done = 0;
+        while (done < bytes) {
+            const ssize_t r = pwrite(ofd, (const char*)src + done, bytes - done, off + (off_t)done);
+            if (r <= 0) return set_err(c, ETHCNN_ERR_IO, "write to %s failed: %s", out_path, std::strerror(errno));
+            done += (size_t)r;
+        }
         return 0;
     };
-    int rc = host_pipeline(c, w, h, nframes, qp, fill, drain);
+    int rc = host_pipeline(c, w, h, (int)(f1 - f0), qp, fill, drain);
     std::fclose(fin);
-    if (std::fclose(fout) != 0 && rc == 0) rc = set_err(c, ETHCNN_ERR_IO, "close of %s failed", tmp.c_str());
-    if (rc == 0 && std::rename(tmp.c_str(), out_path) != 0)
-        rc = set_err(c, ETHCNN_ERR_IO, "rename %s -> %s failed: %s", tmp.c_str(), out_path, std::strerror(errno));
-    if (rc != 0) std::remove(tmp.c_str());
+    if (std::fclose(fout) != 0 && rc == 0) rc = set_err(c, ETHCNN_ERR_IO, "close of output failed");
+    if (!shard) {
+        if (rc == 0 && std::rename(tmp.c_str(), out_path) != 0)
+            rc = set_err(c, ETHCNN_ERR_IO, "rename %s -> %s failed: %s", tmp.c_str(), out_path, std::strerror(errno));
+        if (rc != 0) std::remove(tmp.c_str());
+    }
     return rc;
+}
+
+extern "C" int ethcnn_predict_yuv_file(ethcnn_ctx* c, const char* yuv, int w, int h, int qp, const char* out_path,
+                                       int64_t* nframes_out) {
+    if (!c || !yuv || !out_path) return c ? set_err(c, ETHCNN_ERR_ARG, "null path") : ETHCNN_ERR_ARG;
+    return yuv_frames(c, yuv, w, h, qp, out_path, false, 0, 0, nframes_out);
+}
+
+extern "C" int ethcnn_predict_yuv_shard(ethcnn_ctx* c, const char* yuv, int w, int h, int qp, const char* out_path,
+                                        int64_t frame_begin, int64_t frame_end) {
+    if (!c || !yuv || !out_path) return c ? set_err(c, ETHCNN_ERR_ARG, "null path") : ETHCNN_ERR_ARG;
+    return yuv_frames(c, yuv, w, h, qp, out_path, true, frame_begin, frame_end, nullptr);
 }
 
 // -------------------------------------------------------------- config #5 -----------

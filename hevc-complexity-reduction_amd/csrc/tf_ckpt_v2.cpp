@@ -141,7 +141,10 @@ static bool for_each_entry(Cur blk, Fn fn, std::string& why) {
         if (!c.ok) { why = "entry overruns block"; return false; }
         key.resize((size_t)shared);
         key.append((const char*)kd.p, (size_t)non_shared);
-        if (!fn(key, val)) { why = "bad entry value for key '" + key + "'"; return false; }
+        if (!fn(key, val)) {
+            if (why.empty()) why = "bad entry value for key '" + key + "'";  // keep a nested, more specific reason
+            return false;
+        }
     }
     return true;
 }
@@ -265,4 +268,8 @@ extern "C" int ethcnn_ckpt_read_index(const char* index_path, ethcnn_ckpt_entry*
 }
 extern "C" uint32_t ethcnn_crc32c_masked(const void* data, size_t n) {
     return ethcnn::crc32c_mask(ethcnn::crc32c(data, n));
+}
+extern "C" int ethcnn_ckpt_read_blob(const char* prefix, float* blob_out, size_t nfloats, char* err, size_t errcap) {
+    if (!prefix || !blob_out || nfloats != ethcnn::kBlobFloats) return ETHCNN_ERR_ARG;
+    return ethcnn::ckpt_load_blob(prefix, blob_out, err, errcap);
 }

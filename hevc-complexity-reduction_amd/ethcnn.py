@@ -60,7 +60,9 @@ SIGNATURES = {
     "ethcnn_predict_luma_device": (_i, [_vp, _vp, _i, _i, _pd, _pd, _i, _i, _vp]),
     "ethcnn_predict_luma": (_i, [_vp, _vp, _i, _i, _pd, _pd, _i, _i, _fp]),
     "ethcnn_predict_yuv_file": (_i, [_vp, _cp, _i, _i, _i, _cp, ctypes.POINTER(ctypes.c_int64)]),
-    "ethcnn_resi_vectors_device": (_i, [_vp, _vp, _i, _i, _pd, _vp]),
+    "ethcnn_predict_yuv_shard": (_i, [_vp, _cp, _i, _i, _i, _cp, ctypes.c_int64, ctypes.c_int64]),
+    "ethcnn_ckpt_read_blob": (_i, [_cp, _fp, _sz, ctypes.c_char_p, _sz]),
+    "ethcnn_resi_vectors_device":(_i, [_vp, _vp, _i, _i, _pd, _vp]),
     "ethcnn_resi_vectors": (_i, [_vp, _vp, _i, _i, _pd, _fp]),
     "ethcnn_device_alloc": (_i, [_vp, _sz, ctypes.POINTER(_vp)]),
     "ethcnn_device_free": (_i, [_vp, _vp]),
@@ -121,9 +123,19 @@ def read_ckpt_index(index_path):
     err = ctypes.create_string_buffer(400)
     rc = lib.ethcnn_ckpt_read_index(index_path.encode(), ents, 256, ctypes.byref(n), err, 400)
     if rc:
-        raise EthCnnError(rc, err.value.decode())
+        raise EthCnnError(rc, err.value.decode("utf-8", "replace"))
     return [(e.name.decode(), e.dtype, tuple(e.shape[i] for i in range(e.rank)), e.shard, e.offset, e.size, e.crc32c)
             for e in ents[: n.value]]
+
+
+def read_ckpt_blob(prefix):
+    """TF-V2 bundle -> float32[BLOB_FLOATS] in checkpoint layout (crc32c-checked, host only)."""
+    out = np.empty(BLOB_FLOATS, dtype=np.float32)
+    err = ctypes.create_string_buffer(400)
+    rc = load_library().ethcnn_ckpt_read_blob(os.fsencode(prefix), out.ctypes.data_as(_fp), out.size, err, 400)
+    if rc:
+        raise EthCnnError(rc, err.value.decode("utf-8", "replace"))
+    return out
 
 
 def crc32c_masked(data):
@@ -271,6 +283,10 @@ class EthCnn(object):
         self._chk(self.lib.ethcnn_predict_yuv_file(self.h, os.fsencode(yuv_path), width, height, int(qp),
                                                    os.fsencode(out_path), ctypes.byref(nf)))
         return nf.value
+
+    def predict_yuv_shard(self, yuv_path, width, height, qp, out_path, frame_begin, frame_end):
+        self._chk(self.lib.ethcnn_predict_yuv_shard(self.h, os.fsencode(yuv_path), width, height, int(qp),
+                                                    os.fsencode(out_path), int(frame_begin), int(frame_end)))
 
     def resi_vectors(self, luma, width, height, pitch=None):
         luma = np.ascontiguousarray(luma, dtype=np.uint8)

@@ -97,6 +97,12 @@ int ethcnn_predict_luma(ethcnn_ctx* ctx, const uint8_t* luma, int width, int hei
 int ethcnn_predict_yuv_file(ethcnn_ctx* ctx, const char* yuv_path, int width, int height, int qp,
                             const char* out_path, int64_t* nframes_out);
 
+/* Multi-GPU sharding (no collective): one worker per GPU handles frames
+ * [frame_begin, frame_end) and pwrites them at frame_begin * nctu * 84 into `out_path`,
+ * which must already exist with its final size (frames * nctu * 84 bytes). */
+int ethcnn_predict_yuv_shard(ethcnn_ctx* ctx, const char* yuv_path, int width, int height, int qp,
+                             const char* out_path, int64_t frame_begin, int64_t frame_end);
+
 /* ---- config #5 front-end: resi_cnn (HM-16.5_Test_LDP/bin/net_CNN_LSTM_one_step.py:151-199)
  *      fed as in resi_to_cu_depth_LDP.py:72-101.  One frame; vec = float32 [nctu][448]. */
 int ethcnn_resi_vectors_device(ethcnn_ctx* ctx, const uint8_t* d_luma, int width, int height,
@@ -156,6 +162,8 @@ typedef struct ethcnn_ckpt_entry {
 int ethcnn_ckpt_read_index(const char* index_path, ethcnn_ckpt_entry* entries, int cap, int* n_out,
                            char* err, size_t errcap);
 uint32_t ethcnn_crc32c_masked(const void* data, size_t nbytes);
+/* <prefix>.index + <prefix>.data-00000-of-00001 -> blob (crc-checked); no context / device needed */
+int ethcnn_ckpt_read_blob(const char* prefix, float* blob_out, size_t nfloats, char* err, size_t errcap);
 
 #ifdef __cplusplus
 }
