@@ -58,19 +58,64 @@ def restore_model(ctx, qp_seq, model_dir='.'):
     return 'synthetic(seed=%s)' % seed
 
 
+def _shard_worker(device, yuv_file, width, height, qp_seq, out_path, f0, f1, thr):
+    """One process per GPU: own context, own frame range, pwrite into out_path."""
+    ctx = _e.EthCnn(device=device)
+    ctx.set_thresholds(*thr)
+    restore_model(ctx, qp_seq)
+    ctx.predict_yuv_shard(yuv_file, width, height, qp_seq, out_path, f0, f1)
+    ctx.close()
+
+
+def predict_sharded(yuv_file, width, height, qp_seq, save_file, devices):
+    """Frame-range sharding over `devices` (list of HIP ordinals, one worker process each).
+    No collective: ranges are disjoint and the output offsets deterministic."""
+    import multiprocessing as mp
+    from . import sharding
+    n_frames = get_file_size(yuv_file) // (width * height * 3 // 2)
+    thr = nt.get_thresholds(THR_FILE)
+    tmp = '%s.tmp.%d' % (save_file, os.getpid())
+    sharding.presize_output(tmp, n_frames, width, height)
+    mpctx = mp.get_context('spawn')
+    procs = []
+    for g, dev in enumerate(devices):
+        f0, f1 = sharding.frame_range(n_frames, len(devices), g)
+        if f1 > f0:
+            p = mpctx.Process(target=_shard_worker, args=(dev, yuv_file, width, height, qp_seq, tmp, f0, f1, thr))
+            p.start()
+            procs.append(p)
+    ok = True
+    for p in procs:
+        p.join()
+        ok = ok and p.exitcode == 0
+    if not ok:
+        os.remove(tmp)
+        raise RuntimeError('a shard worker failed')
+    os.replace(tmp, save_file)
+    return n_frames
+
+
 def main(argv=None):
     argv = sys.argv if argv is None else argv
     assert len(argv) == 5                      # :120
     yuv_file = argv[1]
     width, height, qp_seq = int(argv[2]), int(argv[3]), int(argv[4])
-    ctx = _e.EthCnn(device=int(os.environ.get('ETHCNN_DEVICE', '0')))
-    ctx.load_thresholds(THR_FILE)              # net_CNN.py:47 (cwd-relative, at import time there)
-    restore_model(ctx, qp_seq)
+    frame_bytes = width * height * 3 // 2
+    assert frame_bytes > 0 and get_file_size(yuv_file) % frame_bytes == 0   # :137
+    # ETHCNN_DEVICES="0,1,2,3" shards frames over several GPUs; default: one GPU (ETHCNN_DEVICE)
+    devices = [int(d) for d in os.environ.get('ETHCNN_DEVICES', os.environ.get('ETHCNN_DEVICE', '0')).split(',')]
     t1 = time.time()
-    n_frames = get_prob(ctx, yuv_file, IMAGE_SIZE, SAVE_FILE, qp_seq, 0,
-                        get_file_size(yuv_file) // (width * height * 3 // 2), width, height)
+    if len(devices) > 1:
+        n_frames = predict_sharded(yuv_file, width, height, qp_seq, SAVE_FILE, devices)
+    else:
+        ctx = _e.EthCnn(device=devices[0])
+        ctx.load_thresholds(THR_FILE)          # net_CNN.py:47 (cwd-relative; at import time there)
+        restore_model(ctx, qp_seq)
+        t1 = time.time()                       # the reference times get_prob only (:142-145)
+        n_frames = get_prob(ctx, yuv_file, IMAGE_SIZE, SAVE_FILE, qp_seq, 0,
+                            get_file_size(yuv_file) // frame_bytes, width, height)
+        ctx.close()
     t2 = time.time()
     print('%s  frame %d/%d  %dx%d' % (yuv_file, n_frames, n_frames, width, height))
     print('--------\n\nPredicting Time: %.3f sec.\n\n--------' % float(t2 - t1))  # :145
-    ctx.close()
     return 0

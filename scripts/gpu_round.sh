@@ -1,0 +1,36 @@
+#!/bin/bash
+# Round evidence in one gpurun call: gpu tests, smoke, benches, rocprofv3 kernel-trace stats,
+# HBM-traffic PMC passes, HM replay case.  Everything lands in gpurun_out/.
+set -u
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+REPO=$PWD
+python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+python __graft_entry__.py smoke 2>&1 | tail -3
+python bench.py > gpurun_out/bench_c2.json 2> gpurun_out/bench_c2.err || tail -5 gpurun_out/bench_c2.err
+python bench.py --workload c3 --no-cpu-baseline > gpurun_out/bench_c3.json 2> gpurun_out/bench_c3.err || tail -5 gpurun_out/bench_c3.err
+python bench.py --workload c4 --no-cpu-baseline --steps 5 > gpurun_out/bench_c4.json 2> gpurun_out/bench_c4.err || tail -5 gpurun_out/bench_c4.err
+python scripts/summarize.py "gpurun_out/bench_c*.json"
+python - <<'PY'
+import json; d=json.load(open("gpurun_out/bench_c2.json")); print("cpu_baseline:", d.get("cpu_baseline"))
+PY
+python scripts/make_hm_case.py 2>&1 | tail -2
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_c2 -o c2 -- python $REPO/bench.py --no-cpu-baseline > $REPO/gpurun_out/prof_c2.log 2>&1
+for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+  tag=$(echo $pmc | tr ' ' '_' | cut -c1-30)
+  rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d $REPO/gpurun_out/pmc_c2_$tag -o p -- python $REPO/bench.py --no-cpu-baseline --steps 5 --warmup 1 > $REPO/gpurun_out/pmc_c2_$tag.log 2>&1
+done
+cd $REPO
+head -12 gpurun_out/prof_c2/c2_kernel_stats.csv
+python - <<'PY'
+import csv, glob, collections
+for f in sorted(glob.glob("gpurun_out/pmc_c2_*/**/*counter_collection.csv", recursive=True)):
+    agg=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.Counter()
+    for r in csv.DictReader(open(f)):
+        k=r["Kernel_Name"][:48]
+        if "ethcnn" not in k: continue
+        agg[k][r["Counter_Name"]]+=float(r["Counter_Value"]); cnt[(k,r["Counter_Name"])]+=1
+    for k,d in agg.items():
+        print(k, {c: "%.5g" % (v/cnt[(k,c)]) for c,v in d.items()})
+PY

@@ -1,0 +1,78 @@
+"""-m gpu: the drop-in command line (what HM's unchanged hook runs) end to end."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tfckpt_writer import write_bundle
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LAUNCHER = os.path.join(ROOT, "video_to_cu_depth.py")
+
+
+def _yuv(path, w, h, frames, seed):
+    rng = np.random.default_rng(seed)
+    data = rng.integers(0, 256, size=frames * (w * h * 3 // 2), dtype=np.uint8)
+    data.tofile(path)
+    return data
+
+
+def _run(cwd, argv, **env):
+    e = dict(os.environ)
+    e.update({k: str(v) for k, v in env.items()})
+    return subprocess.run([sys.executable, LAUNCHER] + [str(a) for a in argv], cwd=str(cwd), env=e, capture_output=True, text=True)
+
+
+def test_cli_with_checkpoint_files(pkg, oracle, tmp_path):
+    """cwd holds Thr_info.txt + model_2000000_qp30~35.dat.{index,data-...}: the reference's
+    own file contract (video_to_cu_depth.py:126-133, net_CNN.py:47)."""
+    w, h, frames, qp = 416, 240, 3, 32
+    yuv = _yuv(str(tmp_path / "seq.yuv"), w, h, frames, 1)
+    (tmp_path / "Thr_info.txt").write_text("0.4 0.6 0.3 0.7 0.2 0.8\n")
+    blob = oracle.synth_blob(21, 8.0)
+    write_bundle(str(tmp_path / "model_2000000_qp30~35.dat"), [(n, np.array(v)) for n, v in oracle.tensor_views(blob).items()],
+                 data_crc=pkg.ethcnn.crc32c_masked)
+    r = _run(tmp_path, ["seq.yuv", w, h, qp])
+    assert r.returncode == 0, r.stderr
+    assert "Predicting Time:" in r.stdout
+    got = np.fromfile(str(tmp_path / "cu_depth.dat"), dtype="<f4").reshape(-1, 21)
+    want = oracle.predict_frames(blob, yuv, w, h, frames, qp, 0.6, 0.7, frame_stride=w * h * 3 // 2)
+    assert got.shape == want.shape == (frames * 7 * 4, 21)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert not [f for f in os.listdir(str(tmp_path)) if ".tmp." in f]
+    # a QP in another band looks for another model file, which is absent -> non-zero exit, old file untouched
+    before = (tmp_path / "cu_depth.dat").read_bytes()
+    r = _run(tmp_path, ["seq.yuv", w, h, 22])
+    assert r.returncode != 0 and (tmp_path / "cu_depth.dat").read_bytes() == before
+
+
+def test_cli_failures_exit_nonzero(tmp_path):
+    _yuv(str(tmp_path / "seq.yuv"), 64, 64, 1, 2)
+    (tmp_path / "Thr_info.txt").write_text("0.5 0.5 0.5 0.5 0.5 0.5\n")
+    assert _run(tmp_path, ["seq.yuv", 64, 64, 32]).returncode != 0                       # no model, no opt-in
+    assert _run(tmp_path, ["seq.yuv", 64, 48, 32], ETHCNN_SYNTHETIC_SEED=1).returncode != 0  # size % frame != 0
+    assert _run(tmp_path, ["absent.yuv", 64, 64, 32], ETHCNN_SYNTHETIC_SEED=1).returncode != 0
+    assert not (tmp_path / "cu_depth.dat").exists()
+    os.remove(str(tmp_path / "Thr_info.txt"))
+    assert _run(tmp_path, ["seq.yuv", 64, 64, 32], ETHCNN_SYNTHETIC_SEED=1).returncode != 0  # Thr_info.txt missing
+
+
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0,0,0,0,0,0"])
+def test_sharded_cli_is_byte_identical(oracle, tmp_path, devices):
+    """Frame-range sharding (no collective).  One MI355X is visible here, so the G workers all
+    use device 0: what is checked is that ranges + offsets reproduce the 1-worker file."""
+    w, h, frames, qp = 832, 480, 11, 37   # 13 x 8 = 104 CTUs per frame, ragged bottom edge
+    yuv = _yuv(str(tmp_path / "seq.yuv"), w, h, frames, 3)
+    (tmp_path / "Thr_info.txt").write_text("0.5 0.5 0.5 0.5 0.5 0.5\n")
+    r = _run(tmp_path, ["seq.yuv", w, h, qp], ETHCNN_SYNTHETIC_SEED=9, ETHCNN_HEAD_GAIN=8)
+    assert r.returncode == 0, r.stderr
+    single = (tmp_path / "cu_depth.dat").read_bytes()
+    os.remove(str(tmp_path / "cu_depth.dat"))
+    r = _run(tmp_path, ["seq.yuv", w, h, qp], ETHCNN_SYNTHETIC_SEED=9, ETHCNN_HEAD_GAIN=8, ETHCNN_DEVICES=devices)
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "cu_depth.dat").read_bytes() == single
+    want = oracle.predict_frames(oracle.synth_blob(9, 8.0), yuv, w, h, frames, qp, 0.5, 0.5, frame_stride=w * h * 3 // 2)
+    assert np.array_equal(np.frombuffer(single, dtype="<f4").view(np.uint32), want.reshape(-1).view(np.uint32))

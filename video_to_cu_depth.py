@@ -7,13 +7,19 @@ import importlib
 import os
 import sys
 
-_home = os.environ.get("ETHCNN_HOME") or os.path.dirname(os.path.realpath(__file__))
-sys.path.insert(0, _home)
-try:
-    _pkg = importlib.import_module("hevc-complexity-reduction_amd")
-    sys.exit(_pkg.video_to_cu_depth.main(sys.argv))
-except SystemExit:
-    raise
-except BaseException as exc:  # any failure must reach HM as a non-zero exit status
-    sys.stderr.write("video_to_cu_depth: %s: %s\n" % (type(exc).__name__, exc))
-    sys.exit(1)
+
+def _main():
+    home = os.environ.get("ETHCNN_HOME") or os.path.dirname(os.path.realpath(__file__))
+    sys.path.insert(0, home)
+    try:
+        pkg = importlib.import_module("hevc-complexity-reduction_amd")
+        return pkg.video_to_cu_depth.main(sys.argv)
+    except SystemExit:
+        raise
+    except BaseException as exc:  # any failure must reach HM as a non-zero exit status
+        sys.stderr.write("video_to_cu_depth: %s: %s\n" % (type(exc).__name__, exc))
+        return 1
+
+
+if __name__ == "__main__":  # guard: multi-GPU mode spawns worker processes that re-import this file
+    sys.exit(_main())
