@@ -363,19 +363,27 @@ int oracle_predict_frames(const float* blob, const uint8_t* luma, int w, int h, 
     int o1[16], o2[64], o3[96];
     build_orders(mode, o1, o2, o3);
     const float qn = (float)qp * c51();
-    uint8_t* ctus = (uint8_t*)malloc((size_t)nctu * 4096);
+    /* frames are independent: work on groups of frames so that all host cores stay busy
+     * (the gate scope stays one frame's <=1024-CTU sub-batch) */
+    int group = 16384 / nctu;
+    if (group < 1) group = 1;
+    if (group > nframes) group = nframes;
+    uint8_t* ctus = (uint8_t*)malloc((size_t)group * nctu * 4096);
     if (!ctus) return -1;
-    for (int f = 0; f < nframes; ++f) {
-        oracle_tile_frame(luma + (size_t)f * frame_stride, w, h, pitch, ctus);
-        float* P = probs + (size_t)f * nctu * NOUT;
-#pragma omp parallel for schedule(dynamic, 4)
-        for (int i = 0; i < nctu; ++i) {
+    for (int f0 = 0; f0 < nframes; f0 += group) {
+        const int nf = (nframes - f0 < group) ? nframes - f0 : group;
+#pragma omp parallel for schedule(static)
+        for (int f = 0; f < nf; ++f)
+            oracle_tile_frame(luma + (size_t)(f0 + f) * frame_stride, w, h, pitch, ctus + (size_t)f * nctu * 4096);
+        float* P = probs + (size_t)f0 * nctu * NOUT;
+#pragma omp parallel for schedule(dynamic, 2)
+        for (int i = 0; i < nf * nctu; ++i) {
             float F[NFEAT], H1[NH1];
             ctu_features(ctus + (size_t)i * 4096, blob, mode, 0, o1, o2, o3, F);
             ctu_fc1(F, blob, H1);
             ctu_heads(H1, blob, qn, P + (size_t)i * NOUT, (float*)0);
         }
-        oracle_gates(P, nctu, 1024, thr1, thr2);
+        for (int f = 0; f < nf; ++f) oracle_gates(P + (size_t)f * nctu * NOUT, nctu, 1024, thr1, thr2);
     }
     free(ctus);
     return 0;
