@@ -355,8 +355,7 @@ static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, lo
     { StageTimer t(c, ETHCNN_STAGE_TILE); launch_tile(d_luma, g, ctu0, n, c->ws, c->stream); }
     { StageTimer t(c, ETHCNN_STAGE_TRUNK); launch_trunk(c->ws, c->dw, n, false, c->stream); }
     { StageTimer t(c, ETHCNN_STAGE_FC1); launch_fc1(c->ws, c->dw, n, c->ws.h1, c->stream); }
-    { StageTimer t(c, ETHCNN_STAGE_FC2); launch_fc2(c->ws, c->dw, n, qn, c->stream); }
-    { StageTimer t(c, ETHCNN_STAGE_HEAD); launch_head(c->ws, c->dw, n, qn, g.nctu, ctu0, c->thr1, c->thr2, d_probs_pass, c->stream); }
+    { StageTimer t(c, ETHCNN_STAGE_HEADS); launch_heads(c->ws, c->dw, n, qn, g.nctu, ctu0, c->thr1, c->thr2, d_probs_pass, c->stream); }
     { StageTimer t(c, ETHCNN_STAGE_GATE); launch_gate(c->ws, n, g.nctu, ctu0, c->thr2, d_probs_pass, c->stream); }
     HIPCHK(c, hipGetLastError());
     c->times.ctus += n;

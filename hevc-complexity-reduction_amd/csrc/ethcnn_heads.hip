@@ -1,0 +1,204 @@
+// ethcnn_heads.hip -- the three QP-conditioned FC heads after FC1, fused in one kernel:
+//   h2 = lrelu([h1, qp] W2 + b2)   (net_CNN.py:159,167,180)
+//   y  = sigmoid([h2, qp] W3 + b3) (net_CNN.py:161,169,182)  + the gate predicates (:175,187)
+// gfx950, v_mfma_f32_16x16x4_f32.
+//
+// One wave = 16 CTUs, "transposed": MFMA rows = output features, columns = CTUs.
+//   FC2^T: A operand = W2 (staged once per block per 16-k chunk by LDS-DMA, shared by the 4
+//          waves), B operand = this wave's h1 rows, one float4 per lane per chunk (element e
+//          feeds MFMA step e -> k order 16c + 4g + e, the canonical FC order).
+//   The FC2^T accumulator of lane (ctu, g) holds h2[ctu][16t + 4g + r]: exactly the B operand
+//   FC3^T needs for step (t, r) -- so FC2 -> FC3 chains in registers (same k order), no LDS,
+//   no HBM round trip.  FC3^T's A operand (W3, <= 3088 floats) comes straight from L1/L2.
+#include <hip/hip_runtime.h>
+
+#include "ethcnn_kernels.h"
+
+namespace ethcnn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ float lrelu_h(float h) { return fmaxf(0.2f * h, h); }
+
+__device__ __forceinline__ float expf_canonical_h(float x) {
+    x = fminf(x, 80.0f);
+    x = fmaxf(x, -86.0f);
+    const float n = rintf(x * 1.44269504088896341f);
+    float r = fmaf(n, -0.693145751953125f, x);
+    r = fmaf(n, -1.42860682030941723212e-6f, r);
+    float p = 1.0f / 5040.0f;
+    p = fmaf(p, r, 1.0f / 720.0f);
+    p = fmaf(p, r, 1.0f / 120.0f);
+    p = fmaf(p, r, 1.0f / 24.0f);
+    p = fmaf(p, r, 1.0f / 6.0f);
+    p = fmaf(p, r, 0.5f);
+    p = fmaf(p, r, 1.0f);
+    p = fmaf(p, r, 1.0f);
+    return __int_as_float(__float_as_int(p) + (((int)n) << 23));
+}
+
+struct HeadsParams {
+    const float* w2[3];
+    const float* b2[3];
+    const float* w3[3];
+    const float* b3[3];
+};
+
+__device__ __forceinline__ long gchunk(long gn, int nctu, int cpf) {
+    const long f = gn / nctu;
+    return f * cpf + (gn - f * nctu) / kSubBatch;
+}
+
+constexpr int kHeadsLds = 2 * 16 * 192;  // double-buffered W2 chunk of the widest head
+
+// one head for this wave's 16 CTUs.  H: 0/1/2 -> (n1, n2, n3) = (64,48,1) / (128,96,4) / (256,192,16)
+template <int H>
+__device__ __forceinline__ void head_pass(float* smem, const float* __restrict__ h1row, const HeadsParams& hp, float qn,
+                                          int lane, int wv, bool valid, int ctu, float* __restrict__ h2row,
+                                          float* __restrict__ logits, float* __restrict__ raw, float* __restrict__ probs,
+                                          int* __restrict__ flag32, int* __restrict__ flag16, float thr1, float thr2) {
+    constexpr int N1 = (H == 0) ? 64 : (H == 1 ? 128 : 256);
+    constexpr int N2 = (H == 0) ? 48 : (H == 1 ? 96 : 192);
+    constexpr int N3 = (H == 0) ? 1 : (H == 1 ? 4 : 16);
+    constexpr int O1 = (H == 0) ? 0 : (H == 1 ? 64 : 192);
+    constexpr int O2 = (H == 0) ? 0 : (H == 1 ? 48 : 144);
+    constexpr int O3 = (H == 0) ? 0 : (H == 1 ? 1 : 5);
+    constexpr int NT = N2 / 16;                 // FC2 output tiles (3 / 6 / 12)
+    constexpr int B_FLOATS = 16 * N2;           // one W2 chunk: 16 k rows x N2
+    constexpr int B_INST = B_FLOATS / 256;      // 3 / 6 / 12 LDS-DMA instructions
+    constexpr int B_PER = (B_INST + 3) / 4;
+    constexpr bool COLSWZ = (N2 % 32 == 0);
+    const int col = lane & 15, g = lane >> 4;
+    const float* W2 = hp.w2[H];
+
+    // LDS-DMA source pointers (same permuted-image scheme as ethcnn_dense.hip)
+    const float* b_src[B_PER];
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+        const int e = (wv + i * 4) * 64 + lane;
+        int row = (e / (N2 / 4)) % 16;
+        int c4 = e % (N2 / 4);
+        if (COLSWZ) c4 ^= ((row >> 2) & 1) << 2;
+        else row ^= (row >> 2) & 1;
+        b_src[i] = W2 + (size_t)row * N2 + c4 * 4;
+    }
+    int bcol[NT], brow[4];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bcol[j] = (j * 16 + col) ^ (COLSWZ ? ((g & 1) << 4) : 0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) brow[e] = (COLSWZ ? e : (e ^ (g & 1))) * N2;
+
+#define HEADS_W2_ISSUE(kc, buf)                                                                              \
+    _Pragma("unroll") for (int i = 0; i < B_PER; ++i) {                                                      \
+        if ((i + 1) * 4 <= B_INST || wv + i * 4 < B_INST)                                                    \
+            __builtin_amdgcn_global_load_lds((glb_void*)(b_src[i] + (size_t)(kc) * 16 * N2),                 \
+                                             (lds_void*)(smem + (buf) * B_FLOATS + (wv + i * 4) * 256), 16, 0, 0); \
+    }
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr int NK = N1 / 16;
+    const float* a_src = h1row + O1 + 4 * g;
+    float4 a_cur, a_nxt;
+    __syncthreads();  // the previous head's last chunk has been consumed by every wave
+    HEADS_W2_ISSUE(0, 0);
+    a_cur = *reinterpret_cast<const float4*>(a_src);
+    a_nxt = a_cur;
+    __syncthreads();
+    for (int kc = 0; kc < NK; ++kc) {
+        const int buf = kc & 1;
+        if (kc + 1 < NK) {
+            HEADS_W2_ISSUE(kc + 1, buf ^ 1);
+            a_nxt = *reinterpret_cast<const float4*>(a_src + (kc + 1) * 16);
+        }
+        const float* bs = smem + buf * B_FLOATS + 4 * g * N2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float hv = (e == 0) ? a_cur.x : (e == 1) ? a_cur.y : (e == 2) ? a_cur.z : a_cur.w;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[j] = MFMA16(bs[brow[e] + bcol[j]], hv, acc[j]);  // rows = W2 columns
+        }
+        a_cur = a_nxt;
+        __syncthreads();
+    }
+#undef HEADS_W2_ISSUE
+
+    // FC2 epilogue in place: lane (ctu = col, g) holds h2[ctu][16 j + 4 g + r]
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = 16 * j + 4 * g;
+        const float4 wq = *reinterpret_cast<const float4*>(W2 + (size_t)N1 * N2 + n);
+        const float4 bv = *reinterpret_cast<const float4*>(hp.b2[H] + n);
+        acc[j][0] = lrelu_h(fmaf(qn, wq.x, acc[j][0]) + bv.x);
+        acc[j][1] = lrelu_h(fmaf(qn, wq.y, acc[j][1]) + bv.y);
+        acc[j][2] = lrelu_h(fmaf(qn, wq.z, acc[j][2]) + bv.z);
+        acc[j][3] = lrelu_h(fmaf(qn, wq.w, acc[j][3]) + bv.w);
+        if (valid) *reinterpret_cast<f32x4*>(h2row + O2 + n) = acc[j];
+    }
+
+    // FC3^T: rows = outputs (N3 of 16 used), columns = CTUs; step (j, r) consumes k = 16 j + 4 g + r
+    const float* W3 = hp.w3[H];
+    f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = 16 * j + 4 * g + r;
+            const float w = (col < N3) ? W3[k * N3 + col] : 0.0f;  // A[i = out][k]
+            z = MFMA16(w, acc[j][r], z);
+        }
+    // lane (ctu = col, g) holds outputs 4 g + r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int o = 4 * g + r;
+        if (o < N3 && valid) {
+            const float zz = fmaf(qn, W3[N2 * N3 + o], z[r]) + hp.b3[H][o];
+            const float p = 1.0f / (1.0f + expf_canonical_h(-zz));
+            const size_t idx = (size_t)ctu * kNOut + O3 + o;
+            logits[idx] = zz;
+            raw[idx] = p;
+            probs[idx] = p;
+            if (H == 0 && p > thr1 && __hip_atomic_load(flag32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+                __hip_atomic_store(flag32, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // any(y64 > THR_L1_LOWER)
+            if (H == 1 && p > thr2 && __hip_atomic_load(flag16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+                __hip_atomic_store(flag16, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // any(y32_tmp > THR_L2_LOWER)
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_heads(const float* __restrict__ H1, HeadsParams hp, float qn, int N, int nctu,
+                                               int cpf, long ctu0, float thr1, float thr2, float* __restrict__ H2,
+                                               float* __restrict__ logits, float* __restrict__ raw,
+                                               float* __restrict__ probs, int* __restrict__ flags) {
+    __shared__ __attribute__((aligned(16))) float smem[kHeadsLds];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int col = lane & 15;
+    const int ctu_raw = (blockIdx.x * 4 + wv) * 16 + col;
+    const bool valid = ctu_raw < N;
+    const int ctu = min(ctu_raw, N - 1);  // clamped rows are loaded, never stored
+    const float* h1row = H1 + (size_t)ctu * kNVec;
+    float* h2row = H2 + (size_t)ctu * kNFc2;
+    int* fl = flags + 2 * (gchunk(ctu0 + ctu, nctu, cpf) - gchunk(ctu0, nctu, cpf));
+    head_pass<2>(smem, h1row, hp, qn, lane, wv, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
+    head_pass<1>(smem, h1row, hp, qn, lane, wv, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
+    head_pass<0>(smem, h1row, hp, qn, lane, wv, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
+}
+
+void launch_heads(const Workspace& ws, const DeviceWeights& w, int n, float qn, int nctu, long ctu0, float thr1,
+                  float thr2, float* d_probs, hipStream_t s) {
+    HeadsParams hp;
+    for (int h = 0; h < 3; ++h) {
+        hp.w2[h] = w.fc2_w[h];
+        hp.b2[h] = w.fc2_b[h];
+        hp.w3[h] = w.fc3_w[h];
+        hp.b3[h] = w.fc3_b[h];
+    }
+    hipLaunchKernelGGL(k_heads, dim3((n + 63) / 64), dim3(256), 0, s, ws.h1, hp, qn, n, nctu, chunks_per_frame(nctu),
+                       ctu0, thr1, thr2, ws.h2, ws.logits, ws.raw, d_probs, ws.flags);
+}
+
+}  // namespace ethcnn

@@ -33,11 +33,9 @@ void launch_tile(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, co
 void launch_trunk(const Workspace& ws, const DeviceWeights& w, int n, bool resi, hipStream_t s);
 // k2: feat -> h1 (bias + leaky-ReLU fused); out may be ws.h1 or a caller buffer (resi vectors)
 void launch_fc1(const Workspace& ws, const DeviceWeights& w, int n, float* out, hipStream_t s);
-// k3: h1 -> h2 (three heads, qp row + bias + leaky-ReLU fused)
-void launch_fc2(const Workspace& ws, const DeviceWeights& w, int n, float qn, hipStream_t s);
-// k4: h2 -> logits, raw probs, probs (ungated) and per-chunk gate flags
-void launch_head(const Workspace& ws, const DeviceWeights& w, int n, float qn, int nctu_per_frame,
-                 long ctu0, float thr1, float thr2, float* d_probs, hipStream_t s);
+// k3+k4 fused: h1 -> h2 -> logits, raw probs, probs (ungated) and per-chunk gate flags
+void launch_heads(const Workspace& ws, const DeviceWeights& w, int n, float qn, int nctu_per_frame,
+                  long ctu0, float thr1, float thr2, float* d_probs, hipStream_t s);
 // k5: apply the batch gates in place on d_probs
 void launch_gate(const Workspace& ws, int n, int nctu_per_frame, long ctu0, float thr2, float* d_probs,
                  hipStream_t s);

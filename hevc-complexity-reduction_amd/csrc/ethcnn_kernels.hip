@@ -8,9 +8,9 @@
 //             v_mfma_f32_16x16x4_f32, "transposed" (rows = output channels, columns = 16
 //             units) so each layer's accumulator registers ARE the next layer's B operand:
 //             no LDS, no cross-lane traffic between layers.
-//   k_dense   LDS-tiled fp32 MFMA GEMM with fused (qp row) + bias + leaky-ReLU epilogue:
-//             FC1 [N,2688]x[2688,448] (:156,164,177) and the three FC2 layers (:159,167,180).
-//   k4_head   FC3 + sigmoid (:161,169,182) and the per-sub-batch gate predicates.
+//   k_dense   (ethcnn_dense.hip) FC1 [N,2688]x[2688,448] + bias + leaky-ReLU (:156,164,177).
+//   k_heads   (ethcnn_heads.hip) FC2 + FC3 + sigmoid of the three heads (:159-182), chained in
+//             registers, and the per-sub-batch gate predicates.
 //   k5_gate   tf.cond zero fill (:175,187).
 //
 // Arithmetic contract ("canonical order"): every dot product is a single
@@ -222,6 +222,13 @@ __device__ __forceinline__ void trunk_tasks(const uint4* __restrict__ X, int nta
     constexpr int OFF2 = (BR == 0) ? 672 : (BR == 1 ? 2208 : 2592);
     constexpr int OFF3 = (BR == 0) ? 0 : (BR == 1 ? 512 : 640);
 
+    // pixel records are prefetched one task ahead: the raw registers are dead as soon as they
+    // are decoded, so the next task's loads fly under this task's 240 MFMAs at no VGPR cost
+    constexpr int NJ = (BR == 0) ? 4 : 8;
+    uint4 raw[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) raw[j] = X[((size_t)wave * NJ + j) * 64 + lane];
+
     for (int task = wave; task < ntasks; task += nwaves) {
         // ---- pixels: x[d][kx], d = 4 q2 + q1 (patch), this lane's row g of each patch
         float x[16][4];
@@ -229,7 +236,7 @@ __device__ __forceinline__ void trunk_tasks(const uint4* __restrict__ X, int nta
         if (BR == 0) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const uint4 d = X[((size_t)task * 4 + j) * 64 + lane];
+                const uint4 d = raw[j];
                 const uint32_t w[4] = {d.x, d.y, d.z, d.w};
 #pragma unroll
                 for (int q1 = 0; q1 < 4; ++q1)
@@ -243,7 +250,7 @@ __device__ __forceinline__ void trunk_tasks(const uint4* __restrict__ X, int nta
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const uint4 d = X[((size_t)task * 8 + j) * 64 + lane];
+                const uint4 d = raw[j];
                 const uint32_t w[4] = {d.x, d.y, d.z, d.w};
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh)
@@ -254,6 +261,10 @@ __device__ __forceinline__ void trunk_tasks(const uint4* __restrict__ X, int nta
                         x[2 * j + hh][kx] = px_value<RESI>(s, POOL * POOL) * SCALE;
                     }
             }
+        }
+        if (task + nwaves < ntasks) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) raw[j] = X[((size_t)(task + nwaves) * NJ + j) * 64 + lane];
         }
         T += __shfl_xor(T, 16);
         T += __shfl_xor(T, 32);
@@ -352,7 +363,7 @@ void launch_trunk(const Workspace& ws, const DeviceWeights& w, int n, bool resi,
     // tasks: S n, M n/4, L n/16 -- all 240 MFMAs each.  Persistent-ish grid: ~2 blocks/CU.
     const int tS = n, tM = (n + 3) / 4, tL = (n + 15) / 16;
     auto blocks = [](int tasks, int budget) { int b = (tasks + 3) / 4; return b < budget ? b : budget; };
-    const int bS = blocks(tS, 768), bM = blocks(tM, 192), bL = blocks(tL, 48);
+    const int bS = blocks(tS, 390), bM = blocks(tM, 98), bL = blocks(tL, 24);  // 512 blocks = 2 per CU (219 VGPRs -> 2 waves per SIMD)
     if (resi)
         hipLaunchKernelGGL(k1_trunk<true>, dim3(bS + bM + bL), dim3(256), 0, s, ws.xs, ws.xm, ws.xl, n, bS, bM,
                            w.trunk_w, w.trunk_b, ws.feat);
@@ -361,296 +372,11 @@ void launch_trunk(const Workspace& ws, const DeviceWeights& w, int n, bool resi,
                            w.trunk_w, w.trunk_b, ws.feat);
 }
 
-// ====================================================================== k_dense ======
-// out[m][n] = lrelu( sum_k A[m][k] W[k][n]  (+ qn * W[K][n])  + bias[n] )
-// Block = WM x WN waves; wave tile = (16 MS) x (16 NS); block tile BM = 16 MS WM rows,
-// BN = 16 NS WN columns.  NSPLIT blocks share one M tile, each owning BN of the layer's
-// NSPLIT*BN columns; the column block is blockIdx.x % NSPLIT, so (dispatcher places block b
-// on XCD b % 8) every XCD only ever touches 1/NSPLIT of W and that slice stays resident in
-// its private 4 MiB L2 (the full FC1 matrix, 4.8 MB, does not fit).  Speed only: results do
-// not depend on placement.  K is consumed in BK-wide chunks staged through LDS
-// (register-staged double buffer, one barrier per chunk); each accumulator is ONE
-// ascending-k MFMA chain (no split-K), which is the canonical order.
-typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void glb_void;
-
-template <int MS, int NS, int WM, int WN, int BK, int NSPLIT, bool QP>
-__global__ __launch_bounds__(64 * WM * WN) void k_dense(const float* __restrict__ A, int lda, int K,
-                                                        const float* __restrict__ W, const float* __restrict__ bias,
-                                                        float qn, float* __restrict__ out, int ldo, int M) {
-    constexpr int NW = WM * WN, NT = 64 * NW;
-    constexpr int BM = 16 * MS * WM, BN = 16 * NS * WN;
-    constexpr int LDW = BN * NSPLIT;  // row stride of W == number of columns of the layer
-    constexpr int AP = BK + 1;        // A tile row pitch (floats): conflict-free column reads
-    // B tile: LINEAR [BK][BN] image (what global_load_lds writes: wave-uniform base + 16 B x
-    // lane).  When BN % 32 == 0 the two k-groups of a 32-lane half (g = 0,1) would hit the
-    // same banks, so odd k rows are stored with adjacent 16-column groups swapped: the
-    // permutation is applied to the per-lane GLOBAL address and undone on the ds_read.
-    constexpr bool SWZ = (BN % 32 == 0);
-    constexpr int A_F4 = BM * BK / 4, A_PER = (A_F4 + NT - 1) / NT;
-    constexpr int B_INST = BK * BN / 256;               // 1 KiB wave-instructions per B tile
-    constexpr int B_PER = (B_INST + NW - 1) / NW;       // per wave
-    constexpr int A_FLOATS = BM * AP, B_FLOATS = BK * BN;
-    constexpr int BUF = (A_FLOATS + B_FLOATS + 3) / 4 * 4;
-    // one LDS object only (a second __shared__ array makes hipcc drain vmcnt before every ds_read)
-    __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int wm = wv / WN, wn = wv % WN;
-    const int col = lane & 15, g = lane >> 4;
-    const int nb = (NSPLIT > 1) ? (int)(blockIdx.x % NSPLIT) : 0;
-    const int m0 = (int)(blockIdx.x / NSPLIT) * BM;
-    const int n0 = nb * BN;
-
-    f32x4 acc[MS][NS];
-#pragma unroll
-    for (int i = 0; i < MS; ++i)
-#pragma unroll
-        for (int j = 0; j < NS; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    // A tile: register staged (rows beyond M clamp to M-1: loaded, never stored)
-    float4 ra[A_PER];
-    const float* a_src[A_PER];
-#pragma unroll
-    for (int i = 0; i < A_PER; ++i) {
-        const int e = tid + i * NT;
-        const int row = (e / (BK / 4)) % BM, k4 = e % (BK / 4);
-        a_src[i] = A + (size_t)min(m0 + row, M - 1) * lda + k4 * 4;
-    }
-    // B tile: wave wv issues instructions wv, wv + NW, ...; instruction q covers float4
-    // indices [64 q, 64 q + 63] of the linear tile
-    const float* b_src[B_PER];
-#pragma unroll
-    for (int i = 0; i < B_PER; ++i) {
-        const int e = (wv + i * NW) * 64 + lane;  // float4 index in the tile
-        const int row = (e / (BN / 4)) % BK;
-        int c4 = e % (BN / 4);
-        if (SWZ) c4 ^= (row & 1) << 2;
-        b_src[i] = W + (size_t)row * LDW + n0 + c4 * 4;
-    }
-#define DENSE_GLOAD(kc, buf)                                                                          \
-    {                                                                                                 \
-        _Pragma("unroll") for (int i = 0; i < A_PER; ++i)                                             \
-            ra[i] = *reinterpret_cast<const float4*>(a_src[i] + (size_t)(kc) * BK);                   \
-        _Pragma("unroll") for (int i = 0; i < B_PER; ++i) {                                           \
-            if ((i + 1) * NW <= B_INST || wv + i * NW < B_INST)                                       \
-                __builtin_amdgcn_global_load_lds((glb_void*)(b_src[i] + (size_t)(kc) * BK * LDW),     \
-                                                 (lds_void*)(smem + (buf) * BUF + A_FLOATS + (wv + i * NW) * 256), \
-                                                 16, 0, 0);                                           \
-        }                                                                                             \
-    }
-#define DENSE_ASTORE(buf)                                                                             \
-    {                                                                                                 \
-        _Pragma("unroll") for (int i = 0; i < A_PER; ++i) {                                           \
-            const int e = tid + i * NT;                                                               \
-            if ((i + 1) * NT <= A_F4 || e < A_F4) {                                                   \
-                const int row = e / (BK / 4), k4 = e % (BK / 4);                                      \
-                float* d = smem + (buf) * BUF + row * AP + k4 * 4;                                    \
-                d[0] = ra[i].x; d[1] = ra[i].y; d[2] = ra[i].z; d[3] = ra[i].w;                       \
-            }                                                                                         \
-        }                                                                                             \
-    }
-
-    const int nk = K / BK;
-    DENSE_GLOAD(0, 0);
-    DENSE_ASTORE(0);
-    __syncthreads();  // (hipcc drains vmcnt here: the LDS-DMA of chunk 0 has landed)
-    const int b_col = wn * 16 * NS + col;
-    for (int kc = 0; kc < nk; ++kc) {
-        const int buf = kc & 1;
-        if (kc + 1 < nk) DENSE_GLOAD(kc + 1, buf ^ 1);  // in flight during the MFMAs below
-        const float* as = smem + buf * BUF + (wm * 16 * MS + col) * AP + g;
-        const float* bs = smem + buf * BUF + A_FLOATS + g * BN;
-#pragma unroll
-        for (int kq = 0; kq < BK / 4; ++kq) {
-            float a[MS], b[NS];
-#pragma unroll
-            for (int i = 0; i < MS; ++i) a[i] = as[i * 16 * AP + kq * 4];
-#pragma unroll
-            for (int j = 0; j < NS; ++j) {
-                int c = b_col + j * 16;
-                if (SWZ) c ^= (g & 1) << 4;  // row k = 4 kq + g is odd iff g is odd
-                b[j] = bs[kq * 4 * BN + c];
-            }
-#pragma unroll
-            for (int i = 0; i < MS; ++i)
-#pragma unroll
-                for (int j = 0; j < NS; ++j) acc[i][j] = MFMA16(a[i], b[j], acc[i][j]);
-        }
-        if (kc + 1 < nk) DENSE_ASTORE(buf ^ 1);
-        __syncthreads();
-    }
-#undef DENSE_GLOAD
-#undef DENSE_ASTORE
-
-    // epilogue: C layout row = 4g + r, col = lane & 15
-#pragma unroll
-    for (int j = 0; j < NS; ++j) {
-        const int n = n0 + wn * 16 * NS + j * 16 + col;
-        const float bv = bias[n];
-        float wq = 0.f;
-        if (QP) wq = W[(size_t)K * LDW + n];
-#pragma unroll
-        for (int i = 0; i < MS; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm * 16 * MS + i * 16 + 4 * g + r;
-                float v = acc[i][j][r];
-                if (QP) v = fmaf(qn, wq, v);
-                v = lrelu(v + bv);
-                if (m < M) out[(size_t)m * ldo + n] = v;
-            }
-    }
-}
-
-template <int MS, int NS, int WM, int WN, int BK, int NSPLIT, bool QP>
-static void launch_dense(const float* A, int lda, int K, const float* W, const float* bias, float qn, float* out,
-                         int ldo, int M, hipStream_t s) {
-    constexpr int BM = 16 * MS * WM;
-    hipLaunchKernelGGL((k_dense<MS, NS, WM, WN, BK, NSPLIT, QP>), dim3(((M + BM - 1) / BM) * NSPLIT),
-                       dim3(64 * WM * WN), 0, s, A, lda, K, W, bias, qn, out, ldo, M);
-}
-
-static int fc1_variant() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("ETHCNN_FC1_VARIANT");  // development knob: tile-shape A/B runs
-        v = e ? atoi(e) : 6;  // measured best on MI355X (profiles/r01_fc1_variants.txt)
-    }
-    return v;
-}
-
-void launch_fc1(const Workspace& ws, const DeviceWeights& w, int n, float* out, hipStream_t s) {
-    const float* A = ws.feat;
-    switch (fc1_variant()) {
-        case 0:  // BM 64 x BN 448, BK 16, 4 waves
-            launch_dense<4, 7, 1, 4, 16, 1, false>(A, kNFeat, kNFeat, w.fc1_w, w.fc1_b, 0.f, out, kNVec, n, s);
-            break;
-        case 1:  // BM 128 x BN 224 (N split 2), 4 waves
-            launch_dense<4, 7, 2, 2, 16, 2, false>(A, kNFeat, kNFeat, w.fc1_w, w.fc1_b, 0.f, out, kNVec, n, s);
-            break;
-        case 2:  // BM 256 x BN 224 (N split 2), 8 waves
-            launch_dense<4, 7, 4, 2, 16, 2, false>(A, kNFeat, kNFeat, w.fc1_w, w.fc1_b, 0.f, out, kNVec, n, s);
-            break;
-        case 3:  // BM 256 x BN 112 (N split 4), 4 waves
-            launch_dense<4, 7, 4, 1, 16, 4, false>(A, kNFeat, kNFeat, w.fc1_w, w.fc1_b, 0.f, out, kNVec, n, s);
-            break;
-        case 4:  // BM 128 x BN 448, 8 waves
-            launch_dense<4, 7, 2, 4, 16, 1, false>(A, kNFeat, kNFeat, w.fc1_w, w.fc1_b, 0.f, out, kNVec, n, s);
-            break;
-        case 5:  // BM 128 x BN 224, BK 32
-            launch_dense<4, 7, 2, 2, 32, 2, false>(A, kNFeat, kNFeat, w.fc1_w, w.fc1_b, 0.f, out, kNVec, n, s);
-            break;
-        default:  // 6: BM 128 x BN 112 (N split 4), wave 32 x 112, 4 waves, ~4 blocks / CU
-            launch_dense<2, 7, 4, 1, 16, 4, false>(A, kNFeat, kNFeat, w.fc1_w, w.fc1_b, 0.f, out, kNVec, n, s);
-            break;
-    }
-}
-
-void launch_fc2(const Workspace& ws, const DeviceWeights& w, int n, float qn, hipStream_t s) {
-    launch_dense<1, 3, 4, 1, 16, 1, true>(ws.h1 + kO1[0], kNVec, kN1[0], w.fc2_w[0], w.fc2_b[0], qn, ws.h2 + kO2[0], kNFc2, n, s);
-    launch_dense<2, 3, 2, 2, 16, 1, true>(ws.h1 + kO1[1], kNVec, kN1[1], w.fc2_w[1], w.fc2_b[1], qn, ws.h2 + kO2[1], kNFc2, n, s);
-    launch_dense<4, 3, 1, 4, 16, 1, true>(ws.h1 + kO1[2], kNVec, kN1[2], w.fc2_w[2], w.fc2_b[2], qn, ws.h2 + kO2[2], kNFc2, n, s);
-}
-
-// =========================================================================== k4 ======
-// FC3 + sigmoid + gate predicates.
-__device__ __forceinline__ float expf_canonical(float x) {
-    x = fminf(x, 80.0f);
-    x = fmaxf(x, -86.0f);
-    const float n = rintf(x * 1.44269504088896341f);
-    float r = fmaf(n, -0.693145751953125f, x);
-    r = fmaf(n, -1.42860682030941723212e-6f, r);
-    float p = 1.0f / 5040.0f;
-    p = fmaf(p, r, 1.0f / 720.0f);
-    p = fmaf(p, r, 1.0f / 120.0f);
-    p = fmaf(p, r, 1.0f / 24.0f);
-    p = fmaf(p, r, 1.0f / 6.0f);
-    p = fmaf(p, r, 0.5f);
-    p = fmaf(p, r, 1.0f);
-    p = fmaf(p, r, 1.0f);
-    return __int_as_float(__float_as_int(p) + (((int)n) << 23));
-}
-
-struct HeadParams {
-    const float* w3[3];
-    const float* b3[3];
-};
+// (k4: the fused FC2 + FC3 + sigmoid heads kernel lives in ethcnn_heads.hip)
 
 __device__ __forceinline__ long global_chunk(long gn, int nctu, int cpf) {
     const long f = gn / nctu;
     return f * cpf + (gn - f * nctu) / kSubBatch;
-}
-
-// One wave = 16 CTUs.  Per head: D[ctu][j] = sum_k H2[ctu][k] W3[k][j] as one 16x16 MFMA
-// tile (n3 = 1 / 4 / 16 real columns, the rest zero), K = 48 / 96 / 192 ascending -- the
-// canonical chain -- then the qp column, bias and sigmoid in the epilogue.  The three
-// heads' chains are independent and interleaved.
-__global__ __launch_bounds__(256) void k4_head(const float* __restrict__ H2, HeadParams hp, float qn, int N,
-                                               int nctu, int cpf, long ctu0, float thr1, float thr2,
-                                               float* __restrict__ logits, float* __restrict__ raw,
-                                               float* __restrict__ probs, int* __restrict__ flags) {
-    const int lane = threadIdx.x & 63, col = lane & 15, g = lane >> 4;
-    const int group = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int base = group * 16;
-    if (base >= N) return;
-    const int arow = min(base + col, N - 1);  // A operand row (clamped: loaded, never stored)
-    const float* x = H2 + (size_t)arow * kNFc2 + g;
-    f32x4 acc[3] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-    constexpr int N2[3] = {48, 96, 192}, N3[3] = {1, 4, 16}, O2[3] = {0, 48, 144}, O3[3] = {0, 1, 5};
-#pragma unroll 4
-    for (int s = 0; s < 48; ++s) {  // 48 k-steps cover head16; head32 uses the first 24, head64 the first 12
-        const int k = 4 * s + g;
-        {
-            const float b = hp.w3[2][k * 16 + col];
-            acc[2] = MFMA16(x[O2[2] + 4 * s], b, acc[2]);
-        }
-        if (s < 24) {
-            const float b = (col < 4) ? hp.w3[1][k * 4 + col] : 0.0f;
-            acc[1] = MFMA16(x[O2[1] + 4 * s], b, acc[1]);
-        }
-        if (s < 12) {
-            const float b = (col < 1) ? hp.w3[0][k] : 0.0f;
-            acc[0] = MFMA16(x[O2[0] + 4 * s], b, acc[0]);
-        }
-    }
-    const long chunk0 = global_chunk(ctu0, nctu, cpf);
-#pragma unroll
-    for (int h = 0; h < 3; ++h) {
-        if (col < N3[h]) {
-            const float wq = hp.w3[h][N2[h] * N3[h] + col], bv = hp.b3[h][col];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = base + 4 * g + r;
-                if (i < N) {
-                    const float z = fmaf(qn, wq, acc[h][r]) + bv;
-                    const float p = 1.0f / (1.0f + expf_canonical(-z));
-                    const size_t o = (size_t)i * kNOut + O3[h] + col;
-                    logits[o] = z;
-                    raw[o] = p;
-                    probs[o] = p;
-                    // any(y64 > THR_L1_LOWER) / any(y32_tmp > THR_L2_LOWER) over the sub-batch
-                    const bool hit = (h == 0 && p > thr1) || (h == 1 && p > thr2);
-                    if (hit) {
-                        int* f = flags + 2 * (global_chunk(ctu0 + i, nctu, cpf) - chunk0) + h;
-                        if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
-                            __hip_atomic_store(f, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-            }
-        }
-    }
-}
-
-void launch_head(const Workspace& ws, const DeviceWeights& w, int n, float qn, int nctu, long ctu0, float thr1,
-                 float thr2, float* d_probs, hipStream_t s) {
-    HeadParams hp;
-    for (int h = 0; h < 3; ++h) {
-        hp.w3[h] = w.fc3_w[h];
-        hp.b3[h] = w.fc3_b[h];
-    }
-    hipLaunchKernelGGL(k4_head, dim3((n + 63) / 64), dim3(256), 0, s, ws.h2, hp, qn, n, nctu,
-                       chunks_per_frame(nctu), ctu0, thr1, thr2, ws.logits, ws.raw, d_probs, ws.flags);
 }
 
 // =========================================================================== k5 ======

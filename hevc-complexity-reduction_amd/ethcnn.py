@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libethcnn.so")
 NOUT, NFEAT, NVEC, NFC2, SUB_BATCH = 21, 2688, 448, 336, 1024
 BLOB_FLOATS = 1288210
 
-STAGES = ("tile", "trunk", "fc1", "fc2", "head", "gate")
+STAGES = ("tile", "trunk", "fc1", "heads", "gate")
 DBG_FEATURES, DBG_FC1, DBG_FC2, DBG_LOGITS, DBG_RAW_PROBS = range(5)
 _DBG_WIDTH = {DBG_FEATURES: NFEAT, DBG_FC1: NVEC, DBG_FC2: NFC2, DBG_LOGITS: NOUT, DBG_RAW_PROBS: NOUT}
 
@@ -31,7 +31,7 @@ class Options(ctypes.Structure):
 
 
 class StageTimes(ctypes.Structure):
-    _fields_ = [("ms", ctypes.c_double * 6), ("launches", ctypes.c_int64 * 6), ("ctus", ctypes.c_int64)]
+    _fields_ = [("ms", ctypes.c_double * 5), ("launches", ctypes.c_int64 * 5), ("ctus", ctypes.c_int64)]
 
 
 class CkptEntry(ctypes.Structure):

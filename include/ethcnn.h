@@ -125,10 +125,9 @@ enum {
     ETHCNN_STAGE_TILE = 0,  /* k0: CTU load + zero-pad tiling + integer pooling (HBM-bound) */
     ETHCNN_STAGE_TRUNK = 1, /* k1: mean removal + 3 conv stages x 21 units (MFMA)          */
     ETHCNN_STAGE_FC1 = 2,   /* k2: [N,2688]x[2688,448] (MFMA) -- dominant kernel           */
-    ETHCNN_STAGE_FC2 = 3,   /* k3: three qp-conditioned FC2 layers (MFMA)                  */
-    ETHCNN_STAGE_HEAD = 4,  /* k4: FC3 + sigmoid + gate flags                              */
-    ETHCNN_STAGE_GATE = 5,  /* k5: batch-level gates (zero fill)                           */
-    ETHCNN_NSTAGES = 6
+    ETHCNN_STAGE_HEADS = 3, /* k3: FC2 + FC3 + sigmoid of the three heads, fused (MFMA)    */
+    ETHCNN_STAGE_GATE = 4,  /* k5: batch-level gates (zero fill)                           */
+    ETHCNN_NSTAGES = 5
 };
 typedef struct ethcnn_stage_times {
     double ms[ETHCNN_NSTAGES];       /* accumulated kernel time per stage since reset */

@@ -121,8 +121,8 @@ def lib():
         fp = ctypes.POINTER(ctypes.c_float)
         up = ctypes.POINTER(ctypes.c_uint8)
         L.oracle_features.argtypes = [fp, up, ctypes.c_int, ctypes.c_int, ctypes.c_int, fp]
-        L.oracle_fc1.argtypes = [fp, fp, ctypes.c_int, fp]
-        L.oracle_heads.argtypes = [fp, fp, ctypes.c_int, ctypes.c_int, fp, fp]
+        L.oracle_fc1.argtypes = [fp, fp, ctypes.c_int, ctypes.c_int, fp]
+        L.oracle_heads.argtypes = [fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, fp, fp]
         L.oracle_gates.argtypes = [fp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float]
         L.oracle_tile_frame.argtypes = [up, ctypes.c_int, ctypes.c_int, ctypes.c_long, up]
         L.oracle_predict_frames.argtypes = [fp, up, ctypes.c_int, ctypes.c_int, ctypes.c_long,
@@ -158,21 +158,21 @@ def features(blob, ctus, mode=0, resi=0):
     return F
 
 
-def fc1(blob, F):
+def fc1(blob, F, mode=0):
     blob = _blob(blob)
     F = np.ascontiguousarray(F, dtype=np.float32)
     H1 = np.empty((F.shape[0], NH1), dtype=np.float32)
-    lib().oracle_fc1(_f(blob), _f(F), F.shape[0], _f(H1))
+    lib().oracle_fc1(_f(blob), _f(F), F.shape[0], mode, _f(H1))
     return H1
 
 
-def heads(blob, H1, qp):
+def heads(blob, H1, qp, mode=0):
     """-> (ungated probs [n,21], logits [n,21])"""
     blob = _blob(blob)
     H1 = np.ascontiguousarray(H1, dtype=np.float32)
     P = np.empty((H1.shape[0], NOUT), dtype=np.float32)
     Z = np.empty((H1.shape[0], NOUT), dtype=np.float32)
-    lib().oracle_heads(_f(blob), _f(H1), H1.shape[0], int(qp), _f(P), _f(Z))
+    lib().oracle_heads(_f(blob), _f(H1), H1.shape[0], int(qp), mode, _f(P), _f(Z))
     return P, Z
 
 

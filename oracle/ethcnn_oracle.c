@@ -239,8 +239,17 @@ static void ctu_features(const uint8_t* ctu, const float* blob, int mode, int re
     }
 }
 
-/* FC1 of the three heads: H1[448] = lrelu(F.W1 + b1), order [64 | 128 | 256]. Ascending k. */
-static void ctu_fc1(const float* F, const float* blob, float* H1) {
+/* position t of the accumulation chain -> k.  literal: ascending.  canonical (FC1, FC2): inside
+ * every 16-wide chunk the kernel's MFMA steps e = 0..3 take k = 16c + 4g + e for g = 0..3
+ * (a lane loads one float4 of activations per chunk; csrc/ethcnn_dense.hip). */
+static inline int fc_k(int t, int mode) {
+    if (mode == 1) return t;
+    const int r = t & 15;
+    return (t & ~15) + 4 * (r & 3) + (r >> 2);
+}
+
+/* FC1 of the three heads: H1[448] = lrelu(F.W1 + b1), order [64 | 128 | 256]. */
+static void ctu_fc1(const float* F, const float* blob, int mode, float* H1) {
     int o = 0;
     for (int h = 0; h < 3; ++h) {
         const int n1 = N1[h];
@@ -248,7 +257,8 @@ static void ctu_fc1(const float* F, const float* blob, float* H1) {
         const float* b = blob + OFF_FC1B[h];
         float acc[256];
         for (int f = 0; f < n1; ++f) acc[f] = 0.0f;
-        for (int k = 0; k < NFEAT; ++k) {
+        for (int t = 0; t < NFEAT; ++t) {
+            const int k = fc_k(t, mode);
             const float a = F[k];
             const float* w = W + (size_t)k * n1;
             for (int f = 0; f < n1; ++f) acc[f] = fmaf(a, w[f], acc[f]);
@@ -259,7 +269,7 @@ static void ctu_fc1(const float* F, const float* blob, float* H1) {
 }
 
 /* FC2 + FC3 + sigmoid: probs_raw[21] (before the batch gates), optional logits[21]. */
-static void ctu_heads(const float* H1, const float* blob, float qn, float* probs, float* logits) {
+static void ctu_heads(const float* H1, const float* blob, float qn, int mode, float* probs, float* logits) {
     int o1 = 0, o3 = 0;
     for (int h = 0; h < 3; ++h) {
         const int n1 = N1[h], n2 = N2[h], n3 = N3[h];
@@ -269,7 +279,8 @@ static void ctu_heads(const float* H1, const float* blob, float qn, float* probs
         const float* b3 = blob + OFF_FC3B[h];
         float acc[192], h2[192];
         for (int j = 0; j < n2; ++j) acc[j] = 0.0f;
-        for (int k = 0; k < n1; ++k) {
+        for (int t = 0; t < n1; ++t) {
+            const int k = fc_k(t, mode);
             const float a = H1[o1 + k];
             for (int j = 0; j < n2; ++j) acc[j] = fmaf(a, W2[k * n2 + j], acc[j]);
         }
@@ -277,8 +288,10 @@ static void ctu_heads(const float* H1, const float* blob, float qn, float* probs
         for (int j = 0; j < n2; ++j) h2[j] = lrelu(acc[j] + b2[j]);
         float z[16];
         for (int j = 0; j < n3; ++j) z[j] = 0.0f;
-        for (int k = 0; k < n2; ++k)
+        for (int t = 0; t < n2; ++t) {
+            const int k = fc_k(t, mode);
             for (int j = 0; j < n3; ++j) z[j] = fmaf(h2[k], W3[k * n3 + j], z[j]);
+        }
         for (int j = 0; j < n3; ++j) {
             z[j] = fmaf(qn, W3[n2 * n3 + j], z[j]) + b3[j];
             if (logits) logits[o3 + j] = z[j];
@@ -317,18 +330,18 @@ int oracle_features(const float* blob, const uint8_t* ctus, int n, int mode, int
     return 0;
 }
 
-int oracle_fc1(const float* blob, const float* F, int n, float* H1) {
+int oracle_fc1(const float* blob, const float* F, int n, int mode, float* H1) {
 #pragma omp parallel for schedule(dynamic, 8)
-    for (int i = 0; i < n; ++i) ctu_fc1(F + (size_t)i * NFEAT, blob, H1 + (size_t)i * NH1);
+    for (int i = 0; i < n; ++i) ctu_fc1(F + (size_t)i * NFEAT, blob, mode, H1 + (size_t)i * NH1);
     return 0;
 }
 
 /* H1 [n][448] -> ungated probabilities [n][21] (+ optional logits). */
-int oracle_heads(const float* blob, const float* H1, int n, int qp, float* probs, float* logits) {
+int oracle_heads(const float* blob, const float* H1, int n, int qp, int mode, float* probs, float* logits) {
     const float qn = (float)qp * c51();
 #pragma omp parallel for schedule(dynamic, 8)
     for (int i = 0; i < n; ++i)
-        ctu_heads(H1 + (size_t)i * NH1, blob, qn, probs + (size_t)i * NOUT,
+        ctu_heads(H1 + (size_t)i * NH1, blob, qn, mode, probs + (size_t)i * NOUT,
                   logits ? logits + (size_t)i * NOUT : (float*)0);
     return 0;
 }
@@ -380,8 +393,8 @@ int oracle_predict_frames(const float* blob, const uint8_t* luma, int w, int h, 
         for (int i = 0; i < nf * nctu; ++i) {
             float F[NFEAT], H1[NH1];
             ctu_features(ctus + (size_t)i * 4096, blob, mode, 0, o1, o2, o3, F);
-            ctu_fc1(F, blob, H1);
-            ctu_heads(H1, blob, qn, P + (size_t)i * NOUT, (float*)0);
+            ctu_fc1(F, blob, mode, H1);
+            ctu_heads(H1, blob, qn, mode, P + (size_t)i * NOUT, (float*)0);
         }
         for (int f = 0; f < nf; ++f) oracle_gates(P + (size_t)f * nctu * NOUT, nctu, 1024, thr1, thr2);
     }
@@ -402,7 +415,7 @@ int oracle_resi_vectors(const float* blob, const uint8_t* luma, int w, int h, lo
     for (int i = 0; i < nctu; ++i) {
         float F[NFEAT];
         ctu_features(ctus + (size_t)i * 4096, blob, mode, 1, o1, o2, o3, F);
-        ctu_fc1(F, blob, vec + (size_t)i * NH1);
+        ctu_fc1(F, blob, mode, vec + (size_t)i * NH1);
     }
     free(ctus);
     return 0;

@@ -17,8 +17,8 @@ TOL = 1e-4
 
 def _run(oracle, blob, ctus, qp, mode, resi=0):
     F = oracle.features(blob, ctus, mode, resi)
-    H1 = oracle.fc1(blob, F)
-    P, Z = oracle.heads(blob, H1, qp)
+    H1 = oracle.fc1(blob, F, mode)
+    P, Z = oracle.heads(blob, H1, qp, mode)
     return F, H1, P, Z
 
 
@@ -41,7 +41,7 @@ def test_oracle_resi_vs_torch_golden(oracle):
     seed, gain = G["resi_seed_gain"]
     blob = oracle.synth_blob(int(seed), float(gain))
     for mode in (0, 1):
-        V = oracle.fc1(blob, oracle.features(blob, G["resi_ctus"], mode, 1))
+        V = oracle.fc1(blob, oracle.features(blob, G["resi_ctus"], mode, 1), mode)
         assert np.abs(V - G["resi_vec"]).max() <= 2e-5
 
 
