@@ -14,9 +14,9 @@
 //   k5_gate   tf.cond zero fill (:175,187).
 //
 // Arithmetic contract ("canonical order"): every dot product is a single
-// k-ordered fmaf chain starting from 0 (what one fp32 MFMA accumulator computes), bias is
-// added afterwards with one rounding, leaky-ReLU = max(0.2f*h, h), pooling and block means
-// come from exact integer pixel sums.  oracle/ethcnn_oracle.c (mode 0) restates exactly
+// k-ordered fmaf chain (what one fp32 MFMA accumulator computes) -- starting from the bias in
+// the trunk convs, from 0 with the bias added afterwards in the FC layers -- leaky-ReLU =
+// max(0.2f*h, h), pooling and block means come from exact integer pixel sums.  oracle/ethcnn_oracle.c (mode 0) restates exactly
 // this, and the parity tests require bit-identical results.  Compile with
 // -ffp-contract=off: the operation sequence below is the contract.
 #include <hip/hip_runtime.h>
@@ -239,13 +239,14 @@ __device__ __forceinline__ void trunk_tasks(const uint4* __restrict__ X, int nta
                 const uint4 d = raw[j];
                 const uint32_t w[4] = {d.x, d.y, d.z, d.w};
 #pragma unroll
-                for (int q1 = 0; q1 < 4; ++q1)
+                for (int q1 = 0; q1 < 4; ++q1) {
+                    T = (int)__builtin_amdgcn_udot4(w[q1], 0x01010101u, (unsigned)T, false);  // exact byte sum
 #pragma unroll
                     for (int kx = 0; kx < 4; ++kx) {
                         const int s = (int)((w[q1] >> (8 * kx)) & 0xff);
-                        T += s;
-                        x[4 * j + q1][kx] = px_value<RESI>(s, 1);
+                        x[4 * j + q1][kx] = RESI ? px_value<true>(s, 1) : (float)s;
                     }
+                }
             }
         } else {
 #pragma unroll
@@ -253,12 +254,13 @@ __device__ __forceinline__ void trunk_tasks(const uint4* __restrict__ X, int nta
                 const uint4 d = raw[j];
                 const uint32_t w[4] = {d.x, d.y, d.z, d.w};
 #pragma unroll
+                for (int i = 0; i < 4; ++i) T += (int)((w[i] & 0xffffu) + (w[i] >> 16));
+#pragma unroll
                 for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
                     for (int kx = 0; kx < 4; ++kx) {
                         const int s = (int)((w[2 * hh + (kx >> 1)] >> (16 * (kx & 1))) & 0xffff);
-                        T += s;
-                        x[2 * j + hh][kx] = px_value<RESI>(s, POOL * POOL) * SCALE;
+                        x[2 * j + hh][kx] = RESI ? px_value<true>(s, POOL * POOL) * SCALE : (float)s;
                     }
             }
         }
@@ -268,7 +270,11 @@ __device__ __forceinline__ void trunk_tasks(const uint4* __restrict__ X, int nta
         }
         T += __shfl_xor(T, 16);
         T += __shfl_xor(T, 32);
+        // canonical centring: AI  v = fma(float(sum), c255 * 2^-p, -mean)  (one rounding);
+        //                                 resi v = x - mean with x = ((s - 128 cnt) / 255 * 10) * 2^-p
         const float mean = px_value<RESI>(T, 256 * POOL * POOL) * (SCALE * (1.0f / 256.0f));
+        const float negmean = -mean;
+        constexpr float C255S = (1.0f / 255.0f) * SCALE;  // exact: SCALE is a power of two
 
         // ---- where this column's outputs go
         int n, by, bx;
@@ -282,19 +288,23 @@ __device__ __forceinline__ void trunk_tasks(const uint4* __restrict__ X, int nta
 #pragma unroll
         for (int q2 = 0; q2 < 4; ++q2) {
             // conv1: 4 patches (q1) x 4 k-steps (s = kx); lane supplies v[patch][ky=g][kx=s]
+            // accumulators start at the bias (MFMA C operand): one rounding chain, no separate add
             f32x4 c1[4];
 #pragma unroll
-            for (int q1 = 0; q1 < 4; ++q1) c1[q1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int q1 = 0; q1 < 4; ++q1) c1[q1] = (f32x4){B1[0], B1[1], B1[2], B1[3]};
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int q1 = 0; q1 < 4; ++q1) c1[q1] = MFMA16(A1[s], x[4 * q2 + q1][s] - mean, c1[q1]);
+                for (int q1 = 0; q1 < 4; ++q1) {
+                    const float xv = x[4 * q2 + q1][s];
+                    c1[q1] = MFMA16(A1[s], RESI ? xv - mean : fmaf(xv, C255S, negmean), c1[q1]);
+                }
 #pragma unroll
             for (int q1 = 0; q1 < 4; ++q1)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) c1[q1][r] = lrelu(c1[q1][r] + B1[r]);
+                for (int r = 0; r < 4; ++r) c1[q1][r] = lrelu(c1[q1][r]);
             // conv2: K = (q1, r, g) with ci = 4g + r; two M tiles (channels 0-15, 16-23 + pad)
-            f32x4 c2[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+            f32x4 c2[2] = {(f32x4){B2[0][0], B2[0][1], B2[0][2], B2[0][3]}, (f32x4){B2[1][0], B2[1][1], B2[1][2], B2[1][3]}};
 #pragma unroll
             for (int q1 = 0; q1 < 4; ++q1)
 #pragma unroll
@@ -305,7 +315,7 @@ __device__ __forceinline__ void trunk_tasks(const uint4* __restrict__ X, int nta
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) c2[t][r] = lrelu(c2[t][r] + B2[t][r]);
+                for (int r = 0; r < 4; ++r) c2[t][r] = lrelu(c2[t][r]);
             a2[q2][0] = c2[0];
             a2[q2][1] = c2[1];
             if (valid) {
@@ -317,7 +327,7 @@ __device__ __forceinline__ void trunk_tasks(const uint4* __restrict__ X, int nta
         }
         // conv3: phase A = channels 0..15 of the 4 positions, phase B = channels 16..23 with
         // positions (2j, 2j+1) packed into the lower / upper lane halves.
-        f32x4 c3[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+        f32x4 c3[2] = {(f32x4){B3[0][0], B3[0][1], B3[0][2], B3[0][3]}, (f32x4){B3[1][0], B3[1][1], B3[1][2], B3[1][3]}};
 #pragma unroll
         for (int q2 = 0; q2 < 4; ++q2)
 #pragma unroll
@@ -340,7 +350,7 @@ __device__ __forceinline__ void trunk_tasks(const uint4* __restrict__ X, int nta
             for (int t = 0; t < 2; ++t) {
                 f32x4 o;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = lrelu(c3[t][r] + B3[t][r]);
+                for (int r = 0; r < 4; ++r) o[r] = lrelu(c3[t][r]);
                 *reinterpret_cast<f32x4*>(dst + 16 * t + 4 * g) = o;
             }
         }

@@ -139,9 +139,11 @@ static void build_orders(int mode, int ord1[16], int ord2[64], int ord3[96]) {
 
 /* One "unit": a 16x16 block at branch resolution.  v = mean-removed input.
  * a2out[q2][24] (q2 = 2*qy+qx), a3out[32]. */
-static void unit_forward(const float v[256], const float* blob, int br, const int ord1[16],
+static void unit_forward(const float v[256], const float* blob, int br, int mode, const int ord1[16],
                          const int ord2[64], const int ord3[96], float a2out[4][24],
                          float a3out[32]) {
+    /* canonical: the chain starts at the bias (MFMA C operand); literal: conv2d from 0, then + b */
+    const int binit = (mode == 0);
     const float* w1 = blob + OFF_CW[br][0];
     const float* b1 = blob + OFF_CB[br][0];
     const float* w2 = blob + OFF_CW[br][1];
@@ -152,34 +154,34 @@ static void unit_forward(const float v[256], const float* blob, int br, const in
     for (int py = 0; py < 4; ++py)
         for (int px = 0; px < 4; ++px) {
             float acc[16];
-            for (int co = 0; co < 16; ++co) acc[co] = 0.0f;
+            for (int co = 0; co < 16; ++co) acc[co] = binit ? b1[co] : 0.0f;
             for (int t = 0; t < 16; ++t) {
                 const int k = ord1[t], ky = k >> 2, kx = k & 3;
                 const float in = v[(4 * py + ky) * 16 + 4 * px + kx];
                 for (int co = 0; co < 16; ++co) acc[co] = fmaf(w1[k * 16 + co], in, acc[co]);
             }
-            for (int co = 0; co < 16; ++co) a1[py * 4 + px][co] = lrelu(acc[co] + b1[co]);
+            for (int co = 0; co < 16; ++co) a1[py * 4 + px][co] = lrelu(binit ? acc[co] : acc[co] + b1[co]);
         }
     for (int q2 = 0; q2 < 4; ++q2) {
         const int qy = q2 >> 1, qx = q2 & 1;
         float acc[24];
-        for (int co = 0; co < 24; ++co) acc[co] = 0.0f;
+        for (int co = 0; co < 24; ++co) acc[co] = binit ? b2[co] : 0.0f;
         for (int t = 0; t < 64; ++t) {
             const int k = ord2[t], q1 = k >> 4, ci = k & 15, ky = q1 >> 1, kx = q1 & 1;
             const float in = a1[(2 * qy + ky) * 4 + 2 * qx + kx][ci];
             for (int co = 0; co < 24; ++co) acc[co] = fmaf(w2[k * 24 + co], in, acc[co]);
         }
-        for (int co = 0; co < 24; ++co) a2out[q2][co] = lrelu(acc[co] + b2[co]);
+        for (int co = 0; co < 24; ++co) a2out[q2][co] = lrelu(binit ? acc[co] : acc[co] + b2[co]);
     }
     {
         float acc[32];
-        for (int co = 0; co < 32; ++co) acc[co] = 0.0f;
+        for (int co = 0; co < 32; ++co) acc[co] = binit ? b3[co] : 0.0f;
         for (int t = 0; t < 96; ++t) {
             const int k = ord3[t], q2 = k / 24, ci = k % 24;
             const float in = a2out[q2][ci];
             for (int co = 0; co < 32; ++co) acc[co] = fmaf(w3[k * 32 + co], in, acc[co]);
         }
-        for (int co = 0; co < 32; ++co) a3out[co] = lrelu(acc[co] + b3[co]);
+        for (int co = 0; co < 32; ++co) a3out[co] = lrelu(binit ? acc[co] : acc[co] + b3[co]);
     }
 }
 
@@ -201,6 +203,7 @@ static void ctu_features(const uint8_t* ctu, const float* blob, int mode, int re
         for (int by = 0; by < nb; ++by)
             for (int bx = 0; bx < nb; ++bx) {
                 float x[256], v[256], mean;
+                int isum[256];
                 if (mode == 0) {
                     int T = 0;
                     for (int yy = 0; yy < 16; ++yy)
@@ -210,6 +213,7 @@ static void ctu_features(const uint8_t* ctu, const float* blob, int mode, int re
                             for (int dy = 0; dy < pool; ++dy)
                                 for (int dx = 0; dx < pool; ++dx) s += ctu[(y0 + dy) * 64 + x0 + dx];
                             T += s;
+                            isum[yy * 16 + xx] = s;
                             x[yy * 16 + xx] = px_value(s, pool * pool, resi) * scale;
                         }
                     mean = px_value(T, 256 * pool * pool, resi) * (scale * (1.0f / 256.0f));
@@ -227,9 +231,14 @@ static void ctu_features(const uint8_t* ctu, const float* blob, int mode, int re
                         }
                     mean = msum;
                 }
-                for (int i = 0; i < 256; ++i) v[i] = x[i] - mean;
+                if (mode == 0 && !resi) { /* canonical AI centring: one rounding, v = fma(sum, c255 * 2^-p, -mean) */
+                    const float c = c255() * scale;
+                    for (int i = 0; i < 256; ++i) v[i] = fmaf((float)isum[i], c, -mean);
+                } else {
+                    for (int i = 0; i < 256; ++i) v[i] = x[i] - mean;
+                }
                 float a2[4][24], a3[32];
-                unit_forward(v, blob, br, ord1, ord2, ord3, a2, a3);
+                unit_forward(v, blob, br, mode, ord1, ord2, ord3, a2, a3);
                 memcpy(F + OFF3[br] + (by * nb + bx) * 32, a3, 32 * sizeof(float));
                 for (int q2 = 0; q2 < 4; ++q2) {
                     const int y = 2 * by + (q2 >> 1), xx = 2 * bx + (q2 & 1);
