@@ -178,18 +178,25 @@ extern "C" int ethcnn_device_name(const ethcnn_ctx* c, char* out, size_t cap) {
 // -------------------------------------------------------------------- weights -------
 static int upload_weights(ethcnn_ctx* c) {
     HIPCHK(c, hipSetDevice(c->device));
-    // one arena: trunk_w | trunk_b | fc1_w | fc1_b | fc2 w,b x3 | fc3 w,b x3 (each 64-float aligned)
+    // one arena: trunk_w | trunk_b | fc1 image (BN 112) | fc1_b | fc2 w,b x3 | fc3 w,b x3 | fc1 image (BN 64)
+    // (each 64-float aligned)
     std::vector<size_t> sizes = {(size_t)3 * kTrunkWFrags * 64, (size_t)3 * kTrunkBFrags * 64,
                                  (size_t)kNFeat * kNVec, (size_t)kNVec};
     for (int h = 0; h < 3; ++h) { sizes.push_back((size_t)(kN1[h] + 1) * kN2[h]); sizes.push_back((size_t)kN2[h]); }
     for (int h = 0; h < 3; ++h) { sizes.push_back((size_t)(kN2[h] + 1) * kN3[h]); sizes.push_back((size_t)kN3[h]); }
+    sizes.push_back((size_t)kNFeat * kNVec);  // [16]
     std::vector<size_t> offs;
     size_t total = 0;
     for (size_t s : sizes) { offs.push_back(total); total += (s + 63) / 64 * 64; }
     std::vector<float> host(total, 0.0f);
     const float* blob = c->blob.data();
     pack_trunk_fragments(blob, host.data() + offs[0], host.data() + offs[1]);
-    pack_fc1(blob, host.data() + offs[2], host.data() + offs[3]);
+    {
+        std::vector<float> wcat((size_t)kNFeat * kNVec);
+        pack_fc1(blob, wcat.data(), host.data() + offs[3]);
+        pack_fc1_image(wcat.data(), 112, 16, host.data() + offs[2]);
+        pack_fc1_image(wcat.data(), 64, 32, host.data() + offs[16]);
+    }
     for (int h = 0; h < 3; ++h) {
         std::memcpy(host.data() + offs[4 + 2 * h], blob + kOffFc2W[h], sizes[4 + 2 * h] * 4);
         std::memcpy(host.data() + offs[5 + 2 * h], blob + kOffFc2B[h], sizes[5 + 2 * h] * 4);
@@ -202,7 +209,8 @@ static int upload_weights(ethcnn_ctx* c) {
     DeviceWeights& d = c->dw;
     d.trunk_w = c->dw_arena + offs[0];
     d.trunk_b = c->dw_arena + offs[1];
-    d.fc1_w = c->dw_arena + offs[2];
+    d.fc1_img112 = c->dw_arena + offs[2];
+    d.fc1_img64 = c->dw_arena + offs[16];
     d.fc1_b = c->dw_arena + offs[3];
     for (int h = 0; h < 3; ++h) {
         d.fc2_w[h] = c->dw_arena + offs[4 + 2 * h];
@@ -667,5 +675,15 @@ extern "C" int ethcnn_debug_fetch(ethcnn_ctx* c, int which, float* out, size_t n
         default: return set_err(c, ETHCNN_ERR_ARG, "unknown debug tensor %d", which);
     }
     if (!src || nfloats > (size_t)c->last_n * per) return set_err(c, ETHCNN_ERR_ARG, "debug_fetch: last pass had %d CTUs", c->last_n);
-    return ethcnn_memcpy_d2h(c, out, src, nfloats * 4);
+    if (which != ETHCNN_DBG_FEATURES) return ethcnn_memcpy_d2h(c, out, src, nfloats * 4);
+    // features live as [group of 16 CTUs][k/4][16][4] (ethcnn_dense.hip); hand back [n][2688]
+    const size_t n = (nfloats + kNFeat - 1) / kNFeat, groups = (n + 15) / 16;
+    std::vector<float> rawf(groups * 16 * kNFeat);
+    int rc = ethcnn_memcpy_d2h(c, rawf.data(), src, rawf.size() * 4);
+    if (rc) return rc;
+    for (size_t i = 0; i < nfloats; ++i) {
+        const size_t row = i / kNFeat, k = i % kNFeat;
+        out[i] = rawf[((row / 16) * (kNFeat / 4) + k / 4) * 64 + (row % 16) * 4 + (k % 4)];
+    }
+    return ETHCNN_OK;
 }

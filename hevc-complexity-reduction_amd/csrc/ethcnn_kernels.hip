@@ -38,13 +38,15 @@ int chunks_per_frame(int nctu) { return (nctu + kSubBatch - 1) / kSubBatch; }
 // =========================================================================== k0 ======
 // One block = 4 consecutive CTUs (global raster index n0 = 4*blockIdx.x over the frame
 // sequence).  Stage: 4 x (64 rows x 64 B) coalesced 16-B loads -> LDS (row pitch 17 dwords)
-// -> three outputs laid out so that every k1 load is one fully coalesced dwordx4 per lane:
-//   XS[n][j][lane]      uint4: dwords q1=0..3 = 4 pixels of row g of patch (q2=j, q1) of unit u
-//                       (lane = u + 16 g).  patch row Y = 16uy + 8(q2>>1) + 4(q1>>1) + g,
+// -> three outputs laid out so that every k1 load is one fully coalesced dwordx4 per lane.  A
+// trunk task is ONE unit position of 16 consecutive CTUs (a "group"); lane = c + 16 g with
+// c = n % 16 the CTU within the group and g the MFMA k-group:
+//   XS[(n/16)*16 + u][j][lane]  uint4: dwords q1=0..3 = 4 pixels of row g of patch (q2=j, q1) of
+//                       S unit u.  patch row Y = 16uy + 8(q2>>1) + 4(q1>>1) + g,
 //                       X = 16ux + 8(q2&1) + 4(q1&1) + 0..3.
-//   XM[n/4][j][lane]    uint4: patch rows d = 2j, 2j+1 (d = 4 q2 + q1), each 4 x u16 sums of
-//                       2x2 raw pixels; column = 4*(n%4) + unit(2x2).
-//   XL[n/16][j][lane]   same with 4x4 sums; column = n % 16.
+//   XM[(n/16)*4 + unit][j][lane] uint4: patch rows d = 2j, 2j+1 (d = 4 q2 + q1) of M unit
+//                       (2x2), each 4 x u16 sums of 2x2 raw pixels.
+//   XL[n/16][j][lane]   same with 4x4 sums.
 constexpr int kTilePitch = 17;
 
 template <bool FAST>
@@ -87,49 +89,48 @@ __global__ __launch_bounds__(256) void k0_tile(const uint8_t* __restrict__ luma,
     }
     __syncthreads();
 
-    // ---- XS: 4 CTUs x 256 uint4, thread t -> (j, lane)
-    {
-        const int j = t >> 6, lane = t & 63, u = lane & 15, g = lane >> 4;
+    const int grp = n0 >> 4, c16 = n0 & 15;
+    // ---- XS: 4 CTUs x 16 units x 4 j x 4 g = 1024 uint4; 4 consecutive threads = the 4 CTUs
+    // of one (u, j, g) -> 64 contiguous bytes
+#pragma unroll
+    for (int rep = 0; rep < 4; ++rep) {
+        const int e = t + 256 * rep;
+        const int c = e & 3, g = (e >> 2) & 3, j = (e >> 4) & 3, u = e >> 6;
         const int uy = u >> 2, ux = u & 3;
+        if (n0 + c < n_total) {
+            uint32_t d[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if (n0 + c < n_total) {
-                uint32_t d[4];
-#pragma unroll
-                for (int q1 = 0; q1 < 4; ++q1) {
-                    const int Y = 16 * uy + 8 * (j >> 1) + 4 * (q1 >> 1) + g;
-                    const int Xd = 4 * ux + 2 * (j & 1) + (q1 & 1);
-                    d[q1] = tile[c][Y][Xd];
-                }
-                XS[(size_t)(n0 + c) * 256 + t] = make_uint4(d[0], d[1], d[2], d[3]);
+            for (int q1 = 0; q1 < 4; ++q1) {
+                const int Y = 16 * uy + 8 * (j >> 1) + 4 * (q1 >> 1) + g;
+                const int Xd = 4 * ux + 2 * (j & 1) + (q1 & 1);
+                d[q1] = tile[c][Y][Xd];
             }
+            XS[(((size_t)grp * 16 + u) * 4 + j) * 64 + (c16 + c) + 16 * g] = make_uint4(d[0], d[1], d[2], d[3]);
         }
     }
-    // ---- XM: one task record (4 CTUs), 512 uint4 -> 2 per thread
-    {
+    // ---- XM: 4 CTUs x 4 units x 8 j x 4 g = 512 uint4
 #pragma unroll
-        for (int rep = 0; rep < 2; ++rep) {
-            const int e = t + 256 * rep;
-            const int j = e >> 6, lane = e & 63, col = lane & 15, g = lane >> 4;
-            const int c = col >> 2, unit = col & 3, uy = unit >> 1, ux = unit & 1;
-            uint32_t out[4];
+    for (int rep = 0; rep < 2; ++rep) {
+        const int e = t + 256 * rep;
+        const int c = e & 3, g = (e >> 2) & 3, j = (e >> 4) & 7, unit = e >> 7;
+        const int uy = unit >> 1, ux = unit & 1;
+        uint32_t out[4];
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const int d = 2 * j + hh, q2 = d >> 2, q1 = d & 3;
-                const int Yp = 16 * uy + 8 * (q2 >> 1) + 4 * (q1 >> 1) + g;  // pooled row (0..31)
-                const int Xp = 16 * ux + 8 * (q2 & 1) + 4 * (q1 & 1);        // pooled col of px 0
-                const uint32_t a0 = tile[c][2 * Yp][Xp >> 1], a1 = tile[c][2 * Yp][(Xp >> 1) + 1];
-                const uint32_t b0 = tile[c][2 * Yp + 1][Xp >> 1], b1 = tile[c][2 * Yp + 1][(Xp >> 1) + 1];
-                // pooled px i uses bytes 2i, 2i+1 of the 8-byte row pair
-                const uint32_t s0 = (a0 & 0xff) + ((a0 >> 8) & 0xff) + (b0 & 0xff) + ((b0 >> 8) & 0xff);
-                const uint32_t s1 = ((a0 >> 16) & 0xff) + (a0 >> 24) + ((b0 >> 16) & 0xff) + (b0 >> 24);
-                const uint32_t s2 = (a1 & 0xff) + ((a1 >> 8) & 0xff) + (b1 & 0xff) + ((b1 >> 8) & 0xff);
-                const uint32_t s3 = ((a1 >> 16) & 0xff) + (a1 >> 24) + ((b1 >> 16) & 0xff) + (b1 >> 24);
-                out[2 * hh] = s0 | (s1 << 16);
-                out[2 * hh + 1] = s2 | (s3 << 16);
-            }
-            XM[(size_t)(n0 >> 2) * 512 + e] = make_uint4(out[0], out[1], out[2], out[3]);
+        for (int hh = 0; hh < 2; ++hh) {
+            const int d = 2 * j + hh, q2 = d >> 2, q1 = d & 3;
+            const int Yp = 16 * uy + 8 * (q2 >> 1) + 4 * (q1 >> 1) + g;  // pooled row (0..31)
+            const int Xp = 16 * ux + 8 * (q2 & 1) + 4 * (q1 & 1);        // pooled col of px 0
+            const uint32_t a0 = tile[c][2 * Yp][Xp >> 1], a1 = tile[c][2 * Yp][(Xp >> 1) + 1];
+            const uint32_t b0 = tile[c][2 * Yp + 1][Xp >> 1], b1 = tile[c][2 * Yp + 1][(Xp >> 1) + 1];
+            // pooled px i uses bytes 2i, 2i+1 of the 8-byte row pair
+            const uint32_t s0 = (a0 & 0xff) + ((a0 >> 8) & 0xff) + (b0 & 0xff) + ((b0 >> 8) & 0xff);
+            const uint32_t s1 = ((a0 >> 16) & 0xff) + (a0 >> 24) + ((b0 >> 16) & 0xff) + (b0 >> 24);
+            const uint32_t s2 = (a1 & 0xff) + ((a1 >> 8) & 0xff) + (b1 & 0xff) + ((b1 >> 8) & 0xff);
+            const uint32_t s3 = ((a1 >> 16) & 0xff) + (a1 >> 24) + ((b1 >> 16) & 0xff) + (b1 >> 24);
+            out[2 * hh] = s0 | (s1 << 16);
+            out[2 * hh + 1] = s2 | (s3 << 16);
         }
+        XM[(((size_t)grp * 4 + unit) * 8 + j) * 64 + (c16 + c) + 16 * g] = make_uint4(out[0], out[1], out[2], out[3]);
     }
     // ---- XL: this block's 4 columns of the 16-CTU task record: 8 j x 4 c x 4 g = 128 uint4
     if (t < 128) {
@@ -172,8 +173,10 @@ void launch_tile(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, co
 }
 
 // =========================================================================== k1 ======
-// One wave = one task = 16 units of one branch (S: the 16 units of one CTU; M: 4 CTUs x 4
-// units; L: 16 CTUs).  lane = col + 16 g: col = unit (MFMA column), g = MFMA k-group.
+// One wave = one task = the SAME unit position of 16 consecutive CTUs (a group): 16 S tasks,
+// 4 M tasks and 1 L task per group.  lane = col + 16 g: col = CTU within the group (MFMA
+// column), g = MFMA k-group.  Features are written as feat[group][k/4][16][4] so that every
+// store here and every FC1 operand load is a full 256-byte run per k-group.
 // MFMA D[row][col] (row = output channel) lives in lane (col, g) as rows 4g..4g+3, which is
 // exactly B[k = g][col] for the 4 k-steps r = 0..3 of the next layer when that layer's K
 // is enumerated as (patch, r, g) with ci = 4g + r.  240 MFMAs per task, 0 LDS bytes.
@@ -277,12 +280,13 @@ __device__ __forceinline__ void trunk_tasks(const uint4* __restrict__ X, int nta
         constexpr float C255S = (1.0f / 255.0f) * SCALE;  // exact: SCALE is a power of two
 
         // ---- where this column's outputs go
-        int n, by, bx;
-        if (BR == 0) { n = task; by = col >> 2; bx = col & 3; }
-        else if (BR == 1) { n = task * 4 + (col >> 2); by = (col >> 1) & 1; bx = col & 1; }
-        else { n = task * 16 + col; by = 0; bx = 0; }
-        const bool valid = n < N;
-        float* Fn = F + (size_t)n * kNFeat;
+        int grp, by, bx;  // wave-uniform
+        if (BR == 0) { grp = task >> 4; by = (task >> 2) & 3; bx = task & 3; }
+        else if (BR == 1) { grp = task >> 2; by = (task >> 1) & 1; bx = task & 1; }
+        else { grp = task; by = 0; bx = 0; }
+        const bool valid = grp * 16 + col < N;
+        // feature k of this lane's CTU: Fg[(k/4) * 64 + (k%4)]  (k % 4 == 0 for every f32x4 below)
+        float* Fg = F + (size_t)grp * kNFeat * 16 + col * 4;
 
         f32x4 a2[4][2];
 #pragma unroll
@@ -320,9 +324,9 @@ __device__ __forceinline__ void trunk_tasks(const uint4* __restrict__ X, int nta
             a2[q2][1] = c2[1];
             if (valid) {
                 const int slot = (2 * by + (q2 >> 1)) * (2 * NB) + 2 * bx + (q2 & 1);
-                float* dst = Fn + OFF2 + slot * 24;
-                *reinterpret_cast<f32x4*>(dst + 4 * g) = c2[0];
-                if (g < 2) *reinterpret_cast<f32x4*>(dst + 16 + 4 * g) = c2[1];
+                const int k0 = OFF2 + slot * 24 + 4 * g;
+                *reinterpret_cast<f32x4*>(Fg + (k0 >> 2) * 64) = c2[0];
+                if (g < 2) *reinterpret_cast<f32x4*>(Fg + ((k0 + 16) >> 2) * 64) = c2[1];
             }
         }
         // conv3: phase A = channels 0..15 of the 4 positions, phase B = channels 16..23 with
@@ -345,13 +349,13 @@ __device__ __forceinline__ void trunk_tasks(const uint4* __restrict__ X, int nta
                 c3[1] = MFMA16(A3[1][16 + 4 * j + r], z, c3[1]);
             }
         if (valid) {
-            float* dst = Fn + OFF3 + (by * NB + bx) * 32;
+            const int k0 = OFF3 + (by * NB + bx) * 32 + 4 * g;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 f32x4 o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = lrelu(c3[t][r]);
-                *reinterpret_cast<f32x4*>(dst + 16 * t + 4 * g) = o;
+                *reinterpret_cast<f32x4*>(Fg + ((k0 + 16 * t) >> 2) * 64) = o;
             }
         }
     }
@@ -364,14 +368,15 @@ __global__ __launch_bounds__(256) void k1_trunk(const uint4* __restrict__ XS, co
                                                 float* __restrict__ F) {
     const int w = threadIdx.x >> 6;
     const int b = blockIdx.x;
-    if (b < bS) trunk_tasks<0, RESI>(XS, N, b * 4 + w, bS * 4, wfrag, bfrag, F, N);
-    else if (b < bS + bM) trunk_tasks<1, RESI>(XM, (N + 3) / 4, (b - bS) * 4 + w, bM * 4, wfrag, bfrag, F, N);
-    else trunk_tasks<2, RESI>(XL, (N + 15) / 16, (b - bS - bM) * 4 + w, (int)(gridDim.x - bS - bM) * 4, wfrag, bfrag, F, N);
+    const int groups = (N + 15) / 16;
+    if (b < bS) trunk_tasks<0, RESI>(XS, groups * 16, b * 4 + w, bS * 4, wfrag, bfrag, F, N);
+    else if (b < bS + bM) trunk_tasks<1, RESI>(XM, groups * 4, (b - bS) * 4 + w, bM * 4, wfrag, bfrag, F, N);
+    else trunk_tasks<2, RESI>(XL, groups, (b - bS - bM) * 4 + w, (int)(gridDim.x - bS - bM) * 4, wfrag, bfrag, F, N);
 }
 
 void launch_trunk(const Workspace& ws, const DeviceWeights& w, int n, bool resi, hipStream_t s) {
     // tasks: S n, M n/4, L n/16 -- all 240 MFMAs each.  Persistent-ish grid: ~2 blocks/CU.
-    const int tS = n, tM = (n + 3) / 4, tL = (n + 15) / 16;
+    const int groups = (n + 15) / 16, tS = groups * 16, tM = groups * 4, tL = groups;
     auto blocks = [](int tasks, int budget) { int b = (tasks + 3) / 4; return b < budget ? b : budget; };
     const int bS = blocks(tS, 390), bM = blocks(tM, 98), bL = blocks(tL, 24);  // 512 blocks = 2 per CU (219 VGPRs -> 2 waves per SIMD)
     if (resi)

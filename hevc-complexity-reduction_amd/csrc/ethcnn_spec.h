@@ -73,7 +73,10 @@ constexpr int kTrunkWFrags = 84, kTrunkBFrags = 20;
 struct DeviceWeights {
     float* trunk_w = nullptr;  // [3][84][64]
     float* trunk_b = nullptr;  // [3][20][64]
-    float* fc1_w = nullptr;    // [2688][448]  columns = 64 | 128 | 256
+    // FC1 weights ([2688][448], columns = 64 | 128 | 256) packed per column block in the exact
+    // LDS image order of k_fc1 (ethcnn_dense.hip): [448/BN][2688/BK][BK][BN], bank-permuted
+    float* fc1_img112 = nullptr;  // BN 112, BK 16
+    float* fc1_img64 = nullptr;   // BN 64,  BK 32
     float* fc1_b = nullptr;    // [448]
     float* fc2_w[3] = {nullptr, nullptr, nullptr};  // [n1+1][n2] (last row = qp row)
     float* fc2_b[3] = {nullptr, nullptr, nullptr};
@@ -84,6 +87,7 @@ struct DeviceWeights {
 // host-side packing (ethcnn_weights.cpp)
 void pack_trunk_fragments(const float* blob, float* w_out /*[3][84][64]*/, float* b_out /*[3][20][64]*/);
 void pack_fc1(const float* blob, float* w_out /*[2688][448]*/, float* b_out /*[448]*/);
+void pack_fc1_image(const float* w_cat /*[2688][448]*/, int bn, int bk, float* img_out /*[2688*448]*/);
 void synth_blob(uint64_t seed, double head_gain, float* blob_out /*[kBlobFloats]*/);
 
 // TF-V2 checkpoint bundle reader (tf_ckpt_v2.cpp).  Returns 0 or a negative ETHCNN_ERR_*;

@@ -141,4 +141,23 @@ void pack_fc1(const float* blob, float* w_out, float* b_out) {
     }
 }
 
+// W1 in the exact LDS image order of k_fc1: [column block][K chunk][LDS row][LDS column], so each
+// LDS-DMA instruction of the kernel is a linear 1 KiB copy.  LDS position (p, c) of a chunk
+// holds W1[chunk*bk + r][block*bn + cc] with the bank permutation of ethcnn_dense.hip:
+//   bn % 32 == 0 : r = p,                 cc = c ^ (16 * ((p >> 2) & 1))   (column-group swap)
+//   bn % 32 == 16: r = p ^ ((p >> 2) & 1), cc = c                           (row swap)
+void pack_fc1_image(const float* w_cat, int bn, int bk, float* img) {
+    const int nsplit = kNVec / bn, nk = kNFeat / bk;
+    const bool colswz = (bn % 32 == 0);
+    for (int nb = 0; nb < nsplit; ++nb)
+        for (int kc = 0; kc < nk; ++kc)
+            for (int p = 0; p < bk; ++p) {
+                const int key = (p >> 2) & 1;
+                const int r = colswz ? p : (p ^ key);
+                float* dst = img + (((size_t)nb * nk + kc) * bk + p) * bn;
+                const float* src = w_cat + (size_t)(kc * bk + r) * kNVec + nb * bn;
+                for (int c = 0; c < bn; ++c) dst[c] = src[colswz ? (c ^ (key << 4)) : c];
+            }
+}
+
 }  // namespace ethcnn
