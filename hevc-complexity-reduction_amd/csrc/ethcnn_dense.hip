@@ -4,16 +4,16 @@
 //
 // Block = WM waves stacked along M; a wave owns MS groups of 16 CTUs x (16 NS) columns; the
 // block's waves share one BK x BN slice of W1 per K chunk (BK = 16 NSUB, BN = 16 NS).
-//   * W1 slice (B operand): global_load_lds (LDS-DMA, no staging VGPRs), double buffered, one
+//   * W1 slice (B operand): global_load_lds (LDS-DMA, no staging VGPRs), three stages, one
 //     barrier per chunk.  The host packs W1 per column block in exactly the LDS image order
 //     (ethcnn_weights.cpp::pack_fc1_image), so every DMA instruction is a linear 1 KiB copy.
 //     The image is bank-permuted: the two k-groups of a 32-lane half read rows e and e+4, so
 //     rows with (k>>2) odd have adjacent 16-column groups swapped (BN % 32 == 0) or adjacent
 //     rows swapped (BN % 32 == 16); undone on the ds_read.
-//   * features (A operand): NOT staged through LDS.  The trunk writes them as
-//     feat[group of 16 CTUs][k/4][16 CTUs][4 floats]; lane (ctu, g) loads ONE float4 per
-//     16-k sub-chunk -- a fully coalesced 1 KiB per wave instruction -- and feeds element e to
-//     MFMA step e.  That fixes the accumulation order inside a sub-chunk to k = 16c + 4g + e
+//   * features (A operand): the trunk writes them as feat[group of 16 CTUs][k/4][16 CTUs][4 floats],
+//     so a wave's operands of one 16-k sub-chunk are ONE linear 1 KiB piece: one DMA instruction
+//     into the wave's private LDS slot, read back as one float4 per lane (ctu, g), whose element
+//     e feeds MFMA step e.  That fixes the accumulation order inside a sub-chunk to k = 16c + 4g + e
 //     (e outer, g inner): the canonical FC order of DESIGN.md, restated by the oracle.
 //   * NSPLIT column blocks per M tile, column block = blockIdx.x % NSPLIT: the dispatcher puts
 //     block b on XCD b % 8, so each XCD streams only 1/NSPLIT of W1 and keeps it L2-resident
@@ -32,17 +32,29 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
+// ---- k_fc1_p3.  Everything arrives by LDS-DMA (W1 chunk shared by the block, each wave's own
+// 1 KiB feature sub-chunks: read back with one conflict-free ds_read_b128), 3 LDS stages,
+// prefetch distance 2.
+// All VMEM operations of a wave are DMA instructions issued in a fixed number per iteration, so
+// the data of chunk kc+1 is known to have landed when `vmcnt` has drained down to this
+// iteration's own issue count: a COUNTED s_waitcnt, never vmcnt(0), and a raw s_barrier (a
+// __syncthreads() would drain the queue, ROCm 7.2).  WAR: stage (kc+3)%3 == kc%3 is refilled in
+// iteration kc+1, after every wave has passed the barrier that ends iteration kc.
 template <int MS, int NS, int WM, int NSUB>
-__global__ __launch_bounds__(64 * WM) void k_fc1(const float* __restrict__ feat, const float* __restrict__ Wimg,
-                                                 const float* __restrict__ bias, float* __restrict__ out, int M) {
+__global__ __launch_bounds__(64 * WM) void k_fc1_p3(const float* __restrict__ feat, const float* __restrict__ Wimg,
+                                                    const float* __restrict__ bias, float* __restrict__ out, int M) {
     constexpr int BK = 16 * NSUB, BN = 16 * NS, NSPLIT = kNVec / BN, BM = 16 * MS * WM;
     constexpr int NK = kNFeat / BK;
     constexpr int B_FLOATS = BK * BN;
     constexpr bool COLSWZ = (BN % 32 == 0);
-    constexpr int B_INST = B_FLOATS / 256;         // 1 KiB wave-instructions per W1 chunk
-    constexpr int B_PER = (B_INST + WM - 1) / WM;  // per wave
-    static_assert(kNVec % BN == 0 && kNFeat % BK == 0 && B_FLOATS % 256 == 0, "tile shape");
-    __shared__ __attribute__((aligned(16))) float smem[2 * B_FLOATS];  // the ONLY LDS object
+    constexpr int B_INST = B_FLOATS / 256;
+    constexpr int B_PER = (B_INST + WM - 1) / WM;   // every wave issues exactly B_PER (tail duplicates the last piece)
+    constexpr int A_PER = NSUB * MS;                // 1 KiB feature pieces per wave per chunk
+    constexpr int ISSUE = B_PER + A_PER;            // VMEM ops per wave per iteration
+    constexpr int A_FLOATS = WM * A_PER * 256;
+    constexpr int STAGE = B_FLOATS + A_FLOATS;
+    static_assert(NK % 3 == 0 && NK >= 3, "K chunks must come in threes");
+    __shared__ __attribute__((aligned(16))) float smem[3 * STAGE];  // the ONLY LDS object
 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int col = lane & 15, g = lane >> 4;
@@ -56,72 +68,86 @@ __global__ __launch_bounds__(64 * WM) void k_fc1(const float* __restrict__ feat,
 #pragma unroll
         for (int j = 0; j < NS; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // feat[group][k/4][16][4]: this lane's float4 of sub-chunk s is at k/4 = 4 s + g.  Groups past
-    // the batch are clamped (loaded, never stored).
     const int ngroups = (M + 15) >> 4;
-    const float* a_src[MS];
+    const float* a_src[MS];  // this lane's 16 B of the group's [k/4][16][4] image: linear in lane
 #pragma unroll
-    for (int i = 0; i < MS; ++i)
-        a_src[i] = feat + ((size_t)min((m0 >> 4) + i, ngroups - 1) * (kNFeat / 4) + g) * 64 + col * 4;
-    const float* b_src = Wimg + (size_t)nb * NK * B_FLOATS + (size_t)wv * 256 + lane * 4;
-    // read side: rows 16 u + 4 g + e have ((row>>2)&1) == (g&1)
+    for (int i = 0; i < MS; ++i) a_src[i] = feat + (size_t)min((m0 >> 4) + i, ngroups - 1) * (kNFeat / 4) * 64 + lane * 4;
+    const float* b_src[B_PER];
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i)
+        b_src[i] = Wimg + (size_t)nb * NK * B_FLOATS + (size_t)min(wv + i * WM, B_INST - 1) * 256 + lane * 4;
     int bcol[NS];
 #pragma unroll
     for (int j = 0; j < NS; ++j) bcol[j] = (j * 16 + col) ^ (COLSWZ ? ((g & 1) << 4) : 0);
     int brow[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) brow[e] = (COLSWZ ? e : (e ^ (g & 1))) * BN;
+    float* a_lds = smem + B_FLOATS + wv * A_PER * 256;  // + stage * STAGE
 
-#define FC1_B_ISSUE(kc, buf)                                                                         \
-    _Pragma("unroll") for (int i = 0; i < B_PER; ++i) {                                              \
-        if ((i + 1) * WM <= B_INST || wv + i * WM < B_INST)                                          \
-            __builtin_amdgcn_global_load_lds((glb_void*)(b_src + (size_t)(kc) * B_FLOATS + i * WM * 256), \
-                                             (lds_void*)(smem + (buf) * B_FLOATS + (wv + i * WM) * 256), 16, 0, 0); \
+    // LDS-DMA through inline asm: hipcc does not model it, so it neither drains it at an LDS read
+    // (as it does for the builtin: a vmcnt(0) before the first ds_read) nor counts it -- the
+    // counted waits below are the only ordering.  M0 = wave-uniform LDS byte address, written in
+    // the same statement that uses it (guide 5.7).
+    const unsigned lds_base = (unsigned)(size_t)(lds_void*)smem;
+    const unsigned wvu = __builtin_amdgcn_readfirstlane(wv);
+#define P3_DMA(gsrc, lds_byte_off)                                                                     \
+    {                                                                                                  \
+        unsigned keep_;                                                                                \
+        const unsigned dst_ = __builtin_amdgcn_readfirstlane(lds_base + (lds_byte_off));               \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                     : "=&s"(keep_) : "v"(gsrc), "s"(dst_) : "memory");                                \
+    }
+#define P3_ISSUE(kc, st)                                                                               \
+    {                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < B_PER; ++i)                                              \
+            P3_DMA(b_src[i] + (size_t)(kc) * B_FLOATS, 4u * ((st) * STAGE + min(wvu + i * WM, (unsigned)(B_INST - 1)) * 256)); \
+        _Pragma("unroll") for (int u = 0; u < NSUB; ++u)                                               \
+            _Pragma("unroll") for (int i = 0; i < MS; ++i)                                             \
+                P3_DMA(a_src[i] + ((size_t)(kc) * NSUB + u) * 256,                                     \
+                       4u * ((st) * STAGE + B_FLOATS + (wvu * A_PER + u * MS + i) * 256));             \
+    }
+#define P3_COMPUTE(st)                                                                                 \
+    {                                                                                                  \
+        _Pragma("unroll") for (int u = 0; u < NSUB; ++u) {                                             \
+            float4 av[MS];                                                                             \
+            _Pragma("unroll") for (int i = 0; i < MS; ++i)                                             \
+                av[i] = *reinterpret_cast<const float4*>(a_lds + (st) * STAGE + (u * MS + i) * 256 + lane * 4); \
+            const float* bs = smem + (st) * STAGE + (16 * u + 4 * g) * BN;                             \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                            \
+                float b[NS];                                                                           \
+                _Pragma("unroll") for (int j = 0; j < NS; ++j) b[j] = bs[brow[e] + bcol[j]];           \
+                _Pragma("unroll") for (int i = 0; i < MS; ++i) {                                       \
+                    const float a = (e == 0) ? av[i].x : (e == 1) ? av[i].y : (e == 2) ? av[i].z : av[i].w; \
+                    _Pragma("unroll") for (int j = 0; j < NS; ++j) acc[i][j] = MFMA16(a, b[j], acc[i][j]); \
+                }                                                                                      \
+            }                                                                                          \
+        }                                                                                              \
+    }
+#define P3_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define P3_STEP(kc, st, st2)                                                                           \
+    {                                                                                                  \
+        if ((kc) + 2 < NK) { P3_ISSUE((kc) + 2, st2); }                                                \
+        P3_COMPUTE(st);                                                                                \
+        if ((kc) + 2 < NK) { P3_WAIT(ISSUE); } else { P3_WAIT(0); }                                    \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                             \
+        __builtin_amdgcn_s_barrier();                                                                  \
     }
 
-    float4 a_cur[NSUB][MS], a_nxt[NSUB][MS];
-    FC1_B_ISSUE(0, 0);
-#pragma unroll
-    for (int u = 0; u < NSUB; ++u)
-#pragma unroll
-        for (int i = 0; i < MS; ++i) a_cur[u][i] = *reinterpret_cast<const float4*>(a_src[i] + u * 256);
-    __syncthreads();  // hipcc drains vmcnt here (LDS-DMA pending): chunk 0 has landed
-    for (int kc = 0; kc < NK; ++kc) {
-        const int buf = kc & 1;
-        if (kc + 1 < NK) {  // both in flight during the MFMAs below
-            FC1_B_ISSUE(kc + 1, buf ^ 1);
-#pragma unroll
-            for (int u = 0; u < NSUB; ++u)
-#pragma unroll
-                for (int i = 0; i < MS; ++i)
-                    a_nxt[u][i] = *reinterpret_cast<const float4*>(a_src[i] + ((size_t)(kc + 1) * NSUB + u) * 256);
-        }
-#pragma unroll
-        for (int u = 0; u < NSUB; ++u) {
-            const float* bs = smem + buf * B_FLOATS + (16 * u + 4 * g) * BN;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float b[NS];
-#pragma unroll
-                for (int j = 0; j < NS; ++j) b[j] = bs[brow[e] + bcol[j]];
-#pragma unroll
-                for (int i = 0; i < MS; ++i) {
-                    const float4 av = a_cur[u][i];
-                    const float a = (e == 0) ? av.x : (e == 1) ? av.y : (e == 2) ? av.z : av.w;
-#pragma unroll
-                    for (int j = 0; j < NS; ++j) acc[i][j] = MFMA16(a, b[j], acc[i][j]);
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < NSUB; ++u)
-#pragma unroll
-            for (int i = 0; i < MS; ++i) a_cur[u][i] = a_nxt[u][i];
-        __syncthreads();
+    P3_ISSUE(0, 0);
+    P3_ISSUE(1, 1);
+    P3_WAIT(ISSUE);  // chunk 0 landed (chunk 1 may still be in flight)
+    __builtin_amdgcn_s_barrier();
+    for (int kc = 0; kc < NK; kc += 3) {
+        P3_STEP(kc, 0, 2);
+        P3_STEP(kc + 1, 1, 0);
+        P3_STEP(kc + 2, 2, 1);
     }
-#undef FC1_B_ISSUE
+#undef P3_DMA
+#undef P3_ISSUE
+#undef P3_COMPUTE
+#undef P3_WAIT
+#undef P3_STEP
 
-    // epilogue: C layout row (CTU) = 4g + r, col = lane & 15
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
         const int n = n0 + j * 16 + col;
@@ -138,9 +164,9 @@ __global__ __launch_bounds__(64 * WM) void k_fc1(const float* __restrict__ feat,
 }
 
 template <int MS, int NS, int WM, int NSUB>
-static void launch_fc1_shape(const float* feat, const float* wimg, const float* bias, float* out, int M, hipStream_t s) {
+static void launch_fc1_p3(const float* feat, const float* wimg, const float* bias, float* out, int M, hipStream_t s) {
     constexpr int BM = 16 * MS * WM, NSPLIT = kNVec / (16 * NS);
-    hipLaunchKernelGGL((k_fc1<MS, NS, WM, NSUB>), dim3(((M + BM - 1) / BM) * NSPLIT), dim3(64 * WM), 0, s, feat, wimg,
+    hipLaunchKernelGGL((k_fc1_p3<MS, NS, WM, NSUB>), dim3(((M + BM - 1) / BM) * NSPLIT), dim3(64 * WM), 0, s, feat, wimg,
                        bias, out, M);
 }
 
@@ -153,32 +179,41 @@ static int fc1_variant() {
     return v;
 }
 
-// Tile shape by batch size.  Both shapes sit on the same plateau for large N (profiles/
-// r01_fc1_variants.txt; 64x64 ~2.5 % lower).  What differs is how evenly the blocks divide over
-// the 256 CUs when there are only a handful per CU (every block runs the full K loop, so a CU
-// with 7 blocks finishes 1/6 later than one with 6).
+// Tile shape by batch size.  Plateau (large N, profiles/r01_fc1_variants.txt): 128x112 > 64x112 >
+// 64x64.  What differs is how evenly the blocks divide over the 256 CUs when there are only a
+// handful per CU (every block runs the full K loop, so a CU with 7 blocks finishes 1/6 later
+// than one with 6): pick the shape with the best plateau x balance product.
 static int fc1_auto_variant(int n) {
-    const int tiles = (n + 63) / 64;
     auto balance = [](int blocks) { return (double)blocks / (256.0 * ((blocks + 255) / 256)); };
-    const double e112 = 1.0 * balance(tiles * 4), e64 = 0.975 * balance(tiles * 7);
-    return e64 > e112 ? 1 : 0;
+    const double e[3] = {1.000 * balance(((n + 127) / 128) * 4), 0.957 * balance(((n + 63) / 64) * 4),
+                         0.937 * balance(((n + 63) / 64) * 7)};
+    int best = 0;
+    for (int i = 1; i < 3; ++i)
+        if (e[i] > e[best]) best = i;
+    return best;
 }
 
 void launch_fc1(const Workspace& ws, const DeviceWeights& w, int n, float* out, hipStream_t s) {
     int variant = fc1_variant();
     if (variant < 0) variant = fc1_auto_variant(n);
     switch (variant) {
-        default:  // 0: 64 CTUs x 112 columns (N split 4), BK 16
-            launch_fc1_shape<1, 7, 4, 1>(ws.feat, w.fc1_img112, w.fc1_b, out, n, s);
+        default:  // 0: 128 CTUs (4 waves x 2 groups) x 112 columns (N split 4), BK 16
+            launch_fc1_p3<2, 7, 4, 1>(ws.feat, w.fc1_img112, w.fc1_b, out, n, s);
             break;
-        case 1:  // 64 CTUs x 64 columns (N split 7), BK 32
-            launch_fc1_shape<1, 4, 4, 2>(ws.feat, w.fc1_img64, w.fc1_b, out, n, s);
+        case 1:  // 64 CTUs x 112 columns
+            launch_fc1_p3<1, 7, 4, 1>(ws.feat, w.fc1_img112, w.fc1_b, out, n, s);
             break;
-        case 2:  // 128 CTUs x 112 columns, 4 waves x 32 rows
-            launch_fc1_shape<2, 7, 4, 1>(ws.feat, w.fc1_img112, w.fc1_b, out, n, s);
+        case 2:  // 64 CTUs x 64 columns (N split 7), BK 32
+            launch_fc1_p3<1, 4, 4, 2>(ws.feat, w.fc1_img64, w.fc1_b, out, n, s);
             break;
-        case 3:  // 128 CTUs x 112 columns, 8 waves x 16 rows
-            launch_fc1_shape<1, 7, 8, 1>(ws.feat, w.fc1_img112, w.fc1_b, out, n, s);
+        case 3:  // 128 CTUs (8 waves) x 112 columns
+            launch_fc1_p3<1, 7, 8, 1>(ws.feat, w.fc1_img112, w.fc1_b, out, n, s);
+            break;
+        case 4:  // 128 CTUs x 64 columns, BK 32
+            launch_fc1_p3<2, 4, 4, 2>(ws.feat, w.fc1_img64, w.fc1_b, out, n, s);
+            break;
+        case 5:  // 256 CTUs (8 waves x 2 groups) x 112 columns
+            launch_fc1_p3<2, 7, 8, 1>(ws.feat, w.fc1_img112, w.fc1_b, out, n, s);
             break;
     }
 }
