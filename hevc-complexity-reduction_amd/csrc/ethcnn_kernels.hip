@@ -1,8 +1,7 @@
 // ethcnn_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the ETH-CNN path.
 //
-//   k0_tile   luma frames -> zero-padded 64x64 CTUs (video_to_cu_depth.py:46-59,88-106) in
-//             trunk-lane order + exact integer 2x2 / 4x4 pooled sums (aver_pool,
-//             net_CNN.py:62-63).  HBM-bound, LDS-staged.
+//   k0_tile   (ethcnn_tile.hip) luma frames -> zero-padded 64x64 CTUs in trunk-lane order +
+//             exact integer 2x2 / 4x4 pooled sums.  HBM-bound, LDS-staged.
 //   k1_trunk  block-mean removal (net_CNN.py:78-84) + the three non-overlapping convs
 //             (:86-92,127-141) of all 21 units per CTU, written as `h_conv_flat` (:143-150).
 //             v_mfma_f32_16x16x4_f32, "transposed" (rows = output channels, columns = 16
@@ -34,143 +33,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float lrelu(float h) { return fmaxf(0.2f * h, h); }
 
 int chunks_per_frame(int nctu) { return (nctu + kSubBatch - 1) / kSubBatch; }
-
-// =========================================================================== k0 ======
-// One block = 4 consecutive CTUs (global raster index n0 = 4*blockIdx.x over the frame
-// sequence).  Stage: 4 x (64 rows x 64 B) coalesced 16-B loads -> LDS (row pitch 17 dwords)
-// -> three outputs laid out so that every k1 load is one fully coalesced dwordx4 per lane.  A
-// trunk task is ONE unit position of 16 consecutive CTUs (a "group"); lane = c + 16 g with
-// c = n % 16 the CTU within the group and g the MFMA k-group:
-//   XS[(n/16)*16 + u][j][lane]  uint4: dwords q1=0..3 = 4 pixels of row g of patch (q2=j, q1) of
-//                       S unit u.  patch row Y = 16uy + 8(q2>>1) + 4(q1>>1) + g,
-//                       X = 16ux + 8(q2&1) + 4(q1&1) + 0..3.
-//   XM[(n/16)*4 + unit][j][lane] uint4: patch rows d = 2j, 2j+1 (d = 4 q2 + q1) of M unit
-//                       (2x2), each 4 x u16 sums of 2x2 raw pixels.
-//   XL[n/16][j][lane]   same with 4x4 sums.
-constexpr int kTilePitch = 17;
-
-template <bool FAST>
-__global__ __launch_bounds__(256) void k0_tile(const uint8_t* __restrict__ luma, int width, int height, long pitch,
-                                               long frame_stride, int cw, int nctu, long ctu0, int n_total,
-                                               uint4* __restrict__ XS, uint4* __restrict__ XM,
-                                               uint4* __restrict__ XL) {
-    __shared__ uint32_t tile[4][64][kTilePitch];
-    const int t = threadIdx.x;
-    const int n0 = blockIdx.x * 4;
-
-    // ---- load 4 CTUs (zero outside the frame / beyond n_total)
-    {
-        const int row = t >> 2, seg = t & 3;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int n = n0 + c;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (n < n_total) {
-                const long gn = ctu0 + n;
-                const long f = gn / nctu;
-                const int rr = (int)(gn - f * nctu);
-                const int cy = rr / cw, cx = rr - cy * cw;
-                const int y = cy * 64 + row, x = cx * 64 + seg * 16;
-                if (y < height && x < width) {
-                    const uint8_t* p = luma + f * frame_stride + (long)y * pitch + x;
-                    if (FAST) {
-                        v = *reinterpret_cast<const uint4*>(p);
-                    } else {
-                        uint32_t w4[4] = {0u, 0u, 0u, 0u};
-                        const int lim = min(16, width - x);
-                        for (int i = 0; i < lim; ++i) w4[i >> 2] |= (uint32_t)p[i] << (8 * (i & 3));
-                        v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
-                    }
-                }
-            }
-            uint32_t* dst = &tile[c][row][seg * 4];
-            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
-        }
-    }
-    __syncthreads();
-
-    const int grp = n0 >> 4, c16 = n0 & 15;
-    // ---- XS: 4 CTUs x 16 units x 4 j x 4 g = 1024 uint4; 4 consecutive threads = the 4 CTUs
-    // of one (u, j, g) -> 64 contiguous bytes
-#pragma unroll
-    for (int rep = 0; rep < 4; ++rep) {
-        const int e = t + 256 * rep;
-        const int c = e & 3, g = (e >> 2) & 3, j = (e >> 4) & 3, u = e >> 6;
-        const int uy = u >> 2, ux = u & 3;
-        if (n0 + c < n_total) {
-            uint32_t d[4];
-#pragma unroll
-            for (int q1 = 0; q1 < 4; ++q1) {
-                const int Y = 16 * uy + 8 * (j >> 1) + 4 * (q1 >> 1) + g;
-                const int Xd = 4 * ux + 2 * (j & 1) + (q1 & 1);
-                d[q1] = tile[c][Y][Xd];
-            }
-            XS[(((size_t)grp * 16 + u) * 4 + j) * 64 + (c16 + c) + 16 * g] = make_uint4(d[0], d[1], d[2], d[3]);
-        }
-    }
-    // ---- XM: 4 CTUs x 4 units x 8 j x 4 g = 512 uint4
-#pragma unroll
-    for (int rep = 0; rep < 2; ++rep) {
-        const int e = t + 256 * rep;
-        const int c = e & 3, g = (e >> 2) & 3, j = (e >> 4) & 7, unit = e >> 7;
-        const int uy = unit >> 1, ux = unit & 1;
-        uint32_t out[4];
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const int d = 2 * j + hh, q2 = d >> 2, q1 = d & 3;
-            const int Yp = 16 * uy + 8 * (q2 >> 1) + 4 * (q1 >> 1) + g;  // pooled row (0..31)
-            const int Xp = 16 * ux + 8 * (q2 & 1) + 4 * (q1 & 1);        // pooled col of px 0
-            const uint32_t a0 = tile[c][2 * Yp][Xp >> 1], a1 = tile[c][2 * Yp][(Xp >> 1) + 1];
-            const uint32_t b0 = tile[c][2 * Yp + 1][Xp >> 1], b1 = tile[c][2 * Yp + 1][(Xp >> 1) + 1];
-            // pooled px i uses bytes 2i, 2i+1 of the 8-byte row pair
-            const uint32_t s0 = (a0 & 0xff) + ((a0 >> 8) & 0xff) + (b0 & 0xff) + ((b0 >> 8) & 0xff);
-            const uint32_t s1 = ((a0 >> 16) & 0xff) + (a0 >> 24) + ((b0 >> 16) & 0xff) + (b0 >> 24);
-            const uint32_t s2 = (a1 & 0xff) + ((a1 >> 8) & 0xff) + (b1 & 0xff) + ((b1 >> 8) & 0xff);
-            const uint32_t s3 = ((a1 >> 16) & 0xff) + (a1 >> 24) + ((b1 >> 16) & 0xff) + (b1 >> 24);
-            out[2 * hh] = s0 | (s1 << 16);
-            out[2 * hh + 1] = s2 | (s3 << 16);
-        }
-        XM[(((size_t)grp * 4 + unit) * 8 + j) * 64 + (c16 + c) + 16 * g] = make_uint4(out[0], out[1], out[2], out[3]);
-    }
-    // ---- XL: this block's 4 columns of the 16-CTU task record: 8 j x 4 c x 4 g = 128 uint4
-    if (t < 128) {
-        const int j = t >> 4, c = (t >> 2) & 3, g = t & 3;
-        uint32_t out[4];
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const int d = 2 * j + hh, q2 = d >> 2, q1 = d & 3;
-            const int Yp = 8 * (q2 >> 1) + 4 * (q1 >> 1) + g;  // pooled row (0..15)
-            const int Xp = 8 * (q2 & 1) + 4 * (q1 & 1);        // pooled col == dword col
-            uint32_t s[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                uint32_t acc = 0;
-#pragma unroll
-                for (int ry = 0; ry < 4; ++ry) {
-                    const uint32_t w = tile[c][4 * Yp + ry][Xp + i];
-                    acc += (w & 0xff) + ((w >> 8) & 0xff) + ((w >> 16) & 0xff) + (w >> 24);
-                }
-                s[i] = acc;
-            }
-            out[2 * hh] = s[0] | (s[1] << 16);
-            out[2 * hh + 1] = s[2] | (s[3] << 16);
-        }
-        const int lane = ((n0 & 15) + c) + 16 * g;
-        XL[((size_t)(n0 >> 4) * 8 + j) * 64 + lane] = make_uint4(out[0], out[1], out[2], out[3]);
-    }
-}
-
-void launch_tile(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, const Workspace& ws, hipStream_t s) {
-    const int blocks = (n + 3) / 4;
-    const bool fast = (g.width % 16 == 0) && (g.pitch % 16 == 0) && (g.frame_stride % 16 == 0) &&
-                      (reinterpret_cast<uintptr_t>(d_luma) % 16 == 0);
-    if (fast)
-        hipLaunchKernelGGL(k0_tile<true>, dim3(blocks), dim3(256), 0, s, d_luma, g.width, g.height, g.pitch,
-                           g.frame_stride, g.cw, g.nctu, ctu0, n, ws.xs, ws.xm, ws.xl);
-    else
-        hipLaunchKernelGGL(k0_tile<false>, dim3(blocks), dim3(256), 0, s, d_luma, g.width, g.height, g.pitch,
-                           g.frame_stride, g.cw, g.nctu, ctu0, n, ws.xs, ws.xm, ws.xl);
-}
 
 // =========================================================================== k1 ======
 // One wave = one task = the SAME unit position of 16 consecutive CTUs (a group): 16 S tasks,
