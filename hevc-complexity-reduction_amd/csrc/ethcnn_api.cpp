@@ -40,7 +40,7 @@ struct ethcnn_ctx {
     int max_ctus = 131072;
     int last_n = 0;  // CTUs of the last pass (debug_fetch)
 
-    bool profiling = false;
+    int profiling = 0;  // 0 off, 1 dominant kernel (FC1) only, 2 every stage
     struct Ev { hipEvent_t a, b; int stage; };
     std::vector<Ev> pending;
     std::vector<hipEvent_t> ev_pool;
@@ -291,15 +291,17 @@ struct StageTimer {
     ethcnn_ctx* c;
     int stage;
     hipEvent_t a = nullptr, b = nullptr;
+    bool on;
     StageTimer(ethcnn_ctx* c_, int st) : c(c_), stage(st) {
-        if (c->profiling) {
+        on = c->profiling >= (st == ETHCNN_STAGE_FC1 ? 1 : 2);
+        if (on) {
             a = get_event(c);
             b = get_event(c);
             (void)hipEventRecord(a, c->stream);
         }
     }
     ~StageTimer() {
-        if (c->profiling) {
+        if (on) {
             (void)hipEventRecord(b, c->stream);
             c->pending.push_back({a, b, stage});
         }
@@ -319,7 +321,7 @@ static void drain_events(ethcnn_ctx* c) {
 extern "C" int ethcnn_set_profiling(ethcnn_ctx* c, int on) {
     if (!c) return ETHCNN_ERR_ARG;
     drain_events(c);
-    c->profiling = on != 0;
+    c->profiling = on < 0 ? 0 : (on > 2 ? 2 : on);
     return ETHCNN_OK;
 }
 extern "C" int ethcnn_get_stage_times(ethcnn_ctx* c, ethcnn_stage_times* out) {

@@ -1,0 +1,250 @@
+// ethcnn_trunk.hip -- k1: 16x16 block-mean removal (zero_mean_norm_local, net_CNN.py:78-84) and the
+// three non-overlapping convs (non_overlap_conv, :86-92,127-141) of the 21 units of every CTU,
+// written as `h_conv_flat` (:143-150).  gfx950, v_mfma_f32_16x16x4_f32.
+//
+// One wave = one task = the SAME unit position of 16 consecutive CTUs (a group): 16 S tasks, 4 M
+// tasks and 1 L task per group, 240 MFMAs each.  lane = col + 16 g: col = CTU within the group
+// (MFMA column), g = MFMA k-group.  The trunk runs "transposed" (rows = output channels): MFMA
+// D[row][col] lives in lane (col, g) as rows 4g..4g+3, which is exactly B[k = g][col] for the 4
+// k-steps r = 0..3 of the next layer when that layer's K is enumerated as (patch, r, g) with
+// ci = 4g + r.  So each layer's accumulator registers ARE the next layer's B operand: no LDS, no
+// cross-lane traffic (one lane-half swap for conv3's channels 16..23).  Weights of the branch
+// live in 84 VGPRs as A operands for the whole task loop.
+//
+// Two waves per SIMD (<= 256 VGPRs) overlap one wave's VALU epilogues with the other's MFMAs; the
+// next task's pixel record is prefetched a task ahead.  (A deeper in-wave software pipeline -- conv1(q+1) before leaky(conv1(q)) --
+// was measured: it needs > 256 VGPRs, drops to one wave per SIMD and is 20 % slower.)
+// Features are written as feat[group][k/4][16][4]: every store is a 256-byte run per k-group.
+//
+// Arithmetic contract (DESIGN.md "canonical order"; oracle/ethcnn_oracle.c mode 0 restates it):
+// each accumulator is one fmaf chain in MFMA k order starting from the bias; leaky = max(0.2h, h);
+// v = fma(float(pixel sum), c255 * 2^-p, -mean) with exact integer pixel sums.
+#include <hip/hip_runtime.h>
+
+#include "ethcnn_kernels.h"
+
+namespace ethcnn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ float lrelu_t(float h) { return fmaxf(0.2f * h, h); }
+__device__ __forceinline__ f32x4 lrelu4(f32x4 v) {
+    return (f32x4){lrelu_t(v[0]), lrelu_t(v[1]), lrelu_t(v[2]), lrelu_t(v[3])};
+}
+
+template <bool RESI>
+__device__ __forceinline__ float px_value(int s, int cnt) {
+    if (RESI) return ((float)(s - 128 * cnt) / 255.0f) * 10.0f;  // (x-128)/255.0*10, LSTM net :153
+    return (float)s * (1.0f / 255.0f);                           // x * 1/255, net_CNN.py:105
+}
+
+template <int BR, bool RESI>
+struct Trunk {
+    static constexpr int POOL = (BR == 0) ? 1 : (BR == 1 ? 2 : 4);
+    static constexpr float SCALE = 1.0f / (float)(POOL * POOL);
+    static constexpr float C255S = (1.0f / 255.0f) * SCALE;  // exact: SCALE is a power of two
+    static constexpr int NB = (BR == 0) ? 4 : (BR == 1 ? 2 : 1);
+    static constexpr int OFF2 = (BR == 0) ? 672 : (BR == 1 ? 2208 : 2592);
+    static constexpr int OFF3 = (BR == 0) ? 0 : (BR == 1 ? 512 : 640);
+    static constexpr int NJ = (BR == 0) ? 4 : 8;  // uint4 records per lane per task
+
+    // raw record -> x[d][kx] (pixel sums as floats; resi: preprocessed values) and the lane's sum
+    static __device__ __forceinline__ void decode(const uint4 (&raw)[NJ], float (&x)[16][4], int& T) {
+        T = 0;
+        if (BR == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t w[4] = {raw[j].x, raw[j].y, raw[j].z, raw[j].w};
+#pragma unroll
+                for (int q1 = 0; q1 < 4; ++q1) {
+                    T = (int)__builtin_amdgcn_udot4(w[q1], 0x01010101u, (unsigned)T, false);  // exact byte sum
+#pragma unroll
+                    for (int kx = 0; kx < 4; ++kx) {
+                        const int s = (int)((w[q1] >> (8 * kx)) & 0xff);
+                        x[4 * j + q1][kx] = RESI ? px_value<true>(s, 1) : (float)s;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t w[4] = {raw[j].x, raw[j].y, raw[j].z, raw[j].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) T += (int)((w[i] & 0xffffu) + (w[i] >> 16));
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                    for (int kx = 0; kx < 4; ++kx) {
+                        const int s = (int)((w[2 * hh + (kx >> 1)] >> (16 * (kx & 1))) & 0xffff);
+                        x[2 * j + hh][kx] = RESI ? px_value<true>(s, POOL * POOL) * SCALE : (float)s;
+                    }
+            }
+        }
+    }
+
+    static __device__ __forceinline__ void run(const uint4* __restrict__ X, int ntasks, int wave, int nwaves,
+                                               const float* __restrict__ wfrag, const float* __restrict__ bfrag,
+                                               float* __restrict__ F, int N) {
+        const int lane = threadIdx.x & 63;
+        const int col = lane & 15, g = lane >> 4;
+        if (wave >= ntasks) return;
+
+        // weights of this branch -> registers (A operands), once per wave
+        float A1[4], A2[2][16], A3[2][24];
+        f32x4 B1, B2[2], B3[2];
+        {
+            const float* wf = wfrag + (size_t)BR * kTrunkWFrags * 64 + lane;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) A1[s] = wf[s * 64];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int s = 0; s < 16; ++s) A2[t][s] = wf[(4 + t * 16 + s) * 64];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int s = 0; s < 24; ++s) A3[t][s] = wf[(36 + t * 24 + s) * 64];
+            const float* bf = bfrag + (size_t)BR * kTrunkBFrags * 64 + lane;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) B1[r] = bf[r * 64];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    B2[t][r] = bf[(4 + t * 4 + r) * 64];
+                    B3[t][r] = bf[(12 + t * 4 + r) * 64];
+                }
+        }
+
+        uint4 raw[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) raw[j] = X[((size_t)wave * NJ + j) * 64 + lane];
+
+        for (int task = wave; task < ntasks; task += nwaves) {
+            // the raw registers are dead once decoded: the next task's record is fetched under this
+            // task's 240 MFMAs at no VGPR cost
+            float x[16][4];
+            int T;
+            decode(raw, x, T);
+            if (task + nwaves < ntasks) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) raw[j] = X[((size_t)(task + nwaves) * NJ + j) * 64 + lane];
+            }
+            T += __shfl_xor(T, 16);
+            T += __shfl_xor(T, 32);
+            // canonical centring: AI  v = fma(float(sum), c255 * 2^-p, -mean)  (one rounding);
+            //                     resi v = x - mean with x = ((s - 128 cnt) / 255 * 10) * 2^-p
+            const float mean = px_value<RESI>(T, 256 * POOL * POOL) * (SCALE * (1.0f / 256.0f));
+            const float negmean = -mean;
+
+            int grp, by, bx;  // wave-uniform
+            if (BR == 0) { grp = task >> 4; by = (task >> 2) & 3; bx = task & 3; }
+            else if (BR == 1) { grp = task >> 2; by = (task >> 1) & 1; bx = task & 1; }
+            else { grp = task; by = 0; bx = 0; }
+            const bool valid = grp * 16 + col < N;
+            // feature k of this lane's CTU: Fg[(k/4) * 64 + (k%4)]  (k % 4 == 0 for every f32x4 below)
+            float* Fg = F + (size_t)grp * kNFeat * 16 + col * 4;
+
+            // conv1 of position q2: 4 patches (q1) x 4 k-steps (s = kx); lane supplies v[patch][ky=g][kx=s]
+#define CONV1(q2, c1)                                                                                  \
+    {                                                                                                  \
+        _Pragma("unroll") for (int q1 = 0; q1 < 4; ++q1) c1[q1] = B1;                                  \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                  \
+            _Pragma("unroll") for (int q1 = 0; q1 < 4; ++q1) {                                         \
+                const float xv = x[4 * (q2) + q1][s];                                                  \
+                c1[q1] = MFMA16(A1[s], RESI ? xv - mean : fmaf(xv, C255S, negmean), c1[q1]);           \
+            }                                                                                          \
+    }
+            // conv2 of position q2: K = (q1, r, g) with ci = 4g + r; two M tiles (channels 0-15, 16-23 + pad)
+#define CONV2(c1, c2)                                                                                  \
+    {                                                                                                  \
+        c2[0] = B2[0];                                                                                 \
+        c2[1] = B2[1];                                                                                 \
+        _Pragma("unroll") for (int q1 = 0; q1 < 4; ++q1)                                               \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                            \
+                c2[0] = MFMA16(A2[0][4 * q1 + r], c1[q1][r], c2[0]);                                   \
+                c2[1] = MFMA16(A2[1][4 * q1 + r], c1[q1][r], c2[1]);                                   \
+            }                                                                                          \
+    }
+#define LEAKY1(c1) { _Pragma("unroll") for (int q1 = 0; q1 < 4; ++q1) c1[q1] = lrelu4(c1[q1]); }
+            // leaky + store of conv2 position q2
+#define FINISH2(q2, c2)                                                                                \
+    {                                                                                                  \
+        a2[q2][0] = lrelu4(c2[0]);                                                                     \
+        a2[q2][1] = lrelu4(c2[1]);                                                                     \
+        if (valid) {                                                                                   \
+            const int slot = (2 * by + ((q2) >> 1)) * (2 * NB) + 2 * bx + ((q2) & 1);                  \
+            const int k0 = OFF2 + slot * 24 + 4 * g;                                                   \
+            *reinterpret_cast<f32x4*>(Fg + (k0 >> 2) * 64) = a2[q2][0];                                \
+            if (g < 2) *reinterpret_cast<f32x4*>(Fg + ((k0 + 16) >> 2) * 64) = a2[q2][1];              \
+        }                                                                                              \
+    }
+            f32x4 a2[4][2];
+            f32x4 c3[2] = {B3[0], B3[1]};
+#pragma unroll
+            for (int q2 = 0; q2 < 4; ++q2) {
+                f32x4 c1[4], c2[2];
+                CONV1(q2, c1);
+                LEAKY1(c1);
+                CONV2(c1, c2);
+                FINISH2(q2, c2);
+            }
+#undef CONV1
+#undef CONV2
+#undef LEAKY1
+#undef FINISH2
+            // conv3 phase A: channels 0..15 of the 4 positions
+#pragma unroll
+            for (int q2 = 0; q2 < 4; ++q2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    c3[0] = MFMA16(A3[0][4 * q2 + r], a2[q2][0][r], c3[0]);
+                    c3[1] = MFMA16(A3[1][4 * q2 + r], a2[q2][0][r], c3[1]);
+                }
+            // phase B: channels 16..23, positions (2j, 2j+1) packed into the lower / upper lane halves
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float hi = __shfl(a2[2 * j + 1][1][r], lane & 31);  // lanes 32..63 <- lanes 0..31 of position 2j+1
+                    const float z = (lane < 32) ? a2[2 * j][1][r] : hi;
+                    c3[0] = MFMA16(A3[0][16 + 4 * j + r], z, c3[0]);
+                    c3[1] = MFMA16(A3[1][16 + 4 * j + r], z, c3[1]);
+                }
+            if (valid) {
+                const int k0 = OFF3 + (by * NB + bx) * 32 + 4 * g;
+                *reinterpret_cast<f32x4*>(Fg + (k0 >> 2) * 64) = lrelu4(c3[0]);
+                *reinterpret_cast<f32x4*>(Fg + ((k0 + 16) >> 2) * 64) = lrelu4(c3[1]);
+            }
+        }
+    }
+};
+
+template <bool RESI>
+__global__ __launch_bounds__(256) void k1_trunk(const uint4* __restrict__ XS, const uint4* __restrict__ XM,
+                                                const uint4* __restrict__ XL, int N, int bS, int bM,
+                                                const float* __restrict__ wfrag, const float* __restrict__ bfrag,
+                                                float* __restrict__ F) {
+    const int w = threadIdx.x >> 6;
+    const int b = blockIdx.x;
+    const int groups = (N + 15) / 16;
+    if (b < bS) Trunk<0, RESI>::run(XS, groups * 16, b * 4 + w, bS * 4, wfrag, bfrag, F, N);
+    else if (b < bS + bM) Trunk<1, RESI>::run(XM, groups * 4, (b - bS) * 4 + w, bM * 4, wfrag, bfrag, F, N);
+    else Trunk<2, RESI>::run(XL, groups, (b - bS - bM) * 4 + w, (int)(gridDim.x - bS - bM) * 4, wfrag, bfrag, F, N);
+}
+
+void launch_trunk(const Workspace& ws, const DeviceWeights& w, int n, bool resi, hipStream_t s) {
+    // tasks per group: 16 S, 4 M, 1 L -- all 240 MFMAs.  512 blocks = 2 per CU, shares 16:4:1.
+    const int groups = (n + 15) / 16, tS = groups * 16, tM = groups * 4, tL = groups;
+    auto blocks = [](int tasks, int budget) { int b = (tasks + 3) / 4; return b < budget ? b : budget; };
+    const int bS = blocks(tS, 390), bM = blocks(tM, 98), bL = blocks(tL, 24);
+    if (resi)
+        hipLaunchKernelGGL(k1_trunk<true>, dim3(bS + bM + bL), dim3(256), 0, s, ws.xs, ws.xm, ws.xl, n, bS, bM,
+                           w.trunk_w, w.trunk_b, ws.feat);
+    else
+        hipLaunchKernelGGL(k1_trunk<false>, dim3(bS + bM + bL), dim3(256), 0, s, ws.xs, ws.xm, ws.xl, n, bS, bM,
+                           w.trunk_w, w.trunk_b, ws.feat);
+}
+
+}  // namespace ethcnn

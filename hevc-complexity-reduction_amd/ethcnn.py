@@ -296,8 +296,9 @@ class EthCnn(object):
         return out
 
     # -- measurement / introspection
-    def set_profiling(self, on=True):
-        self._chk(self.lib.ethcnn_set_profiling(self.h, 1 if on else 0))
+    def set_profiling(self, level=2):
+        """0 off, 1 dominant kernel (FC1) only, 2 every stage."""
+        self._chk(self.lib.ethcnn_set_profiling(self.h, int(level)))
 
     def reset_stage_times(self):
         self._chk(self.lib.ethcnn_reset_stage_times(self.h))

@@ -134,7 +134,8 @@ typedef struct ethcnn_stage_times {
     int64_t launches[ETHCNN_NSTAGES];
     int64_t ctus;                    /* CTUs processed since reset */
 } ethcnn_stage_times;
-int ethcnn_set_profiling(ethcnn_ctx* ctx, int on); /* on: events around every launch */
+int ethcnn_set_profiling(ethcnn_ctx* ctx, int level); /* 0 off; 1 events around the dominant kernel (FC1) only;
+                                                          2 around every launch (each event pair costs ~5 us of stream time) */
 int ethcnn_get_stage_times(ethcnn_ctx* ctx, ethcnn_stage_times* out); /* synchronizes */
 int ethcnn_reset_stage_times(ethcnn_ctx* ctx);
 
