@@ -28,9 +28,18 @@ namespace ethcnn {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-__device__ __forceinline__ float lrelu_t(float h) { return fmaxf(0.2f * h, h); }
-__device__ __forceinline__ f32x4 lrelu4(f32x4 v) {
-    return (f32x4){lrelu_t(v[0]), lrelu_t(v[1]), lrelu_t(v[2]), lrelu_t(v[3])};
+// max(0.2h, h) as v_mul + ONE v_max per value: fmaxf() makes hipcc canonicalise the raw MFMA
+// output first (a second v_max per value; 104 values per task).  Hazards (guide 5.7): the
+// compiler-generated multiplies read the MFMA result first, so the MFMA->VALU wait states are
+// served before the asm issues; the asm's outputs feed MFMA operands, hence the trailing s_nop 1
+// (VALU write -> MFMA read), paid once per four values.
+__device__ __forceinline__ f32x4 lrelu4(f32x4 h) {
+    const float t0 = 0.2f * h[0], t1 = 0.2f * h[1], t2 = 0.2f * h[2], t3 = 0.2f * h[3];
+    float o0, o1, o2, o3;
+    asm volatile("v_max_f32 %0, %4, %8\n\tv_max_f32 %1, %5, %9\n\tv_max_f32 %2, %6, %10\n\tv_max_f32 %3, %7, %11\n\ts_nop 1"
+                 : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3)
+                 : "v"(t0), "v"(t1), "v"(t2), "v"(t3), "v"(h[0]), "v"(h[1]), "v"(h[2]), "v"(h[3]));
+    return (f32x4){o0, o1, o2, o3};
 }
 
 template <bool RESI>
