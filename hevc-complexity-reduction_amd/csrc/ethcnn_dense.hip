@@ -15,9 +15,10 @@
 //     into the wave's private LDS slot, read back as one float4 per lane (ctu, g), whose element
 //     e feeds MFMA step e.  That fixes the accumulation order inside a sub-chunk to k = 16c + 4g + e
 //     (e outer, g inner): the canonical FC order of DESIGN.md, restated by the oracle.
-//   * NSPLIT column blocks per M tile, column block = blockIdx.x % NSPLIT: the dispatcher puts
-//     block b on XCD b % 8, so each XCD streams only 1/NSPLIT of W1 and keeps it L2-resident
-//     (W1 is 4.8 MB, an XCD's L2 4 MiB).  Speed only; results are placement-independent.
+//   * NSPLIT column blocks per M tile.  The dispatcher puts block b on XCD b % 8; the blocks of
+//     one M tile are mapped to consecutive slots of the same XCD so the tile's features cross
+//     the fabric once and are shared through that XCD's L2 (measured: FETCH_SIZE / NSPLIT, same
+//     or better time).  Speed only; results are placement-independent.
 //   * one ascending-chunk MFMA chain per accumulator, no split-K; bias + leaky-ReLU epilogue.
 #include <hip/hip_runtime.h>
 
@@ -40,7 +41,7 @@ typedef const __attribute__((address_space(1))) void glb_void;
 // iteration's own issue count: a COUNTED s_waitcnt, never vmcnt(0), and a raw s_barrier (a
 // __syncthreads() would drain the queue, ROCm 7.2).  WAR: stage (kc+3)%3 == kc%3 is refilled in
 // iteration kc+1, after every wave has passed the barrier that ends iteration kc.
-template <int MS, int NS, int WM, int NSUB>
+template <int MS, int NS, int WM, int NSUB, bool GROUP>
 __global__ __launch_bounds__(64 * WM) void k_fc1_p3(const float* __restrict__ feat, const float* __restrict__ Wimg,
                                                     const float* __restrict__ bias, float* __restrict__ out, int M) {
     constexpr int BK = 16 * NSUB, BN = 16 * NS, NSPLIT = kNVec / BN, BM = 16 * MS * WM;
@@ -58,8 +59,21 @@ __global__ __launch_bounds__(64 * WM) void k_fc1_p3(const float* __restrict__ fe
 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int col = lane & 15, g = lane >> 4;
-    const int nb = (int)(blockIdx.x % NSPLIT);
-    const int m0 = (int)(blockIdx.x / NSPLIT) * BM + wv * 16 * MS;
+    // block -> (M tile, column block).  Spread: column block = b % NSPLIT, an XCD (b % 8) streams one
+    // slice of W1 but every M tile's features are fetched by NSPLIT different XCDs.  GROUP: the
+    // NSPLIT column blocks of an M tile are consecutive slots of ONE XCD, so its features come
+    // from HBM once and are shared through that XCD's L2 (W1 is then swept whole per XCD).
+    int nb, mt;
+    if (GROUP) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        nb = slot % NSPLIT;
+        mt = (slot / NSPLIT) * 8 + xcd;
+        if (mt * BM >= M) return;  // whole block leaves before any barrier
+    } else {
+        nb = (int)(blockIdx.x % NSPLIT);
+        mt = (int)(blockIdx.x / NSPLIT);
+    }
+    const int m0 = mt * BM + wv * 16 * MS;
     const int n0 = nb * BN;
 
     f32x4 acc[MS][NS];
@@ -163,11 +177,12 @@ __global__ __launch_bounds__(64 * WM) void k_fc1_p3(const float* __restrict__ fe
     }
 }
 
-template <int MS, int NS, int WM, int NSUB>
+template <int MS, int NS, int WM, int NSUB, bool GROUP = false>
 static void launch_fc1_p3(const float* feat, const float* wimg, const float* bias, float* out, int M, hipStream_t s) {
     constexpr int BM = 16 * MS * WM, NSPLIT = kNVec / (16 * NS);
-    hipLaunchKernelGGL((k_fc1_p3<MS, NS, WM, NSUB>), dim3(((M + BM - 1) / BM) * NSPLIT), dim3(64 * WM), 0, s, feat, wimg,
-                       bias, out, M);
+    const int mtiles = (M + BM - 1) / BM;
+    const int blocks = GROUP ? ((mtiles + 7) / 8) * 8 * NSPLIT : mtiles * NSPLIT;
+    hipLaunchKernelGGL((k_fc1_p3<MS, NS, WM, NSUB, GROUP>), dim3(blocks), dim3(64 * WM), 0, s, feat, wimg, bias, out, M);
 }
 
 static int fc1_variant() {
@@ -196,25 +211,19 @@ static int fc1_auto_variant(int n) {
 void launch_fc1(const Workspace& ws, const DeviceWeights& w, int n, float* out, hipStream_t s) {
     int variant = fc1_variant();
     if (variant < 0) variant = fc1_auto_variant(n);
-    switch (variant) {
+    switch (variant) {  // production shapes run XCD-grouped; 10..12 are the ungrouped A/B twins
         default:  // 0: 128 CTUs (4 waves x 2 groups) x 112 columns (N split 4), BK 16
-            launch_fc1_p3<2, 7, 4, 1>(ws.feat, w.fc1_img112, w.fc1_b, out, n, s);
+            launch_fc1_p3<2, 7, 4, 1, true>(ws.feat, w.fc1_img112, w.fc1_b, out, n, s);
             break;
         case 1:  // 64 CTUs x 112 columns
-            launch_fc1_p3<1, 7, 4, 1>(ws.feat, w.fc1_img112, w.fc1_b, out, n, s);
+            launch_fc1_p3<1, 7, 4, 1, true>(ws.feat, w.fc1_img112, w.fc1_b, out, n, s);
             break;
         case 2:  // 64 CTUs x 64 columns (N split 7), BK 32
-            launch_fc1_p3<1, 4, 4, 2>(ws.feat, w.fc1_img64, w.fc1_b, out, n, s);
+            launch_fc1_p3<1, 4, 4, 2, true>(ws.feat, w.fc1_img64, w.fc1_b, out, n, s);
             break;
-        case 3:  // 128 CTUs (8 waves) x 112 columns
-            launch_fc1_p3<1, 7, 8, 1>(ws.feat, w.fc1_img112, w.fc1_b, out, n, s);
-            break;
-        case 4:  // 128 CTUs x 64 columns, BK 32
-            launch_fc1_p3<2, 4, 4, 2>(ws.feat, w.fc1_img64, w.fc1_b, out, n, s);
-            break;
-        case 5:  // 256 CTUs (8 waves x 2 groups) x 112 columns
-            launch_fc1_p3<2, 7, 8, 1>(ws.feat, w.fc1_img112, w.fc1_b, out, n, s);
-            break;
+        case 10: launch_fc1_p3<2, 7, 4, 1, false>(ws.feat, w.fc1_img112, w.fc1_b, out, n, s); break;
+        case 11: launch_fc1_p3<1, 7, 4, 1, false>(ws.feat, w.fc1_img112, w.fc1_b, out, n, s); break;
+        case 12: launch_fc1_p3<1, 4, 4, 2, false>(ws.feat, w.fc1_img64, w.fc1_b, out, n, s); break;
     }
 }
 
