@@ -22,6 +22,23 @@ for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GR
   rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d $REPO/gpurun_out/pmc_c2_$tag -o p -- python $REPO/bench.py --no-cpu-baseline --steps 5 --warmup 1 > $REPO/gpurun_out/pmc_c2_$tag.log 2>&1
 done
 cd $REPO
+python - <<'PY'
+# FC1 HBM traffic per launch from the FETCH_SIZE / WRITE_SIZE passes (KB as reported; FETCH x2 on gfx950)
+import csv, glob, json
+def avg(tag, counter):
+    vals=[]
+    for f in glob.glob("gpurun_out/pmc_c2_%s/**/*counter_collection.csv" % tag, recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "k_fc1" in r["Kernel_Name"] and r["Counter_Name"] == counter: vals.append(float(r["Counter_Value"]))
+    return sum(vals)/len(vals) if vals else None
+fe, wr = avg("FETCH_SIZE","FETCH_SIZE"), avg("WRITE_SIZE","WRITE_SIZE")
+if fe is not None and wr is not None:
+    n = 25500
+    out = {"c2": {"bytes_per_launch": int(fe*1024*2 + wr*1024), "fetch_size_kb_reported": fe, "write_size_kb_reported": wr,
+                  "algorithmic_bytes_per_launch": n*2688*4 + 2688*448*4 + n*448*4,
+                  "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of `python bench.py --no-cpu-baseline --steps 5 --warmup 1` (scripts/gpu_round.sh); FETCH_SIZE x2 (gfx950 correction)"}}
+    json.dump(out, open("gpurun_out/fc1_traffic.json","w"), indent=1); print("fc1 traffic:", out)
+PY
 head -12 gpurun_out/prof_c2/c2_kernel_stats.csv
 python - <<'PY'
 import csv, glob, collections

@@ -142,3 +142,47 @@ def test_errors_are_loud(pkg, ctx):
         pkg.EthCnn(device=0).predict_luma(np.zeros((64, 64), np.uint8), 64, 64, 1, 32)  # no weights
     with pytest.raises(pkg.EthCnnError):
         ctx.load_blob(np.zeros(10, np.float32))
+
+
+# ---- BASELINE.json full sizes: size-independent properties + sampled oracle frames --------------
+def _full_size_case(pkg, oracle, w, h, frames, qp, sample_frames):
+    import bench
+    luma = bench.synth_luma(w, h, frames, seed=77)
+    blob = oracle.synth_blob(1, 8.0)
+    nctu = pkg.ethcnn.ctus_per_frame(w, h)
+    outs = []
+    for cap in (0, 8192):  # default workspace (one pass) vs many passes / split frames
+        c = pkg.EthCnn(device=0, max_ctus_per_pass=cap)
+        c.load_blob(blob)
+        outs.append(c.predict_luma(luma, w, h, frames, qp))
+        if cap == 0:  # frames are independent: reversing the frame order reverses the output blocks
+            rev = c.predict_luma(luma[::-1].copy(), w, h, frames, qp)
+            assert np.array_equal(_bits(rev.reshape(frames, nctu, 21)[::-1]), _bits(outs[0].reshape(frames, nctu, 21)))
+            again = c.predict_luma(luma, w, h, frames, qp)  # idempotent / no state carried between calls
+            assert np.array_equal(_bits(again), _bits(outs[0]))
+        c.close()
+    assert np.array_equal(_bits(outs[0]), _bits(outs[1])), "result depends on the pass plan"
+    P = outs[0].reshape(frames, nctu, 21)
+    assert np.isfinite(P).all() and P.min() >= 0.0 and P.max() <= 1.0
+    for f in sample_frames:  # sampled frames against the oracle (bit-exact)
+        want = oracle.predict_frames(blob, luma[f], w, h, 1, qp, 0.5, 0.5, mode=0)
+        assert np.array_equal(_bits(P[f]), _bits(want)), "frame %d" % f
+    # gate structure: a closed L1 gate zeroes p32 for the whole sub-batch, and then p16 too
+    for f in range(frames):
+        for s0 in range(0, nctu, 1024):
+            blk = P[f, s0:s0 + 1024]
+            if not (blk[:, 0] > 0.5).any():
+                assert not blk[:, 1:].any()
+            if not (blk[:, 1:5] > 0.5).any():
+                assert not blk[:, 5:].any()
+
+
+def test_full_size_c2(pkg, oracle):
+    """BASELINE.json configs[1]: 1920x1080 QP32 x 50 frames (25,500 CTUs)."""
+    _full_size_case(pkg, oracle, 1920, 1080, 50, 32, sample_frames=(0, 17, 49))
+
+
+@pytest.mark.parametrize("qp", [22, 37])
+def test_full_size_c3(pkg, oracle, qp):
+    """BASELINE.json configs[2]: 3840x2160 x 50 frames (102,000 CTUs; sub-batches 1024 + 1016)."""
+    _full_size_case(pkg, oracle, 3840, 2160, 50, qp, sample_frames=(0, 31))
