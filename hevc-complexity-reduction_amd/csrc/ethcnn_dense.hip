@@ -208,23 +208,43 @@ static int fc1_auto_variant(int n) {
     return best;
 }
 
-void launch_fc1(const Workspace& ws, const DeviceWeights& w, int n, float* out, hipStream_t s) {
-    int variant = fc1_variant();
-    if (variant < 0) variant = fc1_auto_variant(n);
+// one shape over rows [row0, row0 + rows) (row0 a multiple of 16): the kernel sees shifted pointers
+static void launch_fc1_rows(int variant, const Workspace& ws, const DeviceWeights& w, int row0, int rows, float* out,
+                            hipStream_t s) {
+    const float* feat = ws.feat + (size_t)(row0 / 16) * kNFeat * 16;
+    float* o = out + (size_t)row0 * kNVec;
     switch (variant) {  // production shapes run XCD-grouped; 10..12 are the ungrouped A/B twins
         default:  // 0: 128 CTUs (4 waves x 2 groups) x 112 columns (N split 4), BK 16
-            launch_fc1_p3<2, 7, 4, 1, true>(ws.feat, w.fc1_img112, w.fc1_b, out, n, s);
+            launch_fc1_p3<2, 7, 4, 1, true>(feat, w.fc1_img112, w.fc1_b, o, rows, s);
             break;
         case 1:  // 64 CTUs x 112 columns
-            launch_fc1_p3<1, 7, 4, 1, true>(ws.feat, w.fc1_img112, w.fc1_b, out, n, s);
+            launch_fc1_p3<1, 7, 4, 1, true>(feat, w.fc1_img112, w.fc1_b, o, rows, s);
             break;
         case 2:  // 64 CTUs x 64 columns (N split 7), BK 32
-            launch_fc1_p3<1, 4, 4, 2, true>(ws.feat, w.fc1_img64, w.fc1_b, out, n, s);
+            launch_fc1_p3<1, 4, 4, 2, true>(feat, w.fc1_img64, w.fc1_b, o, rows, s);
             break;
-        case 10: launch_fc1_p3<2, 7, 4, 1, false>(ws.feat, w.fc1_img112, w.fc1_b, out, n, s); break;
-        case 11: launch_fc1_p3<1, 7, 4, 1, false>(ws.feat, w.fc1_img112, w.fc1_b, out, n, s); break;
-        case 12: launch_fc1_p3<1, 4, 4, 2, false>(ws.feat, w.fc1_img64, w.fc1_b, out, n, s); break;
+        case 10: launch_fc1_p3<2, 7, 4, 1, false>(feat, w.fc1_img112, w.fc1_b, o, rows, s); break;
+        case 11: launch_fc1_p3<1, 7, 4, 1, false>(feat, w.fc1_img112, w.fc1_b, o, rows, s); break;
+        case 12: launch_fc1_p3<1, 4, 4, 2, false>(feat, w.fc1_img64, w.fc1_b, o, rows, s); break;
     }
+}
+
+void launch_fc1(const Workspace& ws, const DeviceWeights& w, int n, float* out, hipStream_t s) {
+    const int variant = fc1_variant();
+    if (variant >= 0 && variant != 20) {  // A/B knob: one fixed shape (20 = the best single shape for n)
+        launch_fc1_rows(variant, ws, w, 0, n, out, s);
+        return;
+    }
+    if (variant == 20) {
+        launch_fc1_rows(fc1_auto_variant(n), ws, w, 0, n, out, s);
+        return;
+    }
+    // Default, split launch: the 128 x 112 shape (best plateau) on as many rows as give a whole number of
+    // blocks per CU (a multiple of 256 blocks), the remaining rows with the shape that balances best.
+    const int big_tiles = ((n / 128) * 4 / 256) * 256 / 4;
+    const int row0 = big_tiles * 128;
+    if (big_tiles > 0) launch_fc1_rows(0, ws, w, 0, row0, out, s);
+    if (n > row0) launch_fc1_rows(fc1_auto_variant(n - row0), ws, w, row0, n - row0, out, s);
 }
 
 }  // namespace ethcnn
