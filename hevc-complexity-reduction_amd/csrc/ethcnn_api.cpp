@@ -13,7 +13,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "ethcnn_kernels.h"
@@ -424,6 +426,28 @@ static int ensure_staging(ethcnn_ctx* c, size_t in_bytes, size_t out_bytes) {
     return 0;
 }
 
+// frames of one staging group are copied / pread by a few host threads (one memcpy stream moves
+// ~10 GB/s, PCIe Gen5 x16 takes ~50): fn(f) for f in [0, n), first non-zero return wins
+template <typename Fn>
+static int parallel_frames(int n, Fn fn) {
+    const int nt = std::min(n, std::min(8, (int)std::max(1u, std::thread::hardware_concurrency())));
+    if (nt <= 1) {
+        for (int f = 0; f < n; ++f)
+            if (int r = fn(f)) return r;
+        return 0;
+    }
+    std::atomic<int> next(0), rc(0);
+    auto work = [&]() {
+        for (int f = next.fetch_add(1); f < n && rc.load() == 0; f = next.fetch_add(1))
+            if (int r = fn(f)) rc.store(r);
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+    return rc.load();
+}
+
 // Generic double-buffered host pipeline: for each group of frames, `fill(buf, f0, nf)` packs
 // luma planes tightly (pitch = width) into pinned memory, then H2D -> kernels -> D2H run on
 // three streams so the copy of group i+1 overlaps the compute of group i, and
@@ -438,7 +462,10 @@ static int host_pipeline(ethcnn_ctx* c, int w, int h, int nframes, int qp, Fill 
     HIPCHK(c, hipSetDevice(c->device));
     // frames per group: whole frames up to max_ctus (a frame larger than the workspace is
     // still one group; run_pass splits it)
-    const int fpg = std::max(1, std::min(nframes, c->max_ctus / g.nctu));
+    // group size: ~8 groups per call so copies, kernels and the drain overlap, but no group smaller
+    // than ~4096 CTUs (kernel efficiency) or larger than the workspace
+    const int fpg = std::max(1, std::min(std::min(nframes, c->max_ctus / g.nctu),
+                                         std::max((4096 + g.nctu - 1) / g.nctu, (nframes + 7) / 8)));
     const size_t plane = (size_t)w * h;
     rc = ensure_staging(c, plane * fpg, (size_t)fpg * g.nctu * kNOut * 4);
     if (rc) return rc;
@@ -509,13 +536,13 @@ extern "C" int ethcnn_predict_luma(ethcnn_ctx* c, const uint8_t* luma, int w, in
     if (pitch < w) return set_err(c, ETHCNN_ERR_ARG, "pitch %td < width %d", pitch, w);
     const int nctu = ((w + 63) / 64) * ((h + 63) / 64);
     auto fill = [&](uint8_t* dst, int f0, int nf) -> int {
-        for (int f = 0; f < nf; ++f) {
+        return parallel_frames(nf, [&](int f) -> int {
             const uint8_t* src = luma + (size_t)(f0 + f) * fstride;
             uint8_t* d = dst + (size_t)f * w * h;
             if (pitch == w) std::memcpy(d, src, (size_t)w * h);
             else for (int y = 0; y < h; ++y) std::memcpy(d + (size_t)y * w, src + (size_t)y * pitch, (size_t)w);
-        }
-        return 0;
+            return 0;
+        });
     };
     auto drain = [&](const float* src, int f0, int nf) -> int {
         std::memcpy(probs + (size_t)f0 * nctu * kNOut, src, (size_t)nf * nctu * kNOut * 4);
@@ -552,17 +579,18 @@ static int yuv_frames(ethcnn_ctx* c, const char* yuv, int w, int h, int qp, cons
     }
     const int fd = fileno(fin), ofd = fileno(fout);
     auto fill = [&](uint8_t* dst, int g0, int nf) -> int {
-        for (int f = 0; f < nf; ++f) {  // luma only; chroma (w*h/2 bytes) is never read (:47-48)
+        const int rc = parallel_frames(nf, [&](int f) -> int {  // luma only; chroma (w*h/2 bytes) is never read (:47-48)
             size_t got = 0;
             const size_t want = (size_t)w * h;
             const off_t off = (off_t)(f0 + g0 + f) * frame_bytes;
             while (got < want) {
                 const ssize_t r = pread(fd, dst + (size_t)f * want + got, want - got, off + (off_t)got);
-                if (r <= 0) return set_err(c, ETHCNN_ERR_IO, "short read in %s (frame %lld)", yuv, (long long)(f0 + g0 + f));
+                if (r <= 0) return ETHCNN_ERR_IO;
                 got += (size_t)r;
             }
-        }
-        return 0;
+            return 0;
+        });
+        return rc ? set_err(c, rc, "short read in %s (frames %lld..%lld)", yuv, (long long)(f0 + g0), (long long)(f0 + g0 + nf - 1)) : 0;
     };
     auto drain = [&](const float* src, int g0, int nf) -> int {
         const size_t bytes = (size_t)nf * nctu * kNOut * 4;
