@@ -4,11 +4,10 @@
 // gfx950, v_mfma_f32_16x16x4_f32.
 //
 // One wave = 16 CTUs, "transposed": MFMA rows = output features, columns = CTUs.
-//   FC2^T: A operand = W2 (one 16-k chunk of every still-active head staged per iteration by
-//          LDS-DMA, shared by the block's 4 waves; ONE barrier per iteration for all heads:
-//          head 16 has 16 chunks, head 32 the first 8, head 64 the first 4), B operand = this
-//          wave's h1 rows, one float4 per lane per chunk and head (element e feeds MFMA step e ->
-//          k order 16c + 4g + e, the canonical FC order).
+//   FC2^T: A operand = W2 (16-k chunks by LDS-DMA, shared by the block's 4 waves, 3 stages),
+//          B operand = this wave's h1 rows, one float4 per lane per chunk (element e feeds MFMA
+//          step e -> k order 16c + 4g + e, the canonical FC order).  Heads run one after the other
+//          (16, 32, 64) so only one head's accumulators are live.
 //   The FC2^T accumulator of lane (ctu, g) holds h2[ctu][16t + 4g + r]: exactly the B operand
 //   FC3^T needs for step (t, r) -- so FC2 -> FC3 chains in registers (same k order), no LDS,
 //   no HBM round trip.  FC3^T's A operand (W3, 3525 floats in all) comes straight from L1/L2.
@@ -67,106 +66,119 @@ struct Hd {
     static constexpr int NK = N1 / 16;             // 16-k chunks (4 / 8 / 16)
     static constexpr int B_FLOATS = 16 * N2;       // one W2 chunk
     static constexpr int B_INST = B_FLOATS / 256;  // 3 / 6 / 12 LDS-DMA instructions
-    static constexpr int LDS_OFF = (H == 2) ? 0 : (H == 1 ? 16 * 192 : 16 * (192 + 96));  // inside a stage
+    static constexpr int B_PER = (B_INST + 3) / 4; // per wave (the tail duplicates the last piece)
+    static constexpr int ISSUE = B_PER + 1;        // VMEM ops per wave per iteration (+ its h1 piece)
     static constexpr bool COLSWZ = (N2 % 32 == 0);
 };
-constexpr int kHeadsStage = 16 * (192 + 96 + 48);  // floats per LDS stage (21.5 KB)
+constexpr int kHeadsStage = 16 * 192 + 4 * 256;  // floats per LDS stage: widest W2 chunk + 4 waves' h1 pieces
 
-// per-head, per-lane state kept across the merged K loop
+// One head for this wave's 16 CTUs.  3 LDS stages, prefetch distance 2, every operand by LDS-DMA
+// (inline asm: hipcc neither drains nor counts it), counted vmcnt + raw barrier -- the FC1 pipeline
+// of ethcnn_dense.hip at the heads' sizes.
 template <int H>
-struct HeadState {
-    f32x4 acc[Hd<H>::NT];
-    float4 a_cur, a_nxt;
-    const float* a_src;   // this lane's h1 float4 stream
-    const float* b_src;   // LDS-DMA source of this lane (instructions wv, wv+4, ...)
-    int bcol[Hd<H>::NT], brow[4];
-};
-
-template <int H>
-__device__ __forceinline__ void head_init(HeadState<H>& st, const float* h1row, const float* W2, int lane, int wv) {
-    using D = Hd<H>;
-    const int col = lane & 15, g = lane >> 4;
-#pragma unroll
-    for (int j = 0; j < D::NT; ++j) st.acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    st.a_src = h1row + D::O1 + 4 * g;
-    // same permuted LDS image as ethcnn_dense.hip: position (p, c) holds W2[p'][c'] with rows /
-    // column groups of odd (k>>2) swapped; here the permutation is applied to the DMA source
-    {
-        const int e = wv * 64 + lane;  // float4 index of instruction wv (others: + 4*64 per step)
-        (void)e;
-    }
-    st.b_src = W2;
-#pragma unroll
-    for (int j = 0; j < D::NT; ++j) st.bcol[j] = (j * 16 + col) ^ (D::COLSWZ ? ((g & 1) << 4) : 0);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) st.brow[e] = (D::COLSWZ ? e : (e ^ (g & 1))) * D::N2;
-}
-
-// issue this wave's share of the LDS-DMA of chunk kc of head H into stage `buf`
-template <int H>
-__device__ __forceinline__ void head_issue(const HeadState<H>& st, float* smem, int kc, int buf, int lane, int wv) {
-    using D = Hd<H>;
-#pragma unroll
-    for (int i = 0; i < (D::B_INST + 3) / 4; ++i) {
-        const int q = wv + i * 4;
-        if ((i + 1) * 4 <= D::B_INST || q < D::B_INST) {
-            const int e = q * 64 + lane;
-            int row = (e / (D::N2 / 4)) % 16;
-            int c4 = e % (D::N2 / 4);
-            if (D::COLSWZ) c4 ^= ((row >> 2) & 1) << 2;
-            else row ^= (row >> 2) & 1;
-            __builtin_amdgcn_global_load_lds((glb_void*)(st.b_src + (size_t)(kc * 16 + row) * D::N2 + c4 * 4),
-                                             (lds_void*)(smem + buf * kHeadsStage + D::LDS_OFF + q * 256), 16, 0, 0);
-        }
-    }
-}
-
-template <int H>
-__device__ __forceinline__ void head_mfma(HeadState<H>& st, const float* smem, int buf, int g) {
-    using D = Hd<H>;
-    const float* bs = smem + buf * kHeadsStage + D::LDS_OFF + 4 * g * D::N2;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float hv = (e == 0) ? st.a_cur.x : (e == 1) ? st.a_cur.y : (e == 2) ? st.a_cur.z : st.a_cur.w;
-#pragma unroll
-        for (int j = 0; j < D::NT; ++j) st.acc[j] = MFMA16(bs[st.brow[e] + st.bcol[j]], hv, st.acc[j]);  // rows = W2 columns
-    }
-}
-
-// FC2 epilogue (qp column, bias, leaky) in place, optional h2 store, FC3^T, sigmoid, outputs
-template <int H>
-__device__ __forceinline__ void head_finish(HeadState<H>& st, const HeadsParams& hp, float qn, int lane, bool valid,
-                                            int ctu, float* __restrict__ h2row, float* __restrict__ logits,
-                                            float* __restrict__ raw, float* __restrict__ probs, int* flag32,
-                                            int* flag16, float thr1, float thr2) {
+__device__ __forceinline__ void head_pass(float* smem, const float* __restrict__ h1row, const HeadsParams& hp, float qn,
+                                          int lane, unsigned wvu, bool valid, int ctu, float* __restrict__ h2row,
+                                          float* __restrict__ logits, float* __restrict__ raw, float* __restrict__ probs,
+                                          int* flag32, int* flag16, float thr1, float thr2) {
     using D = Hd<H>;
     const int col = lane & 15, g = lane >> 4;
     const float* W2 = hp.w2[H];
     const float* W3 = hp.w3[H];
+    const unsigned lds_base = (unsigned)(size_t)(lds_void*)smem;
+
+    // DMA sources.  W2 chunk: permuted LDS image (rows / column groups with odd (k>>2) swapped, as in
+    // ethcnn_dense.hip) applied to the per-lane source address.  h1 piece: lane (ctu, g) fetches
+    // its own float4 h1[ctu][O1 + 16 kc + 4 g ..], landing linearly at lane * 16 B.
+    const float* b_src[D::B_PER];
+#pragma unroll
+    for (int i = 0; i < D::B_PER; ++i) {
+        const int q = min((int)wvu + i * 4, D::B_INST - 1);
+        const int e = q * 64 + lane;
+        int row = (e / (D::N2 / 4)) % 16;
+        int c4 = e % (D::N2 / 4);
+        if (D::COLSWZ) c4 ^= ((row >> 2) & 1) << 2;
+        else row ^= (row >> 2) & 1;
+        b_src[i] = W2 + (size_t)row * D::N2 + c4 * 4;
+    }
+    const float* a_src = h1row + D::O1 + 4 * g;
+    int bcol[D::NT], brow[4];
+#pragma unroll
+    for (int j = 0; j < D::NT; ++j) bcol[j] = (j * 16 + col) ^ (D::COLSWZ ? ((g & 1) << 4) : 0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) brow[e] = (D::COLSWZ ? e : (e ^ (g & 1))) * D::N2;
+
+#define HP_DMA(gsrc, lds_byte_off)                                                                       \
+    {                                                                                                    \
+        unsigned keep_;                                                                                  \
+        const unsigned dst_ = __builtin_amdgcn_readfirstlane(lds_base + (lds_byte_off));                 \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                     : "=&s"(keep_) : "v"(gsrc), "s"(dst_) : "memory");                                  \
+    }
+#define HP_ISSUE(kc, st)                                                                                 \
+    {                                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < D::B_PER; ++i)                                             \
+            HP_DMA(b_src[i] + (size_t)(kc) * 16 * D::N2,                                                 \
+                   4u * ((st) * kHeadsStage + min(wvu + i * 4, (unsigned)(D::B_INST - 1)) * 256));       \
+        HP_DMA(a_src + (kc) * 16, 4u * ((st) * kHeadsStage + 16 * 192 + wvu * 256));                     \
+    }
+#define HP_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+    f32x4 acc[D::NT];
+#pragma unroll
+    for (int j = 0; j < D::NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    __builtin_amdgcn_s_barrier();  // the previous head's last stage has been consumed by every wave
+    HP_ISSUE(0, 0);
+    HP_ISSUE(1, 1);
+    HP_WAIT(D::ISSUE);
+    __builtin_amdgcn_s_barrier();
+    int st = 0;
+#pragma unroll 1
+    for (int kc = 0; kc < D::NK; ++kc) {
+        int st2 = st + 2;
+        if (st2 >= 3) st2 -= 3;
+        if (kc + 2 < D::NK) { HP_ISSUE(kc + 2, st2); }
+        const float4 av = *reinterpret_cast<const float4*>(smem + st * kHeadsStage + 16 * 192 + wvu * 256 + lane * 4);
+        const float* bs = smem + st * kHeadsStage + 4 * g * D::N2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float hv = (e == 0) ? av.x : (e == 1) ? av.y : (e == 2) ? av.z : av.w;
+#pragma unroll
+            for (int j = 0; j < D::NT; ++j) acc[j] = MFMA16(bs[brow[e] + bcol[j]], hv, acc[j]);  // rows = W2 columns
+        }
+        if (kc + 2 < D::NK) { HP_WAIT(D::ISSUE); } else { HP_WAIT(0); }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        st = (st == 2) ? 0 : st + 1;
+    }
+#undef HP_DMA
+#undef HP_ISSUE
+#undef HP_WAIT
+
     // FC3^T A operand: W3[k = 16 j + 4 g + r][out = col]; all loads issued before the first use
     float w3r[D::NT][4];
 #pragma unroll
     for (int j = 0; j < D::NT; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) w3r[j][r] = (col < D::N3) ? W3[(16 * j + 4 * g + r) * D::N3 + col] : 0.0f;
-    // lane (ctu = col, g) holds h2[ctu][16 j + 4 g + r]
+    // FC2 epilogue in place: lane (ctu = col, g) holds h2[ctu][16 j + 4 g + r]
 #pragma unroll
     for (int j = 0; j < D::NT; ++j) {
         const int n = 16 * j + 4 * g;
         const float4 wq = *reinterpret_cast<const float4*>(W2 + (size_t)D::N1 * D::N2 + n);
         const float4 bv = *reinterpret_cast<const float4*>(hp.b2[H] + n);
-        st.acc[j][0] = lrelu_h(fmaf(qn, wq.x, st.acc[j][0]) + bv.x);
-        st.acc[j][1] = lrelu_h(fmaf(qn, wq.y, st.acc[j][1]) + bv.y);
-        st.acc[j][2] = lrelu_h(fmaf(qn, wq.z, st.acc[j][2]) + bv.z);
-        st.acc[j][3] = lrelu_h(fmaf(qn, wq.w, st.acc[j][3]) + bv.w);
-        if (valid && h2row) *reinterpret_cast<f32x4*>(h2row + D::O2 + n) = st.acc[j];
+        acc[j][0] = lrelu_h(fmaf(qn, wq.x, acc[j][0]) + bv.x);
+        acc[j][1] = lrelu_h(fmaf(qn, wq.y, acc[j][1]) + bv.y);
+        acc[j][2] = lrelu_h(fmaf(qn, wq.z, acc[j][2]) + bv.z);
+        acc[j][3] = lrelu_h(fmaf(qn, wq.w, acc[j][3]) + bv.w);
+        if (valid && h2row) *reinterpret_cast<f32x4*>(h2row + D::O2 + n) = acc[j];
     }
     // FC3^T: rows = outputs (N3 of 16 used), columns = CTUs; step (j, r) consumes k = 16 j + 4 g + r
     f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < D::NT; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) z = MFMA16(w3r[j][r], st.acc[j][r], z);
+        for (int r = 0; r < 4; ++r) z = MFMA16(w3r[j][r], acc[j][r], z);
     // lane (ctu = col, g) holds outputs 4 g + r
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -190,57 +202,19 @@ __global__ __launch_bounds__(256) void k_heads(const float* __restrict__ H1, Hea
                                                int cpf, long ctu0, float thr1, float thr2, float* __restrict__ H2,
                                                float* __restrict__ logits, float* __restrict__ raw,
                                                float* __restrict__ probs, int* __restrict__ flags) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * kHeadsStage];  // the ONLY LDS object
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int col = lane & 15, g = lane >> 4;
-    const int ctu_raw = (blockIdx.x * 4 + wv) * 16 + col;
+    __shared__ __attribute__((aligned(16))) float smem[3 * kHeadsStage];  // the ONLY LDS object (48 KB)
+    const int lane = threadIdx.x & 63;
+    const unsigned wvu = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col = lane & 15;
+    const int ctu_raw = (blockIdx.x * 4 + (int)wvu) * 16 + col;
     const bool valid = ctu_raw < N;
     const int ctu = min(ctu_raw, N - 1);  // clamped rows are loaded, never stored
     const float* h1row = H1 + (size_t)ctu * kNVec;
-    int* fl = flags + 2 * (gchunk(ctu0 + ctu, nctu, cpf) - gchunk(ctu0, nctu, cpf));
-
-    HeadState<0> s0;
-    HeadState<1> s1;
-    HeadState<2> s2;
-    head_init<0>(s0, h1row, hp.w2[0], lane, wv);
-    head_init<1>(s1, h1row, hp.w2[1], lane, wv);
-    head_init<2>(s2, h1row, hp.w2[2], lane, wv);
-
-    head_issue<2>(s2, smem, 0, 0, lane, wv);
-    head_issue<1>(s1, smem, 0, 0, lane, wv);
-    head_issue<0>(s0, smem, 0, 0, lane, wv);
-    s2.a_cur = *reinterpret_cast<const float4*>(s2.a_src);
-    s1.a_cur = *reinterpret_cast<const float4*>(s1.a_src);
-    s0.a_cur = *reinterpret_cast<const float4*>(s0.a_src);
-    s2.a_nxt = s2.a_cur; s1.a_nxt = s1.a_cur; s0.a_nxt = s0.a_cur;
-    __syncthreads();  // hipcc drains vmcnt here (LDS-DMA pending): chunk 0 has landed
-#pragma unroll 1
-    for (int kc = 0; kc < 16; ++kc) {
-        const int buf = kc & 1;
-        if (kc + 1 < 16) {
-            head_issue<2>(s2, smem, kc + 1, buf ^ 1, lane, wv);
-            s2.a_nxt = *reinterpret_cast<const float4*>(s2.a_src + (kc + 1) * 16);
-            if (kc + 1 < 8) {
-                head_issue<1>(s1, smem, kc + 1, buf ^ 1, lane, wv);
-                s1.a_nxt = *reinterpret_cast<const float4*>(s1.a_src + (kc + 1) * 16);
-            }
-            if (kc + 1 < 4) {
-                head_issue<0>(s0, smem, kc + 1, buf ^ 1, lane, wv);
-                s0.a_nxt = *reinterpret_cast<const float4*>(s0.a_src + (kc + 1) * 16);
-            }
-        }
-        head_mfma<2>(s2, smem, buf, g);
-        if (kc < 8) head_mfma<1>(s1, smem, buf, g);
-        if (kc < 4) head_mfma<0>(s0, smem, buf, g);
-        s2.a_cur = s2.a_nxt;
-        s1.a_cur = s1.a_nxt;
-        s0.a_cur = s0.a_nxt;
-        __syncthreads();
-    }
     float* h2row = H2 ? H2 + (size_t)ctu * kNFc2 : nullptr;
-    head_finish<0>(s0, hp, qn, lane, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
-    head_finish<1>(s1, hp, qn, lane, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
-    head_finish<2>(s2, hp, qn, lane, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
+    int* fl = flags + 2 * (gchunk(ctu0 + ctu, nctu, cpf) - gchunk(ctu0, nctu, cpf));
+    head_pass<2>(smem, h1row, hp, qn, lane, wvu, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
+    head_pass<1>(smem, h1row, hp, qn, lane, wvu, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
+    head_pass<0>(smem, h1row, hp, qn, lane, wvu, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
 }
 
 void launch_heads(const Workspace& ws, const DeviceWeights& w, int n, float qn, int nctu, long ctu0, float thr1,
