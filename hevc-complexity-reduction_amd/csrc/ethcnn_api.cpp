@@ -38,6 +38,15 @@ struct ethcnn_ctx {
 
     float thr1 = 0.5f, thr2 = 0.5f;  // shipped Thr_info.txt: 0.5 x 6
 
+    // LDP (ETH-LSTM one step): the LSTM checkpoint payload as stored, and per-frame buffers
+    bool have_lstm = false;
+    std::vector<float> lstm_blob;
+    float* d_lstm = nullptr;
+    float* d_vec = nullptr;       // [lstm_cap][448]
+    float* d_state[2] = {nullptr, nullptr};  // [lstm_cap][2][448] in / out
+    float* d_lprobs = nullptr;    // [lstm_cap][21]
+    int lstm_cap = 0;
+
     Workspace ws;
     int max_ctus = 131072;
     int last_n = 0;  // CTUs of the last pass (debug_fetch)
@@ -165,6 +174,11 @@ extern "C" void ethcnn_destroy(ethcnn_ctx* c) {
     free_workspace(c);
     free_staging(c);
     if (c->dw_arena) (void)hipFree(c->dw_arena);
+    {
+        void* lp[] = {c->d_lstm, c->d_vec, c->d_state[0], c->d_state[1], c->d_lprobs};
+        for (void* p : lp)
+            if (p) (void)hipFree(p);
+    }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->copy_in) (void)hipStreamDestroy(c->copy_in);
     if (c->copy_out) (void)hipStreamDestroy(c->copy_out);
@@ -658,6 +672,117 @@ extern "C" int ethcnn_resi_vectors(ethcnn_ctx* c, const uint8_t* luma, int w, in
     rc = ethcnn_resi_vectors_device(c, c->d_in[0], w, h, pitch, c->d_out[0]);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(vec, c->d_out[0], (size_t)nctu * kNVec * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ETHCNN_OK;
+}
+
+// ------------------------------------------------ config #5: ETH-LSTM one step -------
+static int upload_lstm(ethcnn_ctx* c) {
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->d_lstm) HIPCHK(c, hipMalloc((void**)&c->d_lstm, kLstmBlobFloats * sizeof(float)));
+    HIPCHK(c, hipMemcpyAsync(c->d_lstm, c->lstm_blob.data(), kLstmBlobFloats * sizeof(float), hipMemcpyHostToDevice,
+                             c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_lstm = true;
+    return ETHCNN_OK;
+}
+
+extern "C" int ethcnn_load_lstm_blob(ethcnn_ctx* c, const float* blob, size_t nfloats) {
+    if (!c || !blob) return ETHCNN_ERR_ARG;
+    if (nfloats != kLstmBlobFloats)
+        return set_err(c, ETHCNN_ERR_ARG, "LSTM blob must hold %zu floats, got %zu", kLstmBlobFloats, nfloats);
+    c->lstm_blob.assign(blob, blob + nfloats);
+    return upload_lstm(c);
+}
+
+extern "C" int ethcnn_load_lstm_synthetic(ethcnn_ctx* c, uint64_t seed, double head_gain) {
+    if (!c) return ETHCNN_ERR_ARG;
+    c->lstm_blob.resize(kLstmBlobFloats);
+    synth_lstm_blob(seed, head_gain, c->lstm_blob.data());
+    return upload_lstm(c);
+}
+
+extern "C" int ethcnn_load_lstm_checkpoint(ethcnn_ctx* c, const char* prefix) {
+    if (!c || !prefix) return ETHCNN_ERR_ARG;
+    std::vector<float> blob(kLstmBlobFloats);
+    char err[400];
+    const int rc = ckpt_load_table(prefix, kLstmTensors, kNumLstmTensors, blob.data(), err, sizeof err);
+    if (rc) return set_err(c, rc, "%s", err);
+    c->lstm_blob.swap(blob);
+    return upload_lstm(c);
+}
+
+extern "C" int ethcnn_get_lstm_blob(const ethcnn_ctx* c, float* out, size_t nfloats) {
+    if (!c || !out || nfloats != kLstmBlobFloats || !c->have_lstm) return ETHCNN_ERR_ARG;
+    std::memcpy(out, c->lstm_blob.data(), nfloats * 4);
+    return ETHCNN_OK;
+}
+
+static int ensure_lstm_buffers(ethcnn_ctx* c, int n) {
+    if (n <= c->lstm_cap) return ETHCNN_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    void* ptrs[] = {c->d_vec, c->d_state[0], c->d_state[1], c->d_lprobs};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    c->d_vec = c->d_state[0] = c->d_state[1] = c->d_lprobs = nullptr;
+    c->lstm_cap = 0;
+    const int cap = (n + 15) / 16 * 16;
+    HIPCHK(c, hipMalloc((void**)&c->d_vec, (size_t)cap * kNVec * 4));
+    HIPCHK(c, hipMalloc((void**)&c->d_state[0], (size_t)cap * 2 * kNVec * 4));
+    HIPCHK(c, hipMalloc((void**)&c->d_state[1], (size_t)cap * 2 * kNVec * 4));
+    HIPCHK(c, hipMalloc((void**)&c->d_lprobs, (size_t)cap * kNOut * 4));
+    c->lstm_cap = cap;
+    return ETHCNN_OK;
+}
+
+// lstm() x3 + heads + gates on resident vectors: the part of sess.run after resi_cnn
+extern "C" int ethcnn_lstm_step_device(ethcnn_ctx* c, const float* d_vec, const float* d_state_in, int n, int qp,
+                                       int i_frame, float* d_state_out, float* d_probs) {
+    if (!c || !d_vec || !d_state_out || !d_probs) return c ? set_err(c, ETHCNN_ERR_ARG, "null pointer") : ETHCNN_ERR_ARG;
+    if (n <= 0) return set_err(c, ETHCNN_ERR_ARG, "n must be positive");
+    if (!c->have_lstm) return set_err(c, ETHCNN_ERR_NOWEIGHTS, "no LSTM weights loaded");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int chunks = (n + kSubBatch - 1) / kSubBatch;
+    int rc = ensure_workspace(c, std::min(n, c->max_ctus), chunks);
+    if (rc) return rc;
+    if (n > c->ws.cap) return set_err(c, ETHCNN_ERR_ARG, "frame of %d CTUs exceeds max_ctus_per_pass", n);
+    HIPCHK(c, hipMemsetAsync(c->ws.flags, 0, (size_t)chunks * 2 * sizeof(int), c->stream));
+    {
+        StageTimer t(c, ETHCNN_STAGE_HEADS);
+        launch_lstm(d_vec, d_state_in, d_state_out, c->d_lstm, n, qp, i_frame, c->thr1, c->thr2, c->ws, d_probs, c->stream);
+    }
+    {
+        StageTimer t(c, ETHCNN_STAGE_GATE);
+        launch_gate(c->ws, n, n, 0, c->thr2, d_probs, c->stream);
+    }
+    HIPCHK(c, hipGetLastError());
+    c->last_n = n;
+    return ETHCNN_OK;
+}
+
+// predict_cu_depth() of resi_to_cu_depth_LDP.py:108-129 for one frame, host buffers
+extern "C" int ethcnn_ldp_predict_frame(ethcnn_ctx* c, const uint8_t* luma, int w, int h, ptrdiff_t pitch, int qp,
+                                        int i_frame, const float* state_in, float* state_out, float* probs) {
+    if (!c || !luma || !state_out || !probs) return c ? set_err(c, ETHCNN_ERR_ARG, "null pointer") : ETHCNN_ERR_ARG;
+    if (w <= 0 || h <= 0 || pitch < w) return set_err(c, ETHCNN_ERR_ARG, "bad geometry");
+    if (!c->have_weights) return set_err(c, ETHCNN_ERR_NOWEIGHTS, "no CNN weights loaded");
+    if (!c->have_lstm) return set_err(c, ETHCNN_ERR_NOWEIGHTS, "no LSTM weights loaded");
+    const int nctu = ((w + 63) / 64) * ((h + 63) / 64);
+    int rc = ensure_staging(c, (size_t)pitch * h, (size_t)nctu * kNVec * 4);
+    if (rc) return rc;
+    rc = ensure_lstm_buffers(c, nctu);
+    if (rc) return rc;
+    const size_t sbytes = (size_t)nctu * 2 * kNVec * 4;
+    HIPCHK(c, hipMemcpyAsync(c->d_in[0], luma, (size_t)pitch * h, hipMemcpyHostToDevice, c->stream));
+    if (state_in) HIPCHK(c, hipMemcpyAsync(c->d_state[0], state_in, sbytes, hipMemcpyHostToDevice, c->stream));
+    rc = ethcnn_resi_vectors_device(c, c->d_in[0], w, h, pitch, c->d_vec);
+    if (rc) return rc;
+    rc = ethcnn_lstm_step_device(c, c->d_vec, state_in ? c->d_state[0] : nullptr, nctu, qp, i_frame, c->d_state[1],
+                                 c->d_lprobs);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(state_out, c->d_state[1], sbytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(probs, c->d_lprobs, (size_t)nctu * kNOut * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return ETHCNN_OK;
 }

@@ -70,6 +70,17 @@ extern "C" int ethcnn_model_name_for_qp(int qp, char* out, size_t cap) {
     return ETHCNN_OK;
 }
 
+// resi_to_cu_depth_LDP.py:170-177 (LSTM file per QP band); the CNN file is fixed (:160)
+extern "C" int ethcnn_lstm_model_name_for_qp(int qp, char* out, size_t cap) {
+    const char* name = qp < 25 ? "model_LDP_200000_qp22.dat"
+                     : qp < 30 ? "model_LDP_200000_qp27.dat"
+                     : qp < 35 ? "model_LDP_200000_qp32.dat"
+                               : "model_LDP_200000_qp37.dat";
+    if (!out || cap <= std::strlen(name)) return ETHCNN_ERR_ARG;
+    std::strcpy(out, name);
+    return ETHCNN_OK;
+}
+
 extern "C" int ethcnn_parse_thresholds(const char* path, float* thr_l1_lower, float* thr_l2_lower) {
     if (!path || !thr_l1_lower || !thr_l2_lower) return ETHCNN_ERR_ARG;
     char err[400];

@@ -1,0 +1,209 @@
+// ethcnn_lstm.hip -- "next" row 1 of SURVEY.md 8f: ETH-LSTM one step + the LDP heads, i.e. what
+// sess.run fetches in predict_cu_depth() (HM-16.5_Test_LDP/bin/resi_to_cu_depth_LDP.py:114-129)
+// after resi_cnn: lstm() x3 and the gates of net() (net_CNN_LSTM_one_step.py:201-323).
+//   tf.contrib.rnn.LSTMCell(n, forget_bias=1.0, cell_clip=5.0), n = 64 / 128 / 256:
+//     z = [x, h_prev] . kernel + bias ;  i, j, f, o = split(z, 4)
+//     c = sigmoid(f + 1) * c_prev + sigmoid(i) * tanh(j) ;  c = clip(c, -5, 5) ;  h = sigmoid(o) * tanh(c)
+//   h2 = lrelu([h, efs] W2 + b2) ;  y = sigmoid([h2, efs] W3 + b3) ;  efs = [qp/51*0.18, onehot4(i_frame % 4)]
+//
+// gfx950, v_mfma_f32_16x16x4_f32, one wave = 16 CTUs, "transposed" (rows = gate / output units,
+// columns = CTUs) exactly like ethcnn_heads.hip: the four gate pre-activations of hidden unit u
+// land in the SAME lane and register slot (tiles u/16 of the i, j, f, o row ranges), so the cell
+// update is lane-local, and h_new in C layout is directly the B operand of fc2^T, whose output is
+// the B operand of fc3^T.  Canonical order: chains over the leading multiple-of-16 inputs in
+// k = 16c + 4g + e order, then the 5 efs columns, then the bias (oracle: oracle_lstm_step).
+// LDP calls this once per frame on a few hundred CTUs (lock-step with the encoder), so this first
+// version takes every weight operand straight from L2 (no LDS staging): latency-, not
+// throughput-oriented.
+#include <hip/hip_runtime.h>
+
+#include "ethcnn_kernels.h"
+
+namespace ethcnn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ float lrelu_l(float h) { return fmaxf(0.2f * h, h); }
+__device__ __forceinline__ float expf_l(float x) {  // the canonical exp of DESIGN.md
+    x = fminf(x, 80.0f);
+    x = fmaxf(x, -86.0f);
+    const float n = rintf(x * 1.44269504088896341f);
+    float r = fmaf(n, -0.693145751953125f, x);
+    r = fmaf(n, -1.42860682030941723212e-6f, r);
+    float p = 1.0f / 5040.0f;
+    p = fmaf(p, r, 1.0f / 720.0f);
+    p = fmaf(p, r, 1.0f / 120.0f);
+    p = fmaf(p, r, 1.0f / 24.0f);
+    p = fmaf(p, r, 1.0f / 6.0f);
+    p = fmaf(p, r, 0.5f);
+    p = fmaf(p, r, 1.0f);
+    p = fmaf(p, r, 1.0f);
+    return __int_as_float(__float_as_int(p) + (((int)n) << 23));
+}
+__device__ __forceinline__ float sigmoid_l(float z) { return 1.0f / (1.0f + expf_l(-z)); }
+__device__ __forceinline__ float tanh_l(float x) {
+    const float e = expf_l(2.0f * x);
+    return (e - 1.0f) / (e + 1.0f);
+}
+
+struct LstmParams {
+    const float* blob;  // the TF-V2 .data payload of model_LDP_200000_qpXX.dat, as stored
+    float efs[5];       // [qp/51*0.18, onehot4(i_frame % 4)]
+};
+
+// float offsets into the blob per level (64, 32, 16): fc2_b, fc2_w, fc3_b, fc3_w, bias, kernel
+__device__ __constant__ int kLstmOff[3][6] = {{723640, 723688, 727000, 727001, 727054, 727310},
+                                              {578784, 578880, 591648, 591652, 592056, 592568},
+                                              {0, 192, 50304, 50320, 53472, 54496}};
+
+template <int LV>
+__device__ __forceinline__ void lstm_level(const LstmParams& lp, const float* __restrict__ vrow,
+                                           const float* __restrict__ sin_row, float* __restrict__ sout_row, bool valid,
+                                           int ctu, int lane, float* __restrict__ raw, float* __restrict__ probs,
+                                           int* flag32, int* flag16, float thr1, float thr2) {
+    constexpr int N = (LV == 0) ? 64 : (LV == 1 ? 128 : 256);
+    constexpr int N2 = (LV == 0) ? 48 : (LV == 1 ? 96 : 192);
+    constexpr int N3 = (LV == 0) ? 1 : (LV == 1 ? 4 : 16);
+    constexpr int O1 = (LV == 0) ? 0 : (LV == 1 ? 64 : 192);
+    constexpr int O3 = (LV == 0) ? 0 : (LV == 1 ? 1 : 5);
+    constexpr int NT = N / 16, NT2 = N2 / 16;
+    const int col = lane & 15, g = lane >> 4;
+    const float* b2 = lp.blob + kLstmOff[LV][0];
+    const float* W2 = lp.blob + kLstmOff[LV][1];
+    const float* b3 = lp.blob + kLstmOff[LV][2];
+    const float* W3 = lp.blob + kLstmOff[LV][3];
+    const float* bk = lp.blob + kLstmOff[LV][4];
+    const float* K = lp.blob + kLstmOff[LV][5];
+
+    f32x4 hreg[NT];  // h_new, lane (ctu, g): units 16 t + 4 g + r
+#pragma unroll 1
+    for (int ub = 0; ub < N / 64; ++ub) {  // 64 hidden units (4 tiles) x 4 gates at a time
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) acc[q][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int kc = 0; kc < 2 * N / 16; ++kc) {  // [x, h_prev]: x first (array_ops.concat([inputs, m_prev], 1))
+            const float* src = (kc < N / 16) ? vrow + O1 + 16 * kc + 4 * g
+                                             : (sin_row ? sin_row + kNVec + O1 + 16 * (kc - N / 16) + 4 * g : nullptr);
+            const float4 bv = src ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float hv = (e == 0) ? bv.x : (e == 1) ? bv.y : (e == 2) ? bv.z : bv.w;
+                const float* krow = K + (size_t)(16 * kc + 4 * g + e) * (4 * N) + ub * 64 + col;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) acc[q][tt] = MFMA16(krow[q * N + 16 * tt], hv, acc[q][tt]);
+            }
+        }
+        // cell update, lane-local: units u = 64 ub + 16 tt + 4 g + r
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const int u0 = 64 * ub + 16 * tt + 4 * g;
+            const float4 cp = sin_row ? *reinterpret_cast<const float4*>(sin_row + O1 + u0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float cpv[4] = {cp.x, cp.y, cp.z, cp.w};
+            f32x4 cn, hn;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int u = u0 + r;
+                const float gi = acc[0][tt][r] + bk[u], gj = acc[1][tt][r] + bk[N + u];
+                const float gf = acc[2][tt][r] + bk[2 * N + u], go = acc[3][tt][r] + bk[3 * N + u];
+                float cc = sigmoid_l(gf + 1.0f) * cpv[r] + sigmoid_l(gi) * tanh_l(gj);
+                cc = fminf(fmaxf(cc, -5.0f), 5.0f);
+                cn[r] = cc;
+                hn[r] = sigmoid_l(go) * tanh_l(cc);
+            }
+            if (valid) {
+                *reinterpret_cast<f32x4*>(sout_row + O1 + u0) = cn;
+                *reinterpret_cast<f32x4*>(sout_row + kNVec + O1 + u0) = hn;
+            }
+            // static register index: ub is a runtime loop variable, so select by comparison
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                if (t == 4 * ub + tt) hreg[t] = hn;
+        }
+    }
+    // fc2^T: rows = h2 units, step (t, r) consumes k = 16 t + 4 g + r
+    f32x4 a2[NT2];
+#pragma unroll
+    for (int j = 0; j < NT2; ++j) a2[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float* wrow = W2 + (size_t)(16 * t + 4 * g + r) * N2 + col;
+#pragma unroll
+            for (int j = 0; j < NT2; ++j) a2[j] = MFMA16(wrow[16 * j], hreg[t][r], a2[j]);
+        }
+#pragma unroll
+    for (int j = 0; j < NT2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int idx = 16 * j + 4 * g + r;
+            float v = a2[j][r];
+#pragma unroll
+            for (int e = 0; e < 5; ++e) v = fmaf(lp.efs[e], W2[(N + e) * N2 + idx], v);
+            a2[j][r] = lrelu_l(v + b2[idx]);
+        }
+    // fc3^T
+    f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NT2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float w = (col < N3) ? W3[(16 * j + 4 * g + r) * N3 + col] : 0.0f;
+            z = MFMA16(w, a2[j][r], z);
+        }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int o = 4 * g + r;
+        if (o < N3 && valid) {
+            float zz = z[r];
+#pragma unroll
+            for (int e = 0; e < 5; ++e) zz = fmaf(lp.efs[e], W3[(N2 + e) * N3 + o], zz);
+            const float p = sigmoid_l(zz + b3[o]);
+            const size_t idx = (size_t)ctu * kNOut + O3 + o;
+            raw[idx] = p;
+            probs[idx] = p;
+            if (LV == 0 && p > thr1 && __hip_atomic_load(flag32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+                __hip_atomic_store(flag32, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (LV == 1 && p > thr2 && __hip_atomic_load(flag16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+                __hip_atomic_store(flag16, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// grid.y = level (64 / 32 / 16 run as independent waves); one wave per 16 CTUs
+__global__ __launch_bounds__(64) void k_lstm(const float* __restrict__ vec, const float* __restrict__ state_in,
+                                             float* __restrict__ state_out, LstmParams lp, int N, float thr1,
+                                             float thr2, float* __restrict__ raw, float* __restrict__ probs,
+                                             int* __restrict__ flags) {
+    const int lane = threadIdx.x;
+    const int col = lane & 15;
+    const int ctu_raw = blockIdx.x * 16 + col;
+    const bool valid = ctu_raw < N;
+    const int ctu = min(ctu_raw, N - 1);
+    const float* vrow = vec + (size_t)ctu * kNVec;
+    const float* sin_row = state_in ? state_in + (size_t)ctu * 2 * kNVec : nullptr;
+    float* sout_row = state_out + (size_t)ctu * 2 * kNVec;
+    int* fl = flags + 2 * (ctu / kSubBatch);  // one frame: mini-batches of 1024 in raster order
+    if (blockIdx.y == 0) lstm_level<0>(lp, vrow, sin_row, sout_row, valid, ctu, lane, raw, probs, fl, fl + 1, thr1, thr2);
+    else if (blockIdx.y == 1) lstm_level<1>(lp, vrow, sin_row, sout_row, valid, ctu, lane, raw, probs, fl, fl + 1, thr1, thr2);
+    else lstm_level<2>(lp, vrow, sin_row, sout_row, valid, ctu, lane, raw, probs, fl, fl + 1, thr1, thr2);
+}
+
+void launch_lstm(const float* d_vec, const float* d_state_in, float* d_state_out, const float* d_lstm_blob, int n, int qp,
+                 int i_frame, float thr1, float thr2, const Workspace& ws, float* d_probs, hipStream_t s) {
+    LstmParams lp;
+    lp.blob = d_lstm_blob;
+    lp.efs[0] = ((float)qp / 51.0f) * 0.18f;  // net():283  qp / 51.0 * 0.18
+    const int phase = ((i_frame % 4) + 4) % 4;
+    for (int e = 0; e < 4; ++e) lp.efs[1 + e] = (e == phase) ? 1.0f : 0.0f;
+    hipLaunchKernelGGL(k_lstm, dim3((n + 15) / 16, 3), dim3(64), 0, s, d_vec, d_state_in, d_state_out, lp, n, thr1, thr2,
+                       ws.raw, d_probs, ws.flags);
+}
+
+}  // namespace ethcnn

@@ -35,6 +35,10 @@ struct TensorDesc {
 };
 constexpr int kNumTensors = 36;
 extern const TensorDesc kTensors[kNumTensors];  // bundle (sorted-key) order
+// ETH-LSTM checkpoints (HM-16.5_Test_LDP/bin/model_LDP_200000_qp*.dat.index): 18 tensors
+constexpr int kNumLstmTensors = 18;
+extern const TensorDesc kLstmTensors[kNumLstmTensors];
+constexpr size_t kLstmBlobFloats = 760078;  // 3,040,312-byte .data payload
 
 // float offsets into the blob ------------------------------------------------------------
 // conv variables are unnamed: L = Variable.._5, M = _6.._11, S = _12.._17 (creation order,
@@ -89,12 +93,14 @@ void pack_trunk_fragments(const float* blob, float* w_out /*[3][84][64]*/, float
 void pack_fc1(const float* blob, float* w_out /*[2688][448]*/, float* b_out /*[448]*/);
 void pack_fc1_image(const float* w_cat /*[2688][448]*/, int bn, int bk, float* img_out /*[2688*448]*/);
 void synth_blob(uint64_t seed, double head_gain, float* blob_out /*[kBlobFloats]*/);
+void synth_lstm_blob(uint64_t seed, double head_gain, float* blob_out /*[kLstmBlobFloats]*/);
 
 // TF-V2 checkpoint bundle reader (tf_ckpt_v2.cpp).  Returns 0 or a negative ETHCNN_ERR_*;
 // on error `err` holds the message.
 using CkptEntry = ::ethcnn_ckpt_entry;
 int ckpt_read_index(const char* index_path, CkptEntry* entries, int cap, int* n_out, char* err, size_t errcap);
 int ckpt_load_blob(const char* prefix, float* blob_out /*[kBlobFloats]*/, char* err, size_t errcap);
+int ckpt_load_table(const char* prefix, const TensorDesc* table, int ntensors, float* blob_out, char* err, size_t errcap);
 uint32_t crc32c(const void* data, size_t n);
 uint32_t crc32c_mask(uint32_t crc);
 

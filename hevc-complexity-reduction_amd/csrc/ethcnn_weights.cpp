@@ -48,6 +48,27 @@ const TensorDesc kTensors[kNumTensors] = {
     {"y_conv_flat__64__w", 2, {49, 1, 0, 0}, 5152644},
 };
 
+const TensorDesc kLstmTensors[kNumLstmTensors] = {
+    {"RNN16/fc2/full_connect_b", 1, {192, 0, 0, 0}, 0},
+    {"RNN16/fc2/full_connect_w", 2, {261, 192, 0, 0}, 768},
+    {"RNN16/fc3/full_connect_b", 1, {16, 0, 0, 0}, 201216},
+    {"RNN16/fc3/full_connect_w", 2, {197, 16, 0, 0}, 201280},
+    {"RNN16/multi_rnn_cell/cell_0/lstm_cell/bias", 1, {1024, 0, 0, 0}, 213888},
+    {"RNN16/multi_rnn_cell/cell_0/lstm_cell/kernel", 2, {512, 1024, 0, 0}, 217984},
+    {"RNN32/fc2/full_connect_b", 1, {96, 0, 0, 0}, 2315136},
+    {"RNN32/fc2/full_connect_w", 2, {133, 96, 0, 0}, 2315520},
+    {"RNN32/fc3/full_connect_b", 1, {4, 0, 0, 0}, 2366592},
+    {"RNN32/fc3/full_connect_w", 2, {101, 4, 0, 0}, 2366608},
+    {"RNN32/multi_rnn_cell/cell_0/lstm_cell/bias", 1, {512, 0, 0, 0}, 2368224},
+    {"RNN32/multi_rnn_cell/cell_0/lstm_cell/kernel", 2, {256, 512, 0, 0}, 2370272},
+    {"RNN64/fc2/full_connect_b", 1, {48, 0, 0, 0}, 2894560},
+    {"RNN64/fc2/full_connect_w", 2, {69, 48, 0, 0}, 2894752},
+    {"RNN64/fc3/full_connect_b", 1, {1, 0, 0, 0}, 2908000},
+    {"RNN64/fc3/full_connect_w", 2, {53, 1, 0, 0}, 2908004},
+    {"RNN64/multi_rnn_cell/cell_0/lstm_cell/bias", 1, {256, 0, 0, 0}, 2908216},
+    {"RNN64/multi_rnn_cell/cell_0/lstm_cell/kernel", 2, {128, 256, 0, 0}, 2909240},
+};
+
 // ---------------------------------------------------------------- synthetic weights ---
 // The trained blobs are absent from the reference (.MISSING_LARGE_BLOBS); every test and
 // benchmark runs on this seeded generator (same function in oracle/ethcnn_np.py::synth_blob
@@ -73,6 +94,27 @@ void synth_blob(uint64_t seed, double head_gain, float* blob) {
             scale = std::sqrt(3.0 / fan_in);
             if (std::strncmp(d.name, "h_fc2", 5) == 0 || std::strncmp(d.name, "y_conv", 6) == 0)
                 scale = scale * head_gain;
+        }
+        float* out = blob + d.offset_bytes / 4;
+        for (size_t i = 0; i < n; ++i) {
+            const uint64_t h = splitmix64(key + (uint64_t)i);
+            const double u = (double)(h >> 40);
+            const double val = (u + 0.5) * (1.0 / 8388608.0) - 1.0;
+            out[i] = (float)(val * scale);
+        }
+    }
+}
+
+// same generator for the LSTM table, tensor index t + 100 (oracle/ethcnn_lstm_np.py::synth_lstm_blob)
+void synth_lstm_blob(uint64_t seed, double head_gain, float* blob) {
+    for (int t = 0; t < kNumLstmTensors; ++t) {
+        const TensorDesc& d = kLstmTensors[t];
+        const size_t n = d.count();
+        const uint64_t key = splitmix64(seed ^ (0xD6E8FEB86659FD93ull * (uint64_t)(t + 101)));
+        double scale = 0.1;
+        if (d.rank == 2) {
+            scale = std::sqrt(3.0 / (double)d.shape[0]);
+            if (std::strstr(d.name, "/fc") != nullptr) scale = scale * head_gain;
         }
         float* out = blob + d.offset_bytes / 4;
         for (size_t i = 0; i < n; ++i) {

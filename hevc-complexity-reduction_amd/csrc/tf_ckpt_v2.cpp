@@ -232,6 +232,10 @@ int ckpt_read_index(const char* index_path, CkptEntry* entries, int cap, int* n_
 }
 
 int ckpt_load_blob(const char* prefix, float* blob, char* err, size_t errcap) {
+    return ckpt_load_table(prefix, kTensors, kNumTensors, blob, err, errcap);
+}
+
+int ckpt_load_table(const char* prefix, const TensorDesc* table, int ntensors, float* blob, char* err, size_t errcap) {
     CkptEntry ent[128];
     int n = 0;
     const std::string idx = std::string(prefix) + ".index";
@@ -240,8 +244,8 @@ int ckpt_load_blob(const char* prefix, float* blob, char* err, size_t errcap) {
     std::vector<uint8_t> data;
     const std::string dpath = std::string(prefix) + ".data-00000-of-00001";
     if (!read_file(dpath, data)) return fail(err, errcap, ETHCNN_ERR_IO, "cannot read " + dpath);
-    for (int t = 0; t < kNumTensors; ++t) {
-        const TensorDesc& d = kTensors[t];
+    for (int t = 0; t < ntensors; ++t) {
+        const TensorDesc& d = table[t];
         const CkptEntry* e = nullptr;
         for (int i = 0; i < n; ++i)
             if (std::strcmp(ent[i].name, d.name) == 0) e = &ent[i];
@@ -272,4 +276,8 @@ extern "C" uint32_t ethcnn_crc32c_masked(const void* data, size_t n) {
 extern "C" int ethcnn_ckpt_read_blob(const char* prefix, float* blob_out, size_t nfloats, char* err, size_t errcap) {
     if (!prefix || !blob_out || nfloats != ethcnn::kBlobFloats) return ETHCNN_ERR_ARG;
     return ethcnn::ckpt_load_blob(prefix, blob_out, err, errcap);
+}
+extern "C" int ethcnn_ckpt_read_lstm_blob(const char* prefix, float* blob_out, size_t nfloats, char* err, size_t errcap) {
+    if (!prefix || !blob_out || nfloats != ethcnn::kLstmBlobFloats) return ETHCNN_ERR_ARG;
+    return ethcnn::ckpt_load_table(prefix, ethcnn::kLstmTensors, ethcnn::kNumLstmTensors, blob_out, err, errcap);
 }

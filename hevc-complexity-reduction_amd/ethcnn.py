@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libethcnn.so")
 
 NOUT, NFEAT, NVEC, NFC2, SUB_BATCH = 21, 2688, 448, 336, 1024
 BLOB_FLOATS = 1288210
+LSTM_BLOB_FLOATS = 760078
 
 STAGES = ("tile", "trunk", "fc1", "heads", "gate")
 DBG_FEATURES, DBG_FC1, DBG_FC2, DBG_LOGITS, DBG_RAW_PROBS = range(5)
@@ -64,6 +65,14 @@ SIGNATURES = {
     "ethcnn_ckpt_read_blob": (_i, [_cp, _fp, _sz, ctypes.c_char_p, _sz]),
     "ethcnn_resi_vectors_device":(_i, [_vp, _vp, _i, _i, _pd, _vp]),
     "ethcnn_resi_vectors": (_i, [_vp, _vp, _i, _i, _pd, _fp]),
+    "ethcnn_load_lstm_checkpoint": (_i, [_vp, _cp]),
+    "ethcnn_load_lstm_blob": (_i, [_vp, _fp, _sz]),
+    "ethcnn_load_lstm_synthetic": (_i, [_vp, ctypes.c_uint64, ctypes.c_double]),
+    "ethcnn_get_lstm_blob": (_i, [_vp, _fp, _sz]),
+    "ethcnn_lstm_model_name_for_qp": (_i, [_i, ctypes.c_char_p, _sz]),
+    "ethcnn_lstm_step_device": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ethcnn_ldp_predict_frame": (_i, [_vp, _vp, _i, _i, _pd, _i, _i, _vp, _fp, _fp]),
+    "ethcnn_ckpt_read_lstm_blob": (_i, [_cp, _fp, _sz, ctypes.c_char_p, _sz]),
     "ethcnn_device_alloc": (_i, [_vp, _sz, ctypes.POINTER(_vp)]),
     "ethcnn_device_free": (_i, [_vp, _vp]),
     "ethcnn_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz]),
@@ -126,6 +135,24 @@ def read_ckpt_index(index_path):
         raise EthCnnError(rc, err.value.decode("utf-8", "replace"))
     return [(e.name.decode(), e.dtype, tuple(e.shape[i] for i in range(e.rank)), e.shard, e.offset, e.size, e.crc32c)
             for e in ents[: n.value]]
+
+
+def lstm_model_name_for_qp(qp):
+    buf = ctypes.create_string_buffer(64)
+    rc = load_library().ethcnn_lstm_model_name_for_qp(int(qp), buf, 64)
+    if rc:
+        raise EthCnnError(rc, "lstm_model_name_for_qp")
+    return buf.value.decode()
+
+
+def read_ckpt_lstm_blob(prefix):
+    """ETH-LSTM TF-V2 bundle -> float32[LSTM_BLOB_FLOATS] in checkpoint layout (crc32c-checked, host only)."""
+    out = np.empty(LSTM_BLOB_FLOATS, dtype=np.float32)
+    err = ctypes.create_string_buffer(400)
+    rc = load_library().ethcnn_ckpt_read_lstm_blob(os.fsencode(prefix), out.ctypes.data_as(_fp), out.size, err, 400)
+    if rc:
+        raise EthCnnError(rc, err.value.decode("utf-8", "replace"))
+    return out
 
 
 def read_ckpt_blob(prefix):
@@ -294,6 +321,58 @@ class EthCnn(object):
         out = np.empty((ctus_per_frame(width, height), NVEC), dtype=np.float32)
         self._chk(self.lib.ethcnn_resi_vectors(self.h, luma.ctypes.data, width, height, pitch, out.ctypes.data_as(_fp)))
         return out
+
+    # -- config #5 back-end: ETH-LSTM one step (resi_to_cu_depth_LDP.py:108-129)
+    def load_lstm_checkpoint(self, prefix):
+        self._chk(self.lib.ethcnn_load_lstm_checkpoint(self.h, os.fsencode(prefix)))
+
+    def load_lstm_blob(self, blob):
+        blob = np.ascontiguousarray(blob, dtype=np.float32)
+        self._chk(self.lib.ethcnn_load_lstm_blob(self.h, blob.ctypes.data_as(_fp), blob.size))
+
+    def load_lstm_synthetic(self, seed=1, head_gain=1.0):
+        self._chk(self.lib.ethcnn_load_lstm_synthetic(self.h, int(seed), float(head_gain)))
+
+    def get_lstm_blob(self):
+        out = np.empty(LSTM_BLOB_FLOATS, dtype=np.float32)
+        self._chk(self.lib.ethcnn_get_lstm_blob(self.h, out.ctypes.data_as(_fp), out.size))
+        return out
+
+    def lstm_step(self, vec, state_in, qp, i_frame):
+        """vec [n,448], state_in [n,2,448] or None -> (probs [n,21] gated, state_out [n,2,448]); the
+        vectors go through HBM buffers and the *_device entry point."""
+        vec = np.ascontiguousarray(vec, dtype=np.float32)
+        n = vec.shape[0]
+        dv, dso, dp = self.alloc(vec.nbytes), self.alloc(n * 2 * NVEC * 4), self.alloc(n * NOUT * 4)
+        dv.upload(vec)
+        dsi = None
+        if state_in is not None:
+            state_in = np.ascontiguousarray(state_in, dtype=np.float32).reshape(n, 2, NVEC)
+            dsi = self.alloc(state_in.nbytes)
+            dsi.upload(state_in)
+        self._chk(self.lib.ethcnn_lstm_step_device(self.h, dv.ptr, dsi.ptr if dsi else None, n, int(qp), int(i_frame),
+                                                   dso.ptr, dp.ptr))
+        probs = dp.download(np.float32, n * NOUT).reshape(n, NOUT)
+        state = dso.download(np.float32, n * 2 * NVEC).reshape(n, 2, NVEC)
+        for b in (dv, dso, dp, dsi):
+            if b is not None:
+                b.free()
+        return probs, state
+
+    def ldp_predict_frame(self, luma, width, height, qp, i_frame, state_in=None, pitch=None):
+        """one frame of resi.yuv luma -> (probs [nctu,21], state_out [nctu,2,448])"""
+        luma = np.ascontiguousarray(luma, dtype=np.uint8)
+        pitch = width if pitch is None else pitch
+        n = ctus_per_frame(width, height)
+        probs = np.empty((n, NOUT), dtype=np.float32)
+        state = np.empty((n, 2, NVEC), dtype=np.float32)
+        sin = None
+        if state_in is not None:
+            sin = np.ascontiguousarray(state_in, dtype=np.float32).reshape(n, 2, NVEC)
+        self._chk(self.lib.ethcnn_ldp_predict_frame(self.h, luma.ctypes.data, width, height, pitch, int(qp), int(i_frame),
+                                                    sin.ctypes.data if sin is not None else None,
+                                                    state.ctypes.data_as(_fp), probs.ctypes.data_as(_fp)))
+        return probs, state
 
     # -- measurement / introspection
     def set_profiling(self, level=2):

@@ -110,6 +110,27 @@ int ethcnn_resi_vectors_device(ethcnn_ctx* ctx, const uint8_t* d_luma, int width
 int ethcnn_resi_vectors(ethcnn_ctx* ctx, const uint8_t* luma, int width, int height,
                         ptrdiff_t pitch, float* vec);
 
+/* ---- config #5 back-end ("next" row 1): one ETH-LSTM step + heads + gates per frame =
+ *      what predict_cu_depth() fetches from sess.run (HM-16.5_Test_LDP/bin/
+ *      resi_to_cu_depth_LDP.py:108-129; graph: net_CNN_LSTM_one_step.py:201-323).
+ *      CNN weights: ethcnn_load_checkpoint("model_LDP_2000000_qp22~37.dat") (same 36-tensor
+ *      table; only conv + FC1 are used).  LSTM weights: the 18-tensor bundle
+ *      model_LDP_200000_qp{22,27,32,37}.dat, reloaded when the QP band changes (:166-179).
+ *      state: float32 [nctu][2][448] = (c, h) per CTU, the layout of state.dat (:103-106,131-137);
+ *      state_in NULL = zeros (i_frame <= 1).  efs = [qp/51*0.18, onehot4(i_frame % 4)].
+ *      Gates are per 1024-CTU mini-batch of the frame (:118). */
+#define ETHCNN_LSTM_BLOB_FLOATS 760078 /* 3,040,312-byte TF-V2 .data payload, fp32 */
+int ethcnn_load_lstm_checkpoint(ethcnn_ctx* ctx, const char* prefix);
+int ethcnn_load_lstm_blob(ethcnn_ctx* ctx, const float* blob, size_t nfloats);
+int ethcnn_load_lstm_synthetic(ethcnn_ctx* ctx, uint64_t seed, double head_gain);
+int ethcnn_get_lstm_blob(const ethcnn_ctx* ctx, float* blob_out, size_t nfloats);
+int ethcnn_lstm_model_name_for_qp(int qp, char* out, size_t cap);
+int ethcnn_lstm_step_device(ethcnn_ctx* ctx, const float* d_vec, const float* d_state_in /* may be NULL */,
+                            int nctu, int qp, int i_frame, float* d_state_out, float* d_probs);
+int ethcnn_ldp_predict_frame(ethcnn_ctx* ctx, const uint8_t* luma, int width, int height, ptrdiff_t pitch,
+                             int qp, int i_frame, const float* state_in /* may be NULL */, float* state_out,
+                             float* probs); /* host pointers; synchronous */
+
 /* ---- device plumbing for callers without a HIP binding (ctypes, cgo, JNI ...) */
 int ethcnn_device_alloc(ethcnn_ctx* ctx, size_t bytes, void** out);
 int ethcnn_device_free(ethcnn_ctx* ctx, void* p);
@@ -164,6 +185,7 @@ int ethcnn_ckpt_read_index(const char* index_path, ethcnn_ckpt_entry* entries, i
 uint32_t ethcnn_crc32c_masked(const void* data, size_t nbytes);
 /* <prefix>.index + <prefix>.data-00000-of-00001 -> blob (crc-checked); no context / device needed */
 int ethcnn_ckpt_read_blob(const char* prefix, float* blob_out, size_t nfloats, char* err, size_t errcap);
+int ethcnn_ckpt_read_lstm_blob(const char* prefix, float* blob_out, size_t nfloats, char* err, size_t errcap);
 
 #ifdef __cplusplus
 }

@@ -429,3 +429,103 @@ int oracle_resi_vectors(const float* blob, const uint8_t* luma, int w, int h, lo
     free(ctus);
     return 0;
 }
+
+/* ======================================================================================
+ * "next" row 1: ETH-LSTM one step + LDP heads, config #5 completed.
+ * Follows /root/reference/HM-16.5_Test_LDP/bin/net_CNN_LSTM_one_step.py:201-323 (lstm(), net())
+ * as fed by resi_to_cu_depth_LDP.py:114-129 (predict_cu_depth: efs = [qp, i_frame % 4],
+ * 1024-CTU mini-batches).  tf.contrib.rnn.LSTMCell(n, forget_bias=1.0, cell_clip=5.0), no
+ * peepholes / projection (TF 1.x rnn_cell_impl.LSTMCell.call):
+ *     z = [x, h_prev] . kernel + bias ;  i, j, f, o = split(z, 4)
+ *     c = sigmoid(f + forget_bias) * c_prev + sigmoid(i) * tanh(j) ;  c = clip(c, -5, 5)
+ *     h = sigmoid(o) * tanh(c)
+ * then  h2 = lrelu([h, efs] W2 + b2),  y = sigmoid([h2, efs] W3 + b3),  efs = [qp/51*0.18,
+ * onehot4(i_frame % 4)], and the same batch gates as the AI net.  The LSTM checkpoints'
+ * .data blobs ARE in the reference (model_LDP_200000_qp{22,27,32,37}.dat, 3,040,312 B): layout
+ * below = their .index.  Parity is still unpinned (no TensorFlow to run the cell), see header.
+ * Canonical order: every matmul chain in the fc_k order over its leading (multiple-of-16)
+ * inputs, then the 5 efs columns in order, then + bias.
+ */
+#define LSTM_BLOB_FLOATS (3040312 / 4)
+/* per level (64, 32, 16 -> hidden 64, 128, 256): float offsets of fc2_b, fc2_w, fc3_b, fc3_w, bias, kernel */
+static const int LOFF[3][6] = {{723640, 723688, 727000, 727001, 727054, 727310},
+                               {578784, 578880, 591648, 591652, 592056, 592568},
+                               {0, 192, 50304, 50320, 53472, 54496}};
+int oracle_lstm_blob_floats(void) { return LSTM_BLOB_FLOATS; }
+
+static inline float tanhf_c(float x) {
+    const float e = oracle_expf(2.0f * x);
+    return (e - 1.0f) / (e + 1.0f);
+}
+
+static void ctu_lstm(const float* lb, const float* vec, const float* st_in, float qpn, int phase, int mode,
+                     float* probs, float* st_out) {
+    float efs[5] = {qpn, 0.0f, 0.0f, 0.0f, 0.0f};
+    efs[1 + phase] = 1.0f; /* tf.one_hot(i_frame % 4, depth 4) */
+    int o1 = 0, o3 = 0;
+    for (int lv = 0; lv < 3; ++lv) {
+        const int n = N1[lv], n2 = N2[lv], n3 = N3[lv];
+        const float* b2 = lb + LOFF[lv][0];
+        const float* W2 = lb + LOFF[lv][1];
+        const float* b3 = lb + LOFF[lv][2];
+        const float* W3 = lb + LOFF[lv][3];
+        const float* bk = lb + LOFF[lv][4];
+        const float* K = lb + LOFF[lv][5];
+        const float* x = vec + o1;
+        const float* cp = st_in + o1;            /* state[...,0,:] = c */
+        const float* hp = st_in + NH1 + o1;      /* state[...,1,:] = h */
+        float z[1024], c[256], h[256];
+        for (int j = 0; j < 4 * n; ++j) z[j] = 0.0f;
+        for (int t = 0; t < 2 * n; ++t) {
+            const int k = fc_k(t, mode);
+            const float in = (k < n) ? x[k] : hp[k - n];
+            const float* w = K + (size_t)k * 4 * n;
+            for (int j = 0; j < 4 * n; ++j) z[j] = fmaf(in, w[j], z[j]);
+        }
+        for (int j = 0; j < 4 * n; ++j) z[j] += bk[j];
+        for (int u = 0; u < n; ++u) {
+            const float gi = z[u], gj = z[n + u], gf = z[2 * n + u], go = z[3 * n + u];
+            float cc = sigmoidf(gf + 1.0f) * cp[u] + sigmoidf(gi) * tanhf_c(gj);
+            cc = fminf(fmaxf(cc, -5.0f), 5.0f);
+            c[u] = cc;
+            h[u] = sigmoidf(go) * tanhf_c(cc);
+        }
+        memcpy(st_out + o1, c, n * sizeof(float));
+        memcpy(st_out + NH1 + o1, h, n * sizeof(float));
+        float acc[192], h2[192], zz[16];
+        for (int j = 0; j < n2; ++j) acc[j] = 0.0f;
+        for (int t = 0; t < n; ++t) {
+            const int k = fc_k(t, mode);
+            for (int j = 0; j < n2; ++j) acc[j] = fmaf(h[k], W2[k * n2 + j], acc[j]);
+        }
+        for (int e = 0; e < 5; ++e)
+            for (int j = 0; j < n2; ++j) acc[j] = fmaf(efs[e], W2[(n + e) * n2 + j], acc[j]);
+        for (int j = 0; j < n2; ++j) h2[j] = lrelu(acc[j] + b2[j]);
+        for (int j = 0; j < n3; ++j) zz[j] = 0.0f;
+        for (int t = 0; t < n2; ++t) {
+            const int k = fc_k(t, mode);
+            for (int j = 0; j < n3; ++j) zz[j] = fmaf(h2[k], W3[k * n3 + j], zz[j]);
+        }
+        for (int e = 0; e < 5; ++e)
+            for (int j = 0; j < n3; ++j) zz[j] = fmaf(efs[e], W3[(n2 + e) * n3 + j], zz[j]);
+        for (int j = 0; j < n3; ++j) probs[o3 + j] = sigmoidf(zz[j] + b3[j]);
+        o1 += n;
+        o3 += n3;
+    }
+}
+
+/* vec [n][448] (resi_cnn output), state_in/out [n][2][448] (c then h; state_in NULL = zeros, as for
+ * i_frame <= 1, resi_to_cu_depth_LDP.py:103-112), probs [n][21] with the gates per <=1024 mini-batch. */
+int oracle_lstm_step(const float* lstm_blob, const float* vec, const float* state_in, int n, int qp, int i_frame,
+                     float thr1, float thr2, int mode, float* probs, float* state_out) {
+    const float qpn = ((float)qp / 51.0f) * 0.18f; /* net():283 qp / 51.0 * 0.18 */
+    const int phase = ((i_frame % 4) + 4) % 4;
+    float* zeros = (float*)calloc((size_t)2 * NH1, sizeof(float));
+    if (!zeros) return -1;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int i = 0; i < n; ++i)
+        ctu_lstm(lstm_blob, vec + (size_t)i * NH1, state_in ? state_in + (size_t)i * 2 * NH1 : zeros, qpn, phase, mode,
+                 probs + (size_t)i * NOUT, state_out + (size_t)i * 2 * NH1);
+    free(zeros);
+    return oracle_gates(probs, n, 1024, thr1, thr2);
+}

@@ -1,0 +1,155 @@
+"""-m gpu: ETH-LSTM one step + LDP heads (k_lstm, through the C ABI) against oracle_lstm_step
+(canonical mode): probabilities, gates and the (c, h) state bit-exact; <= 1e-4 against the
+float64 restatement; on synthetic weights and on the reference's trained qp32 LSTM weights."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+REAL = os.path.join(GOLDEN, "model_LDP_200000_qp32.dat")
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _inputs(rng, n, scale=1.0):
+    vec = (np.abs(rng.standard_normal((n, 448))) * scale).astype(np.float32)
+    vec[:, ::7] *= -0.2
+    state = np.stack([rng.uniform(-5, 5, (n, 448)), rng.uniform(-1, 1, (n, 448))], 1).astype(np.float32)
+    return vec, state
+
+
+@pytest.fixture(scope="module")
+def lstm(oracle):
+    import ethcnn_lstm_np
+    return ethcnn_lstm_np
+
+
+@pytest.mark.parametrize("n,gain,qp,i_frame,with_state", [(1, 1.0, 32, 1, False), (16, 2.0, 22, 2, True),
+                                                          (45, 4.0, 27, 7, True), (510, 2.0, 37, 4, True),
+                                                          (1064, 6.0, 32, 9, True)])
+def test_lstm_step_bit_exact(ctx, lstm, n, gain, qp, i_frame, with_state):
+    rng = np.random.default_rng(n)
+    blob = lstm.synth_lstm_blob(3, gain)
+    ctx.load_lstm_blob(blob)
+    ctx.set_thresholds(0.5, 0.5)
+    vec, state = _inputs(rng, n)
+    sin = state if with_state else None
+    got_p, got_s = ctx.lstm_step(vec, sin, qp, i_frame)
+    want_p, want_s = lstm.lstm_step(blob, vec, sin, qp, i_frame, 0.5, 0.5, mode=0)
+    assert np.array_equal(_bits(got_s), _bits(want_s)), "state: max |d| = %g" % np.abs(got_s - want_s).max()
+    assert np.array_equal(_bits(got_p), _bits(want_p)), "probs: max |d| = %g" % np.abs(got_p - want_p).max()
+    ctx.set_thresholds(-1.0, -1.0)  # gates open: raw probabilities against float64
+    raw_p, _ = ctx.lstm_step(vec, sin, qp, i_frame)
+    rP, rS = lstm.lstm_forward64(blob, vec, sin, qp, i_frame)
+    assert np.abs(raw_p - rP).max() <= 1e-4 and np.abs(got_s - rS).max() <= 1e-4
+    ctx.set_thresholds(0.5, 0.5)
+
+
+def test_lstm_synthetic_generator_matches(ctx, lstm):
+    ctx.load_lstm_synthetic(17, 3.0)
+    assert np.array_equal(_bits(ctx.get_lstm_blob()), _bits(lstm.synth_lstm_blob(17, 3.0)))
+
+
+def test_lstm_trained_weights_recurrence(ctx, lstm):
+    """the reference's own trained LSTM checkpoint, loaded through the bundle reader; 6 recurrent
+    steps, each bit-exact against the oracle fed the same state"""
+    ctx.load_lstm_checkpoint(REAL)
+    blob = ctx.get_lstm_blob()
+    ctx.set_thresholds(0.5, 0.5)
+    rng = np.random.default_rng(1)
+    n = 135
+    g_state = o_state = None
+    for i_frame in range(1, 7):
+        vec, _ = _inputs(rng, n, 0.5)
+        gp, g_state = ctx.lstm_step(vec, g_state, 32, i_frame)
+        op, o_state = lstm.lstm_step(blob, vec, o_state, 32, i_frame, 0.5, 0.5, mode=0)
+        assert np.array_equal(_bits(gp), _bits(op)) and np.array_equal(_bits(g_state), _bits(o_state)), i_frame
+    assert gp[:, 0].min() > 0.0 and gp.max() < 1.0
+
+
+@pytest.mark.parametrize("w,h", [(416, 240), (200, 136), (1920, 1080)])
+def test_ldp_predict_frame(ctx, oracle, lstm, w, h):
+    """the whole per-frame call: residual luma -> resi_cnn -> LSTM step -> heads -> gates"""
+    rng = np.random.default_rng(w)
+    cblob = oracle.synth_blob(21, 1.0)
+    lblob = lstm.synth_lstm_blob(22, 3.0)
+    ctx.load_blob(cblob)
+    ctx.load_lstm_blob(lblob)
+    ctx.set_thresholds(0.5, 0.5)
+    g_state = o_state = None
+    for i_frame in (1, 2, 3):
+        luma = rng.integers(0, 256, size=(h, w), dtype=np.uint8)
+        gp, g_state = ctx.ldp_predict_frame(luma, w, h, 32, i_frame, g_state)
+        vec = oracle.resi_vectors(cblob, luma, w, h)
+        op, o_state = lstm.lstm_step(lblob, vec.reshape(-1, 448), o_state, 32, i_frame, 0.5, 0.5, mode=0)
+        assert np.array_equal(_bits(gp), _bits(op)) and np.array_equal(_bits(g_state), _bits(o_state)), i_frame
+
+
+def test_lstm_errors(pkg, oracle):
+    e = pkg.ethcnn
+    c = pkg.EthCnn(device=0)
+    try:
+        with pytest.raises(e.EthCnnError) as ei:
+            c.lstm_step(np.zeros((4, 448), np.float32), None, 32, 1)
+        assert ei.value.code == -5  # ETHCNN_ERR_NOWEIGHTS
+        with pytest.raises(e.EthCnnError):
+            c.load_lstm_blob(np.zeros(100, np.float32))
+        c.load_lstm_synthetic(1, 1.0)
+        with pytest.raises(e.EthCnnError) as ei:  # LSTM present, CNN absent
+            c.ldp_predict_frame(np.zeros((64, 64), np.uint8), 64, 64, 32, 1)
+        assert ei.value.code == -5
+    finally:
+        c.close()
+
+
+def test_ldp_daemon_handshake(pkg, oracle, lstm, tmp_path, monkeypatch):
+    """The file handshake of TEncGOP.cpp:1463-1503 played from the test as "HM": resi.yuv +
+    command.dat + pred_start.sig -> wait pred_end.sig -> cu_depth.dat; 3 frames with the
+    reference's trained LSTM weights (QP 32 band) and seeded CNN weights; every frame
+    bit-exact against the oracle chain; state.dat carries the recurrence."""
+    import shutil
+    import threading
+    import time
+    d = pkg.resi_to_cu_depth_LDP
+    w, h, qp = 416, 240, 32
+    for ext in (".index", ".data-00000-of-00001"):
+        shutil.copy(REAL + ext, tmp_path / ("model_LDP_200000_qp32.dat" + ext))
+    (tmp_path / "Thr_info.txt").write_text("0.4 0.6 0.3 0.7 0.2 0.8")
+    monkeypatch.setenv("ETHCNN_SYNTHETIC_SEED", "21")
+    result = {}
+    th = threading.Thread(target=lambda: result.setdefault("n", d.serve(str(tmp_path), max_frames=3, idle_timeout=60.0,
+                                                                       verbose=False)))
+    th.start()
+    cblob = oracle.synth_blob(21, 1.0)
+    lblob = np.fromfile(REAL + ".data-00000-of-00001", dtype=np.float32)
+    rng = np.random.default_rng(8)
+    n = ((w + 63) // 64) * ((h + 63) // 64)
+    o_state = None
+    try:
+        for poc in (1, 2, 3):
+            luma = rng.integers(96, 160, size=(h, w), dtype=np.uint8)  # residual + 128, roughly
+            with open(tmp_path / "resi.yuv", "wb") as f:
+                f.write(luma.tobytes())
+                f.write(bytes(w * h // 2))
+            (tmp_path / "command.dat").write_text("%d %d %d %d [end]" % (poc, w, h, qp))
+            open(tmp_path / "pred_start.sig", "w").close()
+            t0 = time.time()
+            while not (tmp_path / "pred_end.sig").exists():
+                assert time.time() - t0 < 60 and th.is_alive(), "daemon did not answer"
+                time.sleep(0.001)
+            os.remove(tmp_path / "pred_end.sig")
+            assert not (tmp_path / "pred_start.sig").exists()
+            got = np.fromfile(tmp_path / "cu_depth.dat", dtype=np.float32).reshape(n, 21)
+            vec = oracle.resi_vectors(cblob, luma, w, h)
+            want, o_state = lstm.lstm_step(lblob, vec, o_state, qp, poc, 0.6, 0.7, mode=0)
+            assert np.array_equal(_bits(got), _bits(want)), poc
+            st = np.fromfile(tmp_path / "state.dat", dtype=np.float32).reshape(n, 2, 448)
+            assert np.array_equal(_bits(st), _bits(o_state)), poc
+    finally:
+        th.join(timeout=90)
+    assert result.get("n") == 3

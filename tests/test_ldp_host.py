@@ -1,0 +1,48 @@
+"""CPU: host logic of the LDP daemon mirror (no GPU): command parsing, state file handling,
+output layout -- the parts of resi_to_cu_depth_LDP.py that are not numerics."""
+import numpy as np
+import pytest
+
+
+def test_get_command(pkg, tmp_path):
+    d = pkg.resi_to_cu_depth_LDP
+    f = tmp_path / "command.dat"
+    f.write_text("7 416 240 32 [end]")  # TEncGOP.cpp:1474-1480 "%d %d %d %d [end]"
+    assert d.get_command(str(f)) == (7, 416, 240, 32)
+    f.write_text("7 416 240 32")        # still being written
+    assert d.get_command(str(f)) == (-1, -1, -1, -1)
+    f.write_text("")
+    assert d.get_command(str(f)) == (-1, -1, -1, -1)
+    assert d.get_command(str(tmp_path / "missing.dat")) == (-1, -1, -1, -1)
+
+
+def test_images_and_state_files(pkg, tmp_path):
+    d = pkg.resi_to_cu_depth_LDP
+    w, h = 200, 136
+    rng = np.random.default_rng(0)
+    luma = rng.integers(0, 256, size=(h, w), dtype=np.uint8)
+    y = tmp_path / "resi.yuv"
+    y.write_bytes(luma.tobytes() + bytes(w * h // 2))
+    got, nv = d.get_images_from_one_file(str(y), w, h, 64)
+    assert nv == 4 * 3 and np.array_equal(got, luma)
+    y.write_bytes(luma.tobytes()[:100])
+    with pytest.raises(IOError):
+        d.get_images_from_one_file(str(y), w, h, 64)
+    s = tmp_path / "state.dat"
+    assert d.get_state_in_from_one_file(str(s), nv, 0) is None
+    assert d.get_state_in_from_one_file(str(s), nv, 1) is None  # zeros for i_frame <= 1 (:103-112)
+    st = rng.standard_normal((nv, 1, 2, 448)).astype(np.float32)
+    depth = rng.random((nv, 21)).astype(np.float32)
+    d.save_cu_depth_and_state(depth, st, str(tmp_path / "cu_depth.dat"), str(s), str(tmp_path / "pred_end.sig"), nv)
+    assert (tmp_path / "pred_end.sig").exists() and (tmp_path / "pred_end.sig").stat().st_size == 0
+    assert np.array_equal(np.fromfile(tmp_path / "cu_depth.dat", dtype=np.float32).reshape(nv, 21), depth)
+    back = d.get_state_in_from_one_file(str(s), nv, 2)
+    assert back.shape == (nv, 1, 2, 448) and np.array_equal(back, st)
+    with pytest.raises(IOError):
+        d.get_state_in_from_one_file(str(s), nv + 1, 2)  # stale state.dat of another resolution
+
+
+def test_constants(pkg):
+    d = pkg.resi_to_cu_depth_LDP
+    assert (d.VECTOR_LENGTH, d.LSTM_DEPTH, d.MINI_BATCH_SIZE, d.NUM_EXT_FEATURES) == (448, 1, 1024, 2)
+    assert d.MODEL_CNN_FILE == "model_LDP_2000000_qp22~37.dat"
