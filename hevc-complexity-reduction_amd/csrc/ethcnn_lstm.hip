@@ -12,9 +12,9 @@
 // update is lane-local, and h_new in C layout is directly the B operand of fc2^T, whose output is
 // the B operand of fc3^T.  Canonical order: chains over the leading multiple-of-16 inputs in
 // k = 16c + 4g + e order, then the 5 efs columns, then the bias (oracle: oracle_lstm_step).
-// LDP calls this once per frame on a few hundred CTUs (lock-step with the encoder), so this first
-// version takes every weight operand straight from L2 (no LDS staging): latency-, not
-// throughput-oriented.
+// LDP calls this once per frame on a few hundred CTUs (lock-step with the encoder): the design
+// goal is latency.  Weight operands come straight from L2 (each is used once per block), the
+// dependent MFMA chain per wave is kept short by spreading hidden tiles over 16 waves.
 #include <hip/hip_runtime.h>
 
 #include "ethcnn_kernels.h"
@@ -57,142 +57,186 @@ __device__ __constant__ int kLstmOff[3][6] = {{723640, 723688, 727000, 727001, 7
                                               {578784, 578880, 591648, 591652, 592056, 592568},
                                               {0, 192, 50304, 50320, 53472, 54496}};
 
+// Two launches per frame, both latency-oriented (few hundred CTUs, lock-step with the encoder):
+//   k_lstm_cell : one wave per (16 CTUs, hidden tile of 16 units): the four gate accumulators of
+//                 the tile, a dependent chain of 2 N / 4 MFMA steps fed by a 4-chunk-deep register
+//                 prefetch of the kernel rows (each weight is used once per wave: no LDS), then the
+//                 lane-local cell update; writes (c, h) to state_out.
+//   k_lstm_heads: one block per (16 CTUs, level): wave j owns fc2 tile j with h_new read back from
+//                 state_out (L2) as the B operand; h2 crosses waves through LDS in [tile][g][ctu][r]
+//                 order (the writer's C-layout quad and the reader's B-operand quad of lane (ctu, g)
+//                 are the same float4 slot); wave 0 finishes fc3 + sigmoid + gate predicates.
 template <int LV>
-__device__ __forceinline__ void lstm_level(const LstmParams& lp, const float* __restrict__ vrow,
-                                           const float* __restrict__ sin_row, float* __restrict__ sout_row, bool valid,
-                                           int ctu, int lane, float* __restrict__ raw, float* __restrict__ probs,
-                                           int* flag32, int* flag16, float thr1, float thr2) {
-    constexpr int N = (LV == 0) ? 64 : (LV == 1 ? 128 : 256);
-    constexpr int N2 = (LV == 0) ? 48 : (LV == 1 ? 96 : 192);
-    constexpr int N3 = (LV == 0) ? 1 : (LV == 1 ? 4 : 16);
-    constexpr int O1 = (LV == 0) ? 0 : (LV == 1 ? 64 : 192);
-    constexpr int O3 = (LV == 0) ? 0 : (LV == 1 ? 1 : 5);
-    constexpr int NT = N / 16, NT2 = N2 / 16;
-    const int col = lane & 15, g = lane >> 4;
-    const float* b2 = lp.blob + kLstmOff[LV][0];
-    const float* W2 = lp.blob + kLstmOff[LV][1];
-    const float* b3 = lp.blob + kLstmOff[LV][2];
-    const float* W3 = lp.blob + kLstmOff[LV][3];
-    const float* bk = lp.blob + kLstmOff[LV][4];
-    const float* K = lp.blob + kLstmOff[LV][5];
+struct LstmDims {
+    static constexpr int N = (LV == 0) ? 64 : (LV == 1 ? 128 : 256);
+    static constexpr int N2 = (LV == 0) ? 48 : (LV == 1 ? 96 : 192);
+    static constexpr int N3 = (LV == 0) ? 1 : (LV == 1 ? 4 : 16);
+    static constexpr int O1 = (LV == 0) ? 0 : (LV == 1 ? 64 : 192);
+    static constexpr int O3 = (LV == 0) ? 0 : (LV == 1 ? 1 : 5);
+    static constexpr int NT = N / 16, NT2 = N2 / 16;
+};
 
-    f32x4 hreg[NT];  // h_new, lane (ctu, g): units 16 t + 4 g + r
+template <int LV>
+__device__ __forceinline__ void lstm_cell(const LstmParams& lp, const float* __restrict__ vrow,
+                                          const float* __restrict__ sin_row, float* __restrict__ sout_row, bool valid,
+                                          int lane, int t) {
+    using D = LstmDims<LV>;
+    constexpr int N = D::N, O1 = D::O1, NC = 2 * N / 16, PF = 4;
+    const int col = lane & 15, g = lane >> 4;
+    const float* bk = lp.blob + kLstmOff[LV][4];
+    const float* kcol = lp.blob + kLstmOff[LV][5] + 16 * t + col + (size_t)(4 * g) * (4 * N);
+    const float* xsrc = vrow + O1 + 4 * g;
+    const float* hsrc = sin_row ? sin_row + kNVec + O1 + 4 * g : xsrc;  // null state: any valid address, zeroed below
+
+    float a[PF][16];
+    float4 bv[PF];
+    auto load = [&](int kc, int p) {  // [x, h_prev]: x first (array_ops.concat([inputs, m_prev], 1))
+        const bool in_x = kc < N / 16;
+        const float* src = in_x ? xsrc + 16 * kc : hsrc + 16 * (kc - N / 16);
+        float4 v = *reinterpret_cast<const float4*>(src);
+        if (!in_x && !sin_row) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        bv[p] = v;
+        const float* krow = kcol + (size_t)(16 * kc) * (4 * N);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[p][4 * e + q] = krow[(size_t)e * (4 * N) + q * N];
+    };
+    f32x4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < PF; ++p) load(p, p);
 #pragma unroll 1
-    for (int ub = 0; ub < N / 64; ++ub) {  // 64 hidden units (4 tiles) x 4 gates at a time
-        f32x4 acc[4][4];
+    for (int kc = 0; kc < NC; kc += PF) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int p = 0; p < PF; ++p) {
+            const float hv[4] = {bv[p].x, bv[p].y, bv[p].z, bv[p].w};
 #pragma unroll
-            for (int tt = 0; tt < 4; ++tt) acc[q][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-        for (int kc = 0; kc < 2 * N / 16; ++kc) {  // [x, h_prev]: x first (array_ops.concat([inputs, m_prev], 1))
-            const float* src = (kc < N / 16) ? vrow + O1 + 16 * kc + 4 * g
-                                             : (sin_row ? sin_row + kNVec + O1 + 16 * (kc - N / 16) + 4 * g : nullptr);
-            const float4 bv = src ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float hv = (e == 0) ? bv.x : (e == 1) ? bv.y : (e == 2) ? bv.z : bv.w;
-                const float* krow = K + (size_t)(16 * kc + 4 * g + e) * (4 * N) + ub * 64 + col;
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int tt = 0; tt < 4; ++tt) acc[q][tt] = MFMA16(krow[q * N + 16 * tt], hv, acc[q][tt]);
-            }
-        }
-        // cell update, lane-local: units u = 64 ub + 16 tt + 4 g + r
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-            const int u0 = 64 * ub + 16 * tt + 4 * g;
-            const float4 cp = sin_row ? *reinterpret_cast<const float4*>(sin_row + O1 + u0) : make_float4(0.f, 0.f, 0.f, 0.f);
-            const float cpv[4] = {cp.x, cp.y, cp.z, cp.w};
-            f32x4 cn, hn;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int u = u0 + r;
-                const float gi = acc[0][tt][r] + bk[u], gj = acc[1][tt][r] + bk[N + u];
-                const float gf = acc[2][tt][r] + bk[2 * N + u], go = acc[3][tt][r] + bk[3 * N + u];
-                float cc = sigmoid_l(gf + 1.0f) * cpv[r] + sigmoid_l(gi) * tanh_l(gj);
-                cc = fminf(fmaxf(cc, -5.0f), 5.0f);
-                cn[r] = cc;
-                hn[r] = sigmoid_l(go) * tanh_l(cc);
-            }
-            if (valid) {
-                *reinterpret_cast<f32x4*>(sout_row + O1 + u0) = cn;
-                *reinterpret_cast<f32x4*>(sout_row + kNVec + O1 + u0) = hn;
-            }
-            // static register index: ub is a runtime loop variable, so select by comparison
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-                if (t == 4 * ub + tt) hreg[t] = hn;
+                for (int q = 0; q < 4; ++q) acc[q] = MFMA16(a[p][4 * e + q], hv[e], acc[q]);
+            load(min(kc + PF + p, NC - 1), p);  // the tail re-reads the last chunk (unused)
         }
     }
-    // fc2^T: rows = h2 units, step (t, r) consumes k = 16 t + 4 g + r
-    f32x4 a2[NT2];
-#pragma unroll
-    for (int j = 0; j < NT2; ++j) a2[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float* wrow = W2 + (size_t)(16 * t + 4 * g + r) * N2 + col;
-#pragma unroll
-            for (int j = 0; j < NT2; ++j) a2[j] = MFMA16(wrow[16 * j], hreg[t][r], a2[j]);
-        }
-#pragma unroll
-    for (int j = 0; j < NT2; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int idx = 16 * j + 4 * g + r;
-            float v = a2[j][r];
-#pragma unroll
-            for (int e = 0; e < 5; ++e) v = fmaf(lp.efs[e], W2[(N + e) * N2 + idx], v);
-            a2[j][r] = lrelu_l(v + b2[idx]);
-        }
-    // fc3^T
-    f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < NT2; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float w = (col < N3) ? W3[(16 * j + 4 * g + r) * N3 + col] : 0.0f;
-            z = MFMA16(w, a2[j][r], z);
-        }
+    // cell update, lane-local: units u = 16 t + 4 g + r
+    const int u0 = 16 * t + 4 * g;
+    const float4 cp = sin_row ? *reinterpret_cast<const float4*>(sin_row + O1 + u0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float cpv[4] = {cp.x, cp.y, cp.z, cp.w};
+    f32x4 cn, hn;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int o = 4 * g + r;
-        if (o < N3 && valid) {
-            float zz = z[r];
-#pragma unroll
-            for (int e = 0; e < 5; ++e) zz = fmaf(lp.efs[e], W3[(N2 + e) * N3 + o], zz);
-            const float p = sigmoid_l(zz + b3[o]);
-            const size_t idx = (size_t)ctu * kNOut + O3 + o;
-            raw[idx] = p;
-            probs[idx] = p;
-            if (LV == 0 && p > thr1 && __hip_atomic_load(flag32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
-                __hip_atomic_store(flag32, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (LV == 1 && p > thr2 && __hip_atomic_load(flag16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
-                __hip_atomic_store(flag16, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        const int u = u0 + r;
+        const float gi = acc[0][r] + bk[u], gj = acc[1][r] + bk[N + u];
+        const float gf = acc[2][r] + bk[2 * N + u], go = acc[3][r] + bk[3 * N + u];
+        float cc = sigmoid_l(gf + 1.0f) * cpv[r] + sigmoid_l(gi) * tanh_l(gj);
+        cc = fminf(fmaxf(cc, -5.0f), 5.0f);
+        cn[r] = cc;
+        hn[r] = sigmoid_l(go) * tanh_l(cc);
+    }
+    if (valid) {
+        *reinterpret_cast<f32x4*>(sout_row + O1 + u0) = cn;
+        *reinterpret_cast<f32x4*>(sout_row + kNVec + O1 + u0) = hn;
     }
 }
 
-// grid.y = level (64 / 32 / 16 run as independent waves); one wave per 16 CTUs
-__global__ __launch_bounds__(64) void k_lstm(const float* __restrict__ vec, const float* __restrict__ state_in,
-                                             float* __restrict__ state_out, LstmParams lp, int N, float thr1,
-                                             float thr2, float* __restrict__ raw, float* __restrict__ probs,
-                                             int* __restrict__ flags) {
+// grid = (groups of 16 CTUs, 28 hidden tiles: 16 of level 16 first, then 8 of level 32, 4 of level 64)
+__global__ __launch_bounds__(64) void k_lstm_cell(const float* __restrict__ vec, const float* __restrict__ state_in,
+                                                  float* __restrict__ state_out, LstmParams lp, int N) {
     const int lane = threadIdx.x;
-    const int col = lane & 15;
-    const int ctu_raw = blockIdx.x * 16 + col;
+    const int ctu_raw = blockIdx.x * 16 + (lane & 15);
     const bool valid = ctu_raw < N;
     const int ctu = min(ctu_raw, N - 1);
     const float* vrow = vec + (size_t)ctu * kNVec;
     const float* sin_row = state_in ? state_in + (size_t)ctu * 2 * kNVec : nullptr;
     float* sout_row = state_out + (size_t)ctu * 2 * kNVec;
+    const int ti = blockIdx.y;
+    if (ti < 16) lstm_cell<2>(lp, vrow, sin_row, sout_row, valid, lane, ti);
+    else if (ti < 24) lstm_cell<1>(lp, vrow, sin_row, sout_row, valid, lane, ti - 16);
+    else lstm_cell<0>(lp, vrow, sin_row, sout_row, valid, lane, ti - 24);
+}
+
+template <int LV>
+__device__ __forceinline__ void lstm_heads(const LstmParams& lp, const float* __restrict__ hrow, bool valid, int ctu,
+                                           int lane, int wave, f32x4* h2T, float* __restrict__ raw,
+                                           float* __restrict__ probs, int* flag32, int* flag16, float thr1, float thr2) {
+    using D = LstmDims<LV>;
+    constexpr int N = D::N, N2 = D::N2, N3 = D::N3, O1 = D::O1, O3 = D::O3, NT = D::NT, NT2 = D::NT2;
+    const int col = lane & 15, g = lane >> 4;
+    const float* b2 = lp.blob + kLstmOff[LV][0];
+    const float* W2 = lp.blob + kLstmOff[LV][1];
+    const float* b3 = lp.blob + kLstmOff[LV][2];
+    const float* W3 = lp.blob + kLstmOff[LV][3];
+    // fc2^T: wave j owns output tile j; step (t, r) consumes k = 16 t + 4 g + r
+    if (wave < NT2) {
+        const int j = wave;
+        f32x4 a2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float* wcol = W2 + 16 * j + col + (size_t)(4 * g) * N2;
+        const float* hsrc = hrow + O1 + 4 * g;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float4 hv4 = *reinterpret_cast<const float4*>(hsrc + 16 * t);
+            const float hv[4] = {hv4.x, hv4.y, hv4.z, hv4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a2 = MFMA16(wcol[(size_t)(16 * t + r) * N2], hv[r], a2);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int idx = 16 * j + 4 * g + r;
+            float v = a2[r];
+#pragma unroll
+            for (int e = 0; e < 5; ++e) v = fmaf(lp.efs[e], W2[(N + e) * N2 + idx], v);
+            a2[r] = lrelu_l(v + b2[idx]);
+        }
+        h2T[(j * 4 + g) * 16 + col] = a2;
+    }
+    __syncthreads();
+    if (wave == 0) {  // fc3^T
+        f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NT2; ++j) {
+            const f32x4 hv = h2T[(j * 4 + g) * 16 + col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float w = (col < N3) ? W3[(16 * j + 4 * g + r) * N3 + col] : 0.0f;
+                z = MFMA16(w, hv[r], z);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = 4 * g + r;
+            if (o < N3 && valid) {
+                float zz = z[r];
+#pragma unroll
+                for (int e = 0; e < 5; ++e) zz = fmaf(lp.efs[e], W3[(N2 + e) * N3 + o], zz);
+                const float p = sigmoid_l(zz + b3[o]);
+                const size_t idx = (size_t)ctu * kNOut + O3 + o;
+                raw[idx] = p;
+                probs[idx] = p;
+                if (LV == 0 && p > thr1 && __hip_atomic_load(flag32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+                    __hip_atomic_store(flag32, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (LV == 1 && p > thr2 && __hip_atomic_load(flag16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+                    __hip_atomic_store(flag16, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
+// grid = (groups of 16 CTUs, level); 12 waves per block (levels 64 / 32 use 3 / 6 of them)
+__global__ __launch_bounds__(768) void k_lstm_heads(const float* __restrict__ state_out, LstmParams lp, int N, float thr1,
+                                                    float thr2, float* __restrict__ raw, float* __restrict__ probs,
+                                                    int* __restrict__ flags) {
+    __shared__ f32x4 h2T[12 * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ctu_raw = blockIdx.x * 16 + (lane & 15);
+    const bool valid = ctu_raw < N;
+    const int ctu = min(ctu_raw, N - 1);
+    const float* hrow = state_out + (size_t)ctu * 2 * kNVec + kNVec;
     int* fl = flags + 2 * (ctu / kSubBatch);  // one frame: mini-batches of 1024 in raster order
-    if (blockIdx.y == 0) lstm_level<0>(lp, vrow, sin_row, sout_row, valid, ctu, lane, raw, probs, fl, fl + 1, thr1, thr2);
-    else if (blockIdx.y == 1) lstm_level<1>(lp, vrow, sin_row, sout_row, valid, ctu, lane, raw, probs, fl, fl + 1, thr1, thr2);
-    else lstm_level<2>(lp, vrow, sin_row, sout_row, valid, ctu, lane, raw, probs, fl, fl + 1, thr1, thr2);
+    const int lv = 2 - (int)blockIdx.y;
+    if (lv == 0) lstm_heads<0>(lp, hrow, valid, ctu, lane, wave, h2T, raw, probs, fl, fl + 1, thr1, thr2);
+    else if (lv == 1) lstm_heads<1>(lp, hrow, valid, ctu, lane, wave, h2T, raw, probs, fl, fl + 1, thr1, thr2);
+    else lstm_heads<2>(lp, hrow, valid, ctu, lane, wave, h2T, raw, probs, fl, fl + 1, thr1, thr2);
 }
 
 void launch_lstm(const float* d_vec, const float* d_state_in, float* d_state_out, const float* d_lstm_blob, int n, int qp,
@@ -202,8 +246,10 @@ void launch_lstm(const float* d_vec, const float* d_state_in, float* d_state_out
     lp.efs[0] = ((float)qp / 51.0f) * 0.18f;  // net():283  qp / 51.0 * 0.18
     const int phase = ((i_frame % 4) + 4) % 4;
     for (int e = 0; e < 4; ++e) lp.efs[1 + e] = (e == phase) ? 1.0f : 0.0f;
-    hipLaunchKernelGGL(k_lstm, dim3((n + 15) / 16, 3), dim3(64), 0, s, d_vec, d_state_in, d_state_out, lp, n, thr1, thr2,
-                       ws.raw, d_probs, ws.flags);
+    const unsigned groups = (unsigned)((n + 15) / 16);
+    hipLaunchKernelGGL(k_lstm_cell, dim3(groups, 28), dim3(64), 0, s, d_vec, d_state_in, d_state_out, lp, n);
+    hipLaunchKernelGGL(k_lstm_heads, dim3(groups, 3), dim3(768), 0, s, d_state_out, lp, n, thr1, thr2, ws.raw, d_probs,
+                       ws.flags);
 }
 
 }  // namespace ethcnn

@@ -1,0 +1,53 @@
+"""Per-frame latency of the LDP call (config #5): ethcnn_ldp_predict_frame (host buffers in/out,
+what the daemon does per frame), its device-side pieces, and the CPU oracle beside it."""
+import importlib, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np
+pkg = importlib.import_module("hevc-complexity-reduction_amd")
+e = pkg.ethcnn
+ctx = pkg.EthCnn(0)
+ctx.load_synthetic(1, 1.0)
+real = os.path.join(ROOT, "tests", "golden", "model_LDP_200000_qp32.dat")
+ctx.load_lstm_checkpoint(real)
+cpu = "--cpu" in sys.argv
+if cpu:
+    import ethcnn_np, ethcnn_lstm_np
+    cblob, lblob = ethcnn_np.synth_blob(1, 1.0), ctx.get_lstm_blob()
+rng = np.random.default_rng(0)
+for name, w, h in (("416x240", 416, 240), ("832x480", 832, 480), ("1280x720", 1280, 720), ("1920x1080", 1920, 1080), ("3840x2160", 3840, 2160)):
+    n = e.ctus_per_frame(w, h)
+    luma = np.clip(128 + rng.laplace(0, 6, size=(h, w)), 0, 255).astype(np.uint8)
+    state = None
+    for i in range(1, 6):
+        _, state = ctx.ldp_predict_frame(luma, w, h, 32, i, state)
+    t0 = time.perf_counter(); reps = 100
+    for i in range(reps):
+        _, state = ctx.ldp_predict_frame(luma, w, h, 32, 6 + i, state)
+    t_host = (time.perf_counter() - t0) / reps
+    # device-resident pieces
+    d_in, d_vec = ctx.alloc(luma.nbytes), ctx.alloc(n * 448 * 4)
+    d_s0, d_s1, d_p = ctx.alloc(n * 896 * 4), ctx.alloc(n * 896 * 4), ctx.alloc(n * 84)
+    d_in.upload(luma); d_s0.upload(state)
+    def dev():
+        ctx._chk(ctx.lib.ethcnn_resi_vectors_device(ctx.h, d_in.ptr, w, h, w, d_vec.ptr))
+        ctx._chk(ctx.lib.ethcnn_lstm_step_device(ctx.h, d_vec.ptr, d_s0.ptr, n, 32, 7, d_s1.ptr, d_p.ptr))
+        ctx.synchronize()
+    for _ in range(10): dev()
+    t0 = time.perf_counter()
+    for _ in range(reps): dev()
+    t_dev = (time.perf_counter() - t0) / reps
+    ctx.set_profiling(2); ctx.reset_stage_times()
+    for _ in range(20): dev()
+    st = ctx.stage_times(); ctx.set_profiling(0)
+    ms = {k: v / 20 * 1e3 for k, v in st["ms"].items()}
+    line = "%-10s %5d CTUs  host-call %8.1f us  device-resident %8.1f us" % (name, n, t_host * 1e6, t_dev * 1e6)
+    if ms: line += "  kernels(us): " + " ".join("%s=%.1f" % (k, v) for k, v in ms.items())
+    if cpu:
+        t0 = time.perf_counter(); r = 3
+        for _ in range(r):
+            vec = ethcnn_np.resi_vectors(cblob, luma, w, h)
+            ethcnn_lstm_np.lstm_step(lblob, vec, state, 32, 7)
+        line += "  cpu-oracle %8.1f us" % ((time.perf_counter() - t0) / r * 1e6)
+    print(line)
+    for b in (d_in, d_vec, d_s0, d_s1, d_p): b.free()
