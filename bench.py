@@ -30,6 +30,10 @@ WORKLOADS = {  # BASELINE.json configs (BASELINE.md section
     "c2": dict(width=1920, height=1080, frames=50, qp=32, name="All-Intra 1920x1080 QP32, 50 frames synthetic YUV"),
     "c3": dict(width=3840, height=2160, frames=50, qp=32, name="All-Intra 3840x2160 QP32, 50 frames synthetic YUV"),
     "c4": dict(width=4928, height=3264, frames=54, qp=27, name="All-Intra 4928x3264 QP27, 54 frames (one GPU's 1/8 share of 425)"),
+    # config #5 (LDP): one frame per call, lock-step with the encoder -> a step is ONE frame through
+    # resi_cnn + one ETH-LSTM step + heads + gates with the recurrent state resident in HBM
+    "c5": dict(width=1920, height=1080, frames=8, qp=32, ldp=True,
+               name="Low-Delay-P 1920x1080 QP32, one residual frame per step (ETH-CNN + ETH-LSTM one step)"),
 }
 MAC_PER_CTU = 1552149          # conv 279,552 + FC1 1,204,224 + FC2 64,848 + FC3 3,525
 FC1_FLOP_PER_CTU = 2 * 1204224
@@ -104,8 +108,23 @@ def main():
     d_out = ctx.alloc(ctus_per_step * 21 * 4)
     d_in.upload(luma)
 
+    ldp = bool(wl.get("ldp"))
+    if ldp:
+        ctus_per_step = nctu
+        ctx.load_lstm_synthetic(seed=2, head_gain=3.0)
+        d_vec = ctx.alloc(nctu * 448 * 4)
+        d_state = [ctx.alloc(nctu * 896 * 4), ctx.alloc(nctu * 896 * 4)]
+        ldp_frame = [0]
+
     def step():
-        ctx.predict_luma_device(d_in, W, H, NF, QP, d_out)
+        if not ldp:
+            ctx.predict_luma_device(d_in, W, H, NF, QP, d_out)
+            return
+        i = ldp_frame[0]
+        ldp_frame[0] = i + 1
+        ctx._chk(ctx.lib.ethcnn_resi_vectors_device(ctx.h, d_in.ptr + (i % NF) * W * H, W, H, W, d_vec.ptr))
+        ctx._chk(ctx.lib.ethcnn_lstm_step_device(ctx.h, d_vec.ptr, d_state[i & 1].ptr if i > 0 else None, nctu, QP,
+                                                 i + 1, d_state[(i + 1) & 1].ptr, d_out.ptr))
 
     for _ in range(args.warmup):
         step()
@@ -164,6 +183,17 @@ def main():
                                "unit": "GB/s", "frac": tile_gbps / PEAK_HBM_GBPS, "avg_launch_ms": tile_ms,
                                "algorithmic_bytes_per_ctu": 4096},
         }
+        if ldp:
+            result["roofline"]["note"] = ("latency-bound call (one frame, %d CTUs): the serial K chain of FC1 sets the "
+                                          "launch time, not the MFMA rate; stage 'heads' = k_lstm_cell + k_lstm_heads" % nctu)
+            result["config"]["sharding"] = "none (lock-step with the encoder): replicas only"
+            if world == 1 and not args.no_cpu_baseline:
+                result["cpu_baseline"] = cpu_baseline_ldp(luma, W, H, QP, args.cpu_seconds)
+            result["parity_first_frames_bit_exact"] = ldp_parity(ctx, luma, W, H, QP)
+            print(json.dumps(result))
+            sys.stdout.flush()
+            ctx.close()
+            return 0
         if world == 1 and not args.no_host_scopes:
             result["host_scopes"] = host_scopes(ctx, luma, W, H, NF, QP)
         if world == 1 and not args.no_cpu_baseline:
@@ -186,6 +216,42 @@ def main():
         dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
     return 0
+
+
+def ldp_parity(ctx, luma, W, H, QP):
+    """first three frames of the LDP chain through the host entry point vs the oracle chain"""
+    try:
+        import numpy as np
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import ethcnn_np as oracle
+        import ethcnn_lstm_np as ol
+        cb, lb = ctx.get_blob(), ctx.get_lstm_blob()
+        gs = os_ = None
+        for i in (1, 2, 3):
+            gp, gs = ctx.ldp_predict_frame(luma[i - 1], W, H, QP, i, gs)
+            op, os_ = ol.lstm_step(lb, oracle.resi_vectors(cb, luma[i - 1], W, H), os_, QP, i, 0.5, 0.5, mode=0)
+            if not (np.array_equal(gp.view(np.uint32), op.view(np.uint32)) and
+                    np.array_equal(gs.view(np.uint32), os_.view(np.uint32))):
+                return False
+        return True
+    except Exception as exc:
+        return "unchecked: %s" % exc
+
+
+def cpu_baseline_ldp(luma, W, H, QP, target_seconds):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ethcnn_np as oracle
+    import ethcnn_lstm_np as ol
+    cb, lb = oracle.synth_blob(1, 8.0), ol.synth_lstm_blob(2, 3.0)
+    nctu = ((W + 63) // 64) * ((H + 63) // 64)
+    st, n, t0 = None, 0, time.perf_counter()
+    while time.perf_counter() - t0 < target_seconds or n < 2:
+        _, st = ol.lstm_step(lb, oracle.resi_vectors(cb, luma[n % luma.shape[0]], W, H), st, QP, n + 1, 0.5, 0.5, mode=0)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n * nctu / dt, "unit": "CTU/s", "cores": os.cpu_count() or 1, "kind": "port",
+            "sample": "%d consecutive frames of %dx%d (%d CTUs each), oracle resi_vectors (OpenMP) + oracle_lstm_step, %.1f s"
+                      % (n, W, H, nctu, dt)}
 
 
 def pmc_traffic(workload):

@@ -200,7 +200,9 @@ static int upload_weights(ethcnn_ctx* c) {
                                  (size_t)kNFeat * kNVec, (size_t)kNVec};
     for (int h = 0; h < 3; ++h) { sizes.push_back((size_t)(kN1[h] + 1) * kN2[h]); sizes.push_back((size_t)kN2[h]); }
     for (int h = 0; h < 3; ++h) { sizes.push_back((size_t)(kN2[h] + 1) * kN3[h]); sizes.push_back((size_t)kN3[h]); }
-    sizes.push_back((size_t)kNFeat * kNVec);  // [16]
+    sizes.push_back((size_t)kNFeat * kNVec);  // [16] fc1 image BN 64
+    sizes.push_back((size_t)kNFeat * kNVec);  // [17] fc1 image BN 32
+    sizes.push_back((size_t)kNFeat * kNVec);  // [18] fc1 image BN 16
     std::vector<size_t> offs;
     size_t total = 0;
     for (size_t s : sizes) { offs.push_back(total); total += (s + 63) / 64 * 64; }
@@ -212,6 +214,8 @@ static int upload_weights(ethcnn_ctx* c) {
         pack_fc1(blob, wcat.data(), host.data() + offs[3]);
         pack_fc1_image(wcat.data(), 112, 16, host.data() + offs[2]);
         pack_fc1_image(wcat.data(), 64, 32, host.data() + offs[16]);
+        pack_fc1_image(wcat.data(), 32, 32, host.data() + offs[17]);
+        pack_fc1_image(wcat.data(), 16, 32, host.data() + offs[18]);
     }
     for (int h = 0; h < 3; ++h) {
         std::memcpy(host.data() + offs[4 + 2 * h], blob + kOffFc2W[h], sizes[4 + 2 * h] * 4);
@@ -227,6 +231,8 @@ static int upload_weights(ethcnn_ctx* c) {
     d.trunk_b = c->dw_arena + offs[1];
     d.fc1_img112 = c->dw_arena + offs[2];
     d.fc1_img64 = c->dw_arena + offs[16];
+    d.fc1_img32 = c->dw_arena + offs[17];
+    d.fc1_img16 = c->dw_arena + offs[18];
     d.fc1_b = c->dw_arena + offs[3];
     for (int h = 0; h < 3; ++h) {
         d.fc2_w[h] = c->dw_arena + offs[4 + 2 * h];

@@ -194,17 +194,22 @@ static int fc1_variant() {
     return v;
 }
 
-// Tile shape by batch size.  Plateau (large N, profiles/r01_fc1_variants.txt): 128x112 > 64x112 >
-// 64x64.  What differs is how evenly the blocks divide over the 256 CUs when there are only a
-// handful per CU (every block runs the full K loop, so a CU with 7 blocks finishes 1/6 later
-// than one with 6): pick the shape with the best plateau x balance product.
-static int fc1_auto_variant(int n) {
-    auto balance = [](int blocks) { return (double)blocks / (256.0 * ((blocks + 255) / 256)); };
-    const double e[3] = {1.000 * balance(((n + 127) / 128) * 4), 0.957 * balance(((n + 63) / 64) * 4),
-                         0.937 * balance(((n + 63) / 64) * 7)};
-    int best = 0;
-    for (int i = 1; i < 3; ++i)
-        if (e[i] > e[best]) best = i;
+// Tile shape for a SHORT row range (the remainder of the split launch, or a whole small batch such
+// as one LDP frame).  Here every block runs the full serial K loop once, so the time is the K-loop
+// latency of the shape times the number of 256-block rounds, not the MFMA rate: measured
+// (profiles/r01_fc1_rows.txt) t[us] ~= a + b * ceil(blocks / 256).  Narrow shapes have short chains
+// (few MFMAs per K chunk per wave) but need more blocks.
+static int fc1_short_variant(int n) {
+    struct Shape { int variant, bm, nsplit; double a, b; };
+    static const Shape shapes[] = {{0, 128, 4, 15.0, 150.0}, {1, 64, 4, 34.0, 74.0}, {2, 64, 7, 12.0, 48.0},
+                                   {3, 64, 14, 9.0, 27.0},   {4, 64, 28, 8.0, 17.0}, {5, 64, 14, 7.0, 27.5}};
+    int best = 2;
+    double tbest = 1e30;
+    for (const Shape& sh : shapes) {
+        const int blocks = ((n + sh.bm - 1) / sh.bm) * sh.nsplit;
+        const double t = sh.a + sh.b * ((blocks + 255) / 256);
+        if (t < tbest) { tbest = t; best = sh.variant; }
+    }
     return best;
 }
 
@@ -223,6 +228,18 @@ static void launch_fc1_rows(int variant, const Workspace& ws, const DeviceWeight
         case 2:  // 64 CTUs x 64 columns (N split 7), BK 32
             launch_fc1_p3<1, 4, 4, 2, true>(feat, w.fc1_img64, w.fc1_b, o, rows, s);
             break;
+        case 3:  // 64 CTUs x 32 columns (N split 14), BK 32: short K-chain time for short row ranges
+            launch_fc1_p3<1, 2, 4, 2, true>(feat, w.fc1_img32, w.fc1_b, o, rows, s);
+            break;
+        case 4:  // 64 CTUs x 16 columns (N split 28), BK 64
+            launch_fc1_p3<1, 1, 4, 4, true>(feat, w.fc1_img16, w.fc1_b, o, rows, s);
+            break;
+        case 5:  // 64 CTUs x 32 columns, BK 64
+            launch_fc1_p3<1, 2, 4, 4, true>(feat, w.fc1_img32, w.fc1_b, o, rows, s);
+            break;
+        case 6:  // 32 CTUs (2 waves) x 32 columns, BK 64
+            launch_fc1_p3<1, 2, 2, 4, true>(feat, w.fc1_img32, w.fc1_b, o, rows, s);
+            break;
         case 10: launch_fc1_p3<2, 7, 4, 1, false>(feat, w.fc1_img112, w.fc1_b, o, rows, s); break;
         case 11: launch_fc1_p3<1, 7, 4, 1, false>(feat, w.fc1_img112, w.fc1_b, o, rows, s); break;
         case 12: launch_fc1_p3<1, 4, 4, 2, false>(feat, w.fc1_img64, w.fc1_b, o, rows, s); break;
@@ -231,20 +248,26 @@ static void launch_fc1_rows(int variant, const Workspace& ws, const DeviceWeight
 
 void launch_fc1(const Workspace& ws, const DeviceWeights& w, int n, float* out, hipStream_t s) {
     const int variant = fc1_variant();
+    if (variant >= 100) {  // A/B knob: default split launch, remainder forced to shape variant - 100
+        const int bt = ((n / 128) * 4 / 256) * 256 / 4;
+        if (bt > 0) launch_fc1_rows(0, ws, w, 0, bt * 128, out, s);
+        if (n > bt * 128) launch_fc1_rows(variant - 100, ws, w, bt * 128, n - bt * 128, out, s);
+        return;
+    }
     if (variant >= 0 && variant != 20) {  // A/B knob: one fixed shape (20 = the best single shape for n)
         launch_fc1_rows(variant, ws, w, 0, n, out, s);
         return;
     }
     if (variant == 20) {
-        launch_fc1_rows(fc1_auto_variant(n), ws, w, 0, n, out, s);
+        launch_fc1_rows(fc1_short_variant(n), ws, w, 0, n, out, s);
         return;
     }
     // Default, split launch: the 128 x 112 shape (best plateau) on as many rows as give a whole number of
-    // blocks per CU (a multiple of 256 blocks), the remaining rows with the shape that balances best.
+    // blocks per CU (a multiple of 256 blocks), the remaining rows (< 8192) with the lowest-latency shape.
     const int big_tiles = ((n / 128) * 4 / 256) * 256 / 4;
     const int row0 = big_tiles * 128;
     if (big_tiles > 0) launch_fc1_rows(0, ws, w, 0, row0, out, s);
-    if (n > row0) launch_fc1_rows(fc1_auto_variant(n - row0), ws, w, row0, n - row0, out, s);
+    if (n > row0) launch_fc1_rows(fc1_short_variant(n - row0), ws, w, row0, n - row0, out, s);
 }
 
 }  // namespace ethcnn

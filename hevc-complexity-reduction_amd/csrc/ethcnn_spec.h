@@ -81,6 +81,8 @@ struct DeviceWeights {
     // LDS image order of k_fc1 (ethcnn_dense.hip): [448/BN][2688/BK][BK][BN], bank-permuted
     float* fc1_img112 = nullptr;  // BN 112, BK 16
     float* fc1_img64 = nullptr;   // BN 64,  BK 32
+    float* fc1_img32 = nullptr;   // BN 32 and BN 16: low-latency shapes for short row ranges (the image
+    float* fc1_img16 = nullptr;   // depends on BN only: chunk rows are consecutive)
     float* fc1_b = nullptr;    // [448]
     float* fc2_w[3] = {nullptr, nullptr, nullptr};  // [n1+1][n2] (last row = qp row)
     float* fc2_b[3] = {nullptr, nullptr, nullptr};
