@@ -11,6 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libethcnn.so")
+LIB_PATH = os.environ.get("ETHCNN_LIB", LIB_PATH)  # development knob: A/B builds of the same library
 
 NOUT, NFEAT, NVEC, NFC2, SUB_BATCH = 21, 2688, 448, 336, 1024
 BLOB_FLOATS = 1288210
