@@ -14,6 +14,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -22,6 +25,77 @@
 #include "ethcnn_spec.h"
 
 using namespace ethcnn;
+
+// Persistent host worker pool for the staging fill (file pread / memcpy into pinned memory):
+// one memcpy stream moves ~10 GB/s while PCIe Gen5 x16 takes ~50, and a fill lasts well under a
+// millisecond, so threads are created once per context, not once per group.
+class HostPool {
+public:
+    explicit HostPool(int nthreads) {
+        for (int t = 1; t < nthreads; ++t) workers_.emplace_back([this] { loop(); });
+    }
+    ~HostPool() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& t : workers_) t.join();
+    }
+    int size() const { return (int)workers_.size() + 1; }
+    // fn(u) for u in [0, n), the caller takes part; first non-zero return wins
+    int run(int n, const std::function<int(int)>& fn) {
+        if (n <= 0) return 0;
+        if (workers_.empty() || n == 1) {
+            for (int u = 0; u < n; ++u)
+                if (int r = fn(u)) return r;
+            return 0;
+        }
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            fn_ = &fn;
+            n_ = n;
+            next_.store(0);
+            rc_.store(0);
+            pending_ = (int)workers_.size();
+            ++gen_;
+        }
+        cv_.notify_all();
+        drain();
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [this] { return pending_ == 0; });
+        fn_ = nullptr;
+        return rc_.load();
+    }
+
+private:
+    void drain() {
+        for (int u = next_.fetch_add(1); u < n_ && rc_.load() == 0; u = next_.fetch_add(1))
+            if (int r = (*fn_)(u)) rc_.store(r);
+    }
+    void loop() {
+        unsigned long seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_;
+            }
+            drain();
+            std::lock_guard<std::mutex> lk(m_);
+            if (--pending_ == 0) done_.notify_one();
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    const std::function<int(int)>* fn_ = nullptr;
+    std::atomic<int> next_{0}, rc_{0};
+    int n_ = 0, pending_ = 0;
+    unsigned long gen_ = 0;
+    bool stop_ = false;
+};
 
 struct ethcnn_ctx {
     int device = 0;
@@ -63,6 +137,7 @@ struct ethcnn_ctx {
     uint8_t* d_in[2] = {nullptr, nullptr};
     float* d_out[2] = {nullptr, nullptr};
     size_t in_cap = 0, out_cap = 0;
+    HostPool* pool = nullptr;  // created on first use by the host / file entry points
 };
 
 static thread_local std::string g_create_err;
@@ -173,6 +248,7 @@ extern "C" void ethcnn_destroy(ethcnn_ctx* c) {
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     free_workspace(c);
     free_staging(c);
+    delete c->pool;
     if (c->dw_arena) (void)hipFree(c->dw_arena);
     {
         void* lp[] = {c->d_lstm, c->d_vec, c->d_state[0], c->d_state[1], c->d_lprobs};
@@ -446,26 +522,27 @@ static int ensure_staging(ethcnn_ctx* c, size_t in_bytes, size_t out_bytes) {
     return 0;
 }
 
-// frames of one staging group are copied / pread by a few host threads (one memcpy stream moves
-// ~10 GB/s, PCIe Gen5 x16 takes ~50): fn(f) for f in [0, n), first non-zero return wins
-template <typename Fn>
-static int parallel_frames(int n, Fn fn) {
-    const int nt = std::min(n, std::min(8, (int)std::max(1u, std::thread::hardware_concurrency())));
-    if (nt <= 1) {
-        for (int f = 0; f < n; ++f)
-            if (int r = fn(f)) return r;
-        return 0;
+// A staging group is filled in units of (frame, band of rows) of ~512 KiB so that the units divide
+// evenly over the pool whatever the frame count of the group: fn(frame, row0, rows).
+static HostPool* host_pool(ethcnn_ctx* c) {
+    if (!c->pool) {
+        int nt = std::min(16, std::max(1, (int)std::thread::hardware_concurrency() / 2));
+        if (const char* e = std::getenv("ETHCNN_HOST_THREADS")) nt = std::max(1, std::min(64, std::atoi(e)));
+        c->pool = new HostPool(nt);
     }
-    std::atomic<int> next(0), rc(0);
-    auto work = [&]() {
-        for (int f = next.fetch_add(1); f < n && rc.load() == 0; f = next.fetch_add(1))
-            if (int r = fn(f)) rc.store(r);
+    return c->pool;
+}
+
+template <typename Fn>
+static int parallel_bands(ethcnn_ctx* c, int nframes, int w, int h, Fn fn) {
+    const size_t plane = (size_t)w * h;
+    const int bands = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::min(h, 32), plane / (512u << 10)));
+    const std::function<int(int)> unit = [&](int u) -> int {
+        const int f = u / bands, b = u % bands;
+        const int r0 = (int)((long)h * b / bands), r1 = (int)((long)h * (b + 1) / bands);
+        return fn(f, r0, r1 - r0);
     };
-    std::vector<std::thread> th;
-    for (int t = 1; t < nt; ++t) th.emplace_back(work);
-    work();
-    for (auto& t : th) t.join();
-    return rc.load();
+    return host_pool(c)->run(nframes * bands, unit);
 }
 
 // Generic double-buffered host pipeline: for each group of frames, `fill(buf, f0, nf)` packs
@@ -556,11 +633,11 @@ extern "C" int ethcnn_predict_luma(ethcnn_ctx* c, const uint8_t* luma, int w, in
     if (pitch < w) return set_err(c, ETHCNN_ERR_ARG, "pitch %td < width %d", pitch, w);
     const int nctu = ((w + 63) / 64) * ((h + 63) / 64);
     auto fill = [&](uint8_t* dst, int f0, int nf) -> int {
-        return parallel_frames(nf, [&](int f) -> int {
-            const uint8_t* src = luma + (size_t)(f0 + f) * fstride;
-            uint8_t* d = dst + (size_t)f * w * h;
-            if (pitch == w) std::memcpy(d, src, (size_t)w * h);
-            else for (int y = 0; y < h; ++y) std::memcpy(d + (size_t)y * w, src + (size_t)y * pitch, (size_t)w);
+        return parallel_bands(c, nf, w, h, [&](int f, int r0, int rows) -> int {
+            const uint8_t* src = luma + (size_t)(f0 + f) * fstride + (size_t)r0 * pitch;
+            uint8_t* d = dst + (size_t)f * w * h + (size_t)r0 * w;
+            if (pitch == w) std::memcpy(d, src, (size_t)w * rows);
+            else for (int y = 0; y < rows; ++y) std::memcpy(d + (size_t)y * w, src + (size_t)y * pitch, (size_t)w);
             return 0;
         });
     };
@@ -599,12 +676,14 @@ static int yuv_frames(ethcnn_ctx* c, const char* yuv, int w, int h, int qp, cons
     }
     const int fd = fileno(fin), ofd = fileno(fout);
     auto fill = [&](uint8_t* dst, int g0, int nf) -> int {
-        const int rc = parallel_frames(nf, [&](int f) -> int {  // luma only; chroma (w*h/2 bytes) is never read (:47-48)
+        // luma only; chroma (w*h/2 bytes per frame) is never read (:47-48)
+        const int rc = parallel_bands(c, nf, w, h, [&](int f, int r0, int rows) -> int {
             size_t got = 0;
-            const size_t want = (size_t)w * h;
-            const off_t off = (off_t)(f0 + g0 + f) * frame_bytes;
+            const size_t want = (size_t)w * rows;
+            const off_t off = (off_t)(f0 + g0 + f) * frame_bytes + (off_t)r0 * w;
+            uint8_t* d = dst + (size_t)f * w * h + (size_t)r0 * w;
             while (got < want) {
-                const ssize_t r = pread(fd, dst + (size_t)f * want + got, want - got, off + (off_t)got);
+                const ssize_t r = pread(fd, d + got, want - got, off + (off_t)got);
                 if (r <= 0) return ETHCNN_ERR_IO;
                 got += (size_t)r;
             }
