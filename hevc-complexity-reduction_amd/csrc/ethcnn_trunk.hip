@@ -21,6 +21,8 @@
 // v = fma(float(pixel sum), c255 * 2^-p, -mean) with exact integer pixel sums.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "ethcnn_kernels.h"
 
 namespace ethcnn {
@@ -58,35 +60,42 @@ struct Trunk {
     static constexpr int OFF3 = (BR == 0) ? 0 : (BR == 1 ? 512 : 640);
     static constexpr int NJ = (BR == 0) ? 4 : 8;  // uint4 records per lane per task
 
-    // raw record -> x[d][kx] (pixel sums as floats; resi: preprocessed values) and the lane's sum
-    static __device__ __forceinline__ void decode(const uint4 (&raw)[NJ], float (&x)[16][4], int& T) {
-        T = 0;
-        if (BR == 0) {
+    // exact integer sum of this lane's part of the record (the block mean needs it before conv1)
+    static __device__ __forceinline__ int raw_sum(const uint4 (&raw)[NJ]) {
+        int T = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t w[4] = {raw[j].x, raw[j].y, raw[j].z, raw[j].w};
+        for (int j = 0; j < NJ; ++j) {
+            const uint32_t w[4] = {raw[j].x, raw[j].y, raw[j].z, raw[j].w};
 #pragma unroll
-                for (int q1 = 0; q1 < 4; ++q1) {
-                    T = (int)__builtin_amdgcn_udot4(w[q1], 0x01010101u, (unsigned)T, false);  // exact byte sum
-#pragma unroll
-                    for (int kx = 0; kx < 4; ++kx) {
-                        const int s = (int)((w[q1] >> (8 * kx)) & 0xff);
-                        x[4 * j + q1][kx] = RESI ? px_value<true>(s, 1) : (float)s;
-                    }
-                }
+            for (int i = 0; i < 4; ++i) {
+                if (BR == 0) T = (int)__builtin_amdgcn_udot4(w[i], 0x01010101u, (unsigned)T, false);  // exact byte sum
+                else T += (int)((w[i] & 0xffffu) + (w[i] >> 16));
             }
+        }
+        return T;
+    }
+    // the 4 conv1 patches of position q2 -> x[q1][kx] (pixel sums as floats; resi: preprocessed values)
+    static __device__ __forceinline__ void decode_q2(const uint4 (&raw)[NJ], int q2, float (&x)[4][4]) {
+        if (BR == 0) {
+            const uint32_t w[4] = {raw[q2].x, raw[q2].y, raw[q2].z, raw[q2].w};
+#pragma unroll
+            for (int q1 = 0; q1 < 4; ++q1)
+#pragma unroll
+                for (int kx = 0; kx < 4; ++kx) {
+                    const int s = (int)((w[q1] >> (8 * kx)) & 0xff);
+                    x[q1][kx] = RESI ? px_value<true>(s, 1) : (float)s;
+                }
         } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const uint32_t w[4] = {raw[j].x, raw[j].y, raw[j].z, raw[j].w};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) T += (int)((w[i] & 0xffffu) + (w[i] >> 16));
+            for (int jj = 0; jj < 2; ++jj) {
+                const uint4 rw = raw[2 * q2 + jj];
+                const uint32_t w[4] = {rw.x, rw.y, rw.z, rw.w};
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
                     for (int kx = 0; kx < 4; ++kx) {
                         const int s = (int)((w[2 * hh + (kx >> 1)] >> (16 * (kx & 1))) & 0xffff);
-                        x[2 * j + hh][kx] = RESI ? px_value<true>(s, POOL * POOL) * SCALE : (float)s;
+                        x[2 * jj + hh][kx] = RESI ? px_value<true>(s, POOL * POOL) * SCALE : (float)s;
                     }
             }
         }
@@ -94,26 +103,26 @@ struct Trunk {
 
     static __device__ __forceinline__ void run(const uint4* __restrict__ X, int ntasks, int wave, int nwaves,
                                                const float* __restrict__ wfrag, const float* __restrict__ bfrag,
-                                               float* __restrict__ F, int N) {
+                                               float* __restrict__ F, int N, float* wl) {
         const int lane = threadIdx.x & 63;
         const int col = lane & 15, g = lane >> 4;
+        // conv2 / conv3 A-operand fragments of this branch -> LDS, once per block (80 of the 84
+        // fragments; every MFMA fetches its A operand with one conflict-free ds_read_b32, which costs
+        // the matrix pipe nothing, and frees 80 VGPRs: three waves per SIMD instead of two)
+        {
+            const float* wf = wfrag + (size_t)BR * kTrunkWFrags * 64;
+            for (int i = threadIdx.x; i < kTrunkWFrags * 64; i += 256) wl[i] = wf[i];
+        }
+        __syncthreads();
         if (wave >= ntasks) return;
+        const float* wA2 = wl + 4 * 64 + lane;   // A2[t][s] = wA2[(t * 16 + s) * 64]
+        const float* wA3 = wl + 36 * 64 + lane;  // A3[t][s] = wA3[(t * 24 + s) * 64]
 
-        // weights of this branch -> registers (A operands), once per wave
-        float A1[4], A2[2][16], A3[2][24];
+        float A1[4];
         f32x4 B1, B2[2], B3[2];
         {
-            const float* wf = wfrag + (size_t)BR * kTrunkWFrags * 64 + lane;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) A1[s] = wf[s * 64];
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int s = 0; s < 16; ++s) A2[t][s] = wf[(4 + t * 16 + s) * 64];
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int s = 0; s < 24; ++s) A3[t][s] = wf[(36 + t * 24 + s) * 64];
+            for (int s = 0; s < 4; ++s) A1[s] = wl[s * 64 + lane];
             const float* bf = bfrag + (size_t)BR * kTrunkBFrags * 64 + lane;
 #pragma unroll
             for (int r = 0; r < 4; ++r) B1[r] = bf[r * 64];
@@ -131,15 +140,7 @@ struct Trunk {
         for (int j = 0; j < NJ; ++j) raw[j] = X[((size_t)wave * NJ + j) * 64 + lane];
 
         for (int task = wave; task < ntasks; task += nwaves) {
-            // the raw registers are dead once decoded: the next task's record is fetched under this
-            // task's 240 MFMAs at no VGPR cost
-            float x[16][4];
-            int T;
-            decode(raw, x, T);
-            if (task + nwaves < ntasks) {
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) raw[j] = X[((size_t)(task + nwaves) * NJ + j) * 64 + lane];
-            }
+            int T = raw_sum(raw);
             T += __shfl_xor(T, 16);
             T += __shfl_xor(T, 32);
             // canonical centring: AI  v = fma(float(sum), c255 * 2^-p, -mean)  (one rounding);
@@ -161,7 +162,7 @@ struct Trunk {
         _Pragma("unroll") for (int q1 = 0; q1 < 4; ++q1) c1[q1] = B1;                                  \
         _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                  \
             _Pragma("unroll") for (int q1 = 0; q1 < 4; ++q1) {                                         \
-                const float xv = x[4 * (q2) + q1][s];                                                  \
+                const float xv = x[q1][s];                                                  \
                 c1[q1] = MFMA16(A1[s], RESI ? xv - mean : fmaf(xv, C255S, negmean), c1[q1]);           \
             }                                                                                          \
     }
@@ -172,8 +173,8 @@ struct Trunk {
         c2[1] = B2[1];                                                                                 \
         _Pragma("unroll") for (int q1 = 0; q1 < 4; ++q1)                                               \
             _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                            \
-                c2[0] = MFMA16(A2[0][4 * q1 + r], c1[q1][r], c2[0]);                                   \
-                c2[1] = MFMA16(A2[1][4 * q1 + r], c1[q1][r], c2[1]);                                   \
+                c2[0] = MFMA16(wA2[(4 * q1 + r) * 64], c1[q1][r], c2[0]);                                   \
+                c2[1] = MFMA16(wA2[(16 + 4 * q1 + r) * 64], c1[q1][r], c2[1]);                                   \
             }                                                                                          \
     }
 #define LEAKY1(c1) { _Pragma("unroll") for (int q1 = 0; q1 < 4; ++q1) c1[q1] = lrelu4(c1[q1]); }
@@ -194,10 +195,18 @@ struct Trunk {
 #pragma unroll
             for (int q2 = 0; q2 < 4; ++q2) {
                 f32x4 c1[4], c2[2];
+                float x[4][4];
+                decode_q2(raw, q2, x);
                 CONV1(q2, c1);
                 LEAKY1(c1);
                 CONV2(c1, c2);
                 FINISH2(q2, c2);
+            }
+            // the raw registers are dead now: the next task's record is fetched under conv3 (and the
+            // other waves' work) at no VGPR cost
+            if (task + nwaves < ntasks) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) raw[j] = X[((size_t)(task + nwaves) * NJ + j) * 64 + lane];
             }
 #undef CONV1
 #undef CONV2
@@ -208,8 +217,8 @@ struct Trunk {
             for (int q2 = 0; q2 < 4; ++q2)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    c3[0] = MFMA16(A3[0][4 * q2 + r], a2[q2][0][r], c3[0]);
-                    c3[1] = MFMA16(A3[1][4 * q2 + r], a2[q2][0][r], c3[1]);
+                    c3[0] = MFMA16(wA3[(4 * q2 + r) * 64], a2[q2][0][r], c3[0]);
+                    c3[1] = MFMA16(wA3[(24 + 4 * q2 + r) * 64], a2[q2][0][r], c3[1]);
                 }
             // phase B: channels 16..23, positions (2j, 2j+1) packed into the lower / upper lane halves
 #pragma unroll
@@ -218,8 +227,8 @@ struct Trunk {
                 for (int r = 0; r < 4; ++r) {
                     const float hi = __shfl(a2[2 * j + 1][1][r], lane & 31);  // lanes 32..63 <- lanes 0..31 of position 2j+1
                     const float z = (lane < 32) ? a2[2 * j][1][r] : hi;
-                    c3[0] = MFMA16(A3[0][16 + 4 * j + r], z, c3[0]);
-                    c3[1] = MFMA16(A3[1][16 + 4 * j + r], z, c3[1]);
+                    c3[0] = MFMA16(wA3[(16 + 4 * j + r) * 64], z, c3[0]);
+                    c3[1] = MFMA16(wA3[(24 + 16 + 4 * j + r) * 64], z, c3[1]);
                 }
             if (valid) {
                 const int k0 = OFF3 + (by * NB + bx) * 32 + 4 * g;
@@ -235,19 +244,23 @@ __global__ __launch_bounds__(256) void k1_trunk(const uint4* __restrict__ XS, co
                                                 const uint4* __restrict__ XL, int N, int bS, int bM,
                                                 const float* __restrict__ wfrag, const float* __restrict__ bfrag,
                                                 float* __restrict__ F) {
+    __shared__ float wl[kTrunkWFrags * 64];  // this block's branch: 84 A-operand fragments, 21 KB
     const int w = threadIdx.x >> 6;
     const int b = blockIdx.x;
     const int groups = (N + 15) / 16;
-    if (b < bS) Trunk<0, RESI>::run(XS, groups * 16, b * 4 + w, bS * 4, wfrag, bfrag, F, N);
-    else if (b < bS + bM) Trunk<1, RESI>::run(XM, groups * 4, (b - bS) * 4 + w, bM * 4, wfrag, bfrag, F, N);
-    else Trunk<2, RESI>::run(XL, groups, (b - bS - bM) * 4 + w, (int)(gridDim.x - bS - bM) * 4, wfrag, bfrag, F, N);
+    if (b < bS) Trunk<0, RESI>::run(XS, groups * 16, b * 4 + w, bS * 4, wfrag, bfrag, F, N, wl);
+    else if (b < bS + bM) Trunk<1, RESI>::run(XM, groups * 4, (b - bS) * 4 + w, bM * 4, wfrag, bfrag, F, N, wl);
+    else Trunk<2, RESI>::run(XL, groups, (b - bS - bM) * 4 + w, (int)(gridDim.x - bS - bM) * 4, wfrag, bfrag, F, N, wl);
 }
 
 void launch_trunk(const Workspace& ws, const DeviceWeights& w, int n, bool resi, hipStream_t s) {
-    // tasks per group: 16 S, 4 M, 1 L -- all 240 MFMAs.  512 blocks = 2 per CU, shares 16:4:1.
+    // tasks per group: 16 S, 4 M, 1 L -- all 240 MFMAs.  768 blocks = 3 per CU (161 VGPRs, 21 KB LDS),
+    // shares 16:4:1.
     const int groups = (n + 15) / 16, tS = groups * 16, tM = groups * 4, tL = groups;
     auto blocks = [](int tasks, int budget) { int b = (tasks + 3) / 4; return b < budget ? b : budget; };
-    const int bS = blocks(tS, 390), bM = blocks(tM, 98), bL = blocks(tL, 24);
+    static int per_cu = 0;
+    if (!per_cu) { const char* e = getenv("ETHCNN_TRUNK_BLOCKS_PER_CU"); per_cu = e ? atoi(e) : 3; }  // development knob
+    const int bS = blocks(tS, 195 * per_cu), bM = blocks(tM, 49 * per_cu), bL = blocks(tL, 12 * per_cu);
     if (resi)
         hipLaunchKernelGGL(k1_trunk<true>, dim3(bS + bM + bL), dim3(256), 0, s, ws.xs, ws.xm, ws.xl, n, bS, bM,
                            w.trunk_w, w.trunk_b, ws.feat);
