@@ -124,6 +124,7 @@ struct ethcnn_ctx {
     Workspace ws;
     int max_ctus = 131072;
     int last_n = 0;  // CTUs of the last pass (debug_fetch)
+    bool debug_capture = false;  // also store FC2 outputs, logits and ungated probabilities (1.7 KB/CTU of writes)
 
     int profiling = 0;  // 0 off, 1 dominant kernel (FC1) only, 2 every stage
     struct Ev { hipEvent_t a, b; int stage; };
@@ -463,7 +464,9 @@ static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, lo
     { StageTimer t(c, ETHCNN_STAGE_TILE); launch_tile(d_luma, g, ctu0, n, c->ws, c->stream); }
     { StageTimer t(c, ETHCNN_STAGE_TRUNK); launch_trunk(c->ws, c->dw, n, false, c->stream); }
     { StageTimer t(c, ETHCNN_STAGE_FC1); launch_fc1(c->ws, c->dw, n, c->ws.h1, c->stream); }
-    { StageTimer t(c, ETHCNN_STAGE_HEADS); launch_heads(c->ws, c->dw, n, qn, g.nctu, ctu0, c->thr1, c->thr2, d_probs_pass, c->stream); }
+    Workspace wv = c->ws;
+    if (!c->debug_capture) wv.h2 = wv.logits = wv.raw = nullptr;
+    { StageTimer t(c, ETHCNN_STAGE_HEADS); launch_heads(wv, c->dw, n, qn, g.nctu, ctu0, c->thr1, c->thr2, d_probs_pass, c->stream); }
     { StageTimer t(c, ETHCNN_STAGE_GATE); launch_gate(c->ws, n, g.nctu, ctu0, c->thr2, d_probs_pass, c->stream); }
     HIPCHK(c, hipGetLastError());
     c->times.ctus += n;
@@ -835,7 +838,9 @@ extern "C" int ethcnn_lstm_step_device(ethcnn_ctx* c, const float* d_vec, const 
     HIPCHK(c, hipMemsetAsync(c->ws.flags, 0, (size_t)chunks * 2 * sizeof(int), c->stream));
     {
         StageTimer t(c, ETHCNN_STAGE_HEADS);
-        launch_lstm(d_vec, d_state_in, d_state_out, c->d_lstm, n, qp, i_frame, c->thr1, c->thr2, c->ws, d_probs, c->stream);
+        Workspace wv = c->ws;
+        if (!c->debug_capture) wv.raw = nullptr;
+        launch_lstm(d_vec, d_state_in, d_state_out, c->d_lstm, n, qp, i_frame, c->thr1, c->thr2, wv, d_probs, c->stream);
     }
     {
         StageTimer t(c, ETHCNN_STAGE_GATE);
@@ -902,8 +907,16 @@ extern "C" int ethcnn_synchronize(ethcnn_ctx* c) {
     return ETHCNN_OK;
 }
 
+extern "C" int ethcnn_set_debug_capture(ethcnn_ctx* c, int on) {
+    if (!c) return ETHCNN_ERR_ARG;
+    c->debug_capture = (on != 0);
+    return ETHCNN_OK;
+}
+
 extern "C" int ethcnn_debug_fetch(ethcnn_ctx* c, int which, float* out, size_t nfloats) {
     if (!c || !out) return ETHCNN_ERR_ARG;
+    if (which >= ETHCNN_DBG_FC2 && which <= ETHCNN_DBG_RAW_PROBS && !c->debug_capture)
+        return set_err(c, ETHCNN_ERR_ARG, "debug_fetch(%d): call ethcnn_set_debug_capture(ctx, 1) before the pass", which);
     const float* src = nullptr;
     size_t per = 0;
     switch (which) {

@@ -187,8 +187,8 @@ __device__ __forceinline__ void head_pass(float* smem, const float* __restrict__
             const float zz = fmaf(qn, W3[D::N2 * D::N3 + o], z[r]) + hp.b3[H][o];
             const float p = 1.0f / (1.0f + expf_canonical_h(-zz));
             const size_t idx = (size_t)ctu * kNOut + D::O3 + o;
-            logits[idx] = zz;
-            raw[idx] = p;
+            if (logits) logits[idx] = zz;  // introspection copies (ethcnn_set_debug_capture), null in production
+            if (raw) raw[idx] = p;
             probs[idx] = p;
             if (H == 0 && p > thr1 && __hip_atomic_load(flag32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
                 __hip_atomic_store(flag32, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // any(y64 > THR_L1_LOWER)

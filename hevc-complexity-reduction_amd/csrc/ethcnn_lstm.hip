@@ -211,7 +211,7 @@ __device__ __forceinline__ void lstm_heads(const LstmParams& lp, const float* __
                 for (int e = 0; e < 5; ++e) zz = fmaf(lp.efs[e], W3[(N2 + e) * N3 + o], zz);
                 const float p = sigmoid_l(zz + b3[o]);
                 const size_t idx = (size_t)ctu * kNOut + O3 + o;
-                raw[idx] = p;
+                if (raw) raw[idx] = p;
                 probs[idx] = p;
                 if (LV == 0 && p > thr1 && __hip_atomic_load(flag32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
                     __hip_atomic_store(flag32, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -84,6 +84,7 @@ SIGNATURES = {
     "ethcnn_get_stage_times": (_i, [_vp, ctypes.POINTER(StageTimes)]),
     "ethcnn_reset_stage_times": (_i, [_vp]),
     "ethcnn_debug_fetch": (_i, [_vp, _i, _fp, _sz]),
+    "ethcnn_set_debug_capture": (_i, [_vp, _i]),
     "ethcnn_ckpt_read_index": (_i, [_cp, ctypes.POINTER(CkptEntry), _i, ctypes.POINTER(_i), ctypes.c_char_p, _sz]),
     "ethcnn_crc32c_masked": (ctypes.c_uint32, [_vp, _sz]),
 }
@@ -387,6 +388,10 @@ class EthCnn(object):
         st = StageTimes()
         self._chk(self.lib.ethcnn_get_stage_times(self.h, ctypes.byref(st)))
         return {"ms": dict(zip(STAGES, list(st.ms))), "launches": dict(zip(STAGES, list(st.launches))), "ctus": st.ctus}
+
+    def set_debug_capture(self, on=True):
+        """store FC2 outputs, logits and ungated probabilities of the following passes (debug_fetch)"""
+        self._chk(self.lib.ethcnn_set_debug_capture(self.h, 1 if on else 0))
 
     def debug_fetch(self, which, n):
         out = np.empty((n, _DBG_WIDTH[which]), dtype=np.float32)

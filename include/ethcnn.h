@@ -169,6 +169,9 @@ enum {
     ETHCNN_DBG_RAW_PROBS = 4 /* [n][21]   before the gates                      */
 };
 int ethcnn_debug_fetch(ethcnn_ctx* ctx, int which, float* host_out, size_t nfloats);
+/* FC2 / LOGITS / RAW_PROBS are only stored when capture is on (off by default: 1.7 KB/CTU of HBM
+ * writes nobody reads in production); FEATURES and FC1 are the path's own buffers, always there. */
+int ethcnn_set_debug_capture(ethcnn_ctx* ctx, int on);
 
 /* ---- checkpoint introspection (the TF-V2 bundle reader on its own; used by the loader
  *      above and by the known-answer tests against the reference's .index files). */

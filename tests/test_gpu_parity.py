@@ -31,6 +31,11 @@ def test_stages_bit_exact(pkg, ctx, oracle, n, gain, qp):
     ctx.load_blob(blob)
     ctx.set_thresholds(0.5, 0.5)
     ctus = _mixed_ctus(rng, n)
+    with pytest.raises(e.EthCnnError):  # logits are not stored unless capture is on
+        ctx.set_debug_capture(False)
+        ctx.predict_ctus(ctus, qp)
+        ctx.debug_fetch(e.DBG_LOGITS, n)
+    ctx.set_debug_capture(True)
     got = ctx.predict_ctus(ctus, qp)
     F = oracle.features(blob, ctus, mode=0)
     H1 = oracle.fc1(blob, F)
@@ -43,8 +48,10 @@ def test_stages_bit_exact(pkg, ctx, oracle, n, gain, qp):
     assert np.array_equal(_bits(gZ), _bits(Z)), "logits: max |d| = %g" % np.abs(gZ - Z).max()
     gP = ctx.debug_fetch(e.DBG_RAW_PROBS, n)
     assert np.array_equal(_bits(gP), _bits(P)), "probs: max |d| = %g" % np.abs(gP - P).max()
+    ctx.set_debug_capture(False)
     want = oracle.gates(P, 0.5, 0.5)
     assert np.array_equal(_bits(got), _bits(want))
+    assert np.array_equal(_bits(ctx.predict_ctus(ctus, qp)), _bits(want))  # same result without the capture stores
     # tolerance the north star states (1e-4) against the independent float64 restatement
     r = oracle.forward64(blob, ctus, qp)
     assert np.abs(gP - r["probs"]).max() <= 1e-4
