@@ -5,12 +5,16 @@
  * and bench.py's cpu_baseline leg may load it.  The shipped path (libethcnn.so) never
  * links, includes or calls anything in oracle/.
  *
- * PARITY STATUS: *unpinned against the reference implementation itself*.  The reference's
- * arithmetic lives in TensorFlow 1.x (not vendored, not installed here, no network) and
- * every trained ETH-CNN weight blob is absent from /root/reference (.MISSING_LARGE_BLOBS),
- * and the reference holds no golden vectors for this path.  What IS pinned:
- *   - constants / strides / shapes against the reference's own .meta graph (tests/golden/
- *     meta_constants.json, extracted by tests/golden/gen_meta_constants.py),
+ * PARITY STATUS: pinned to the reference's own SERIALIZED TensorFlow graphs, *unpinned against a
+ * TensorFlow binary*.  The reference's arithmetic lives in TensorFlow 1.x (not vendored, not
+ * installed here, no network), every trained ETH-CNN weight blob is absent from /root/reference
+ * (.MISSING_LARGE_BLOBS) and the reference holds no golden vectors for this path.  What IS pinned:
+ *   - the MetaGraphDefs TF 1.4.1 wrote from the authors' graphs (the .meta files next to the
+ *     checkpoints), executed node by node without TensorFlow by tests/meta_graph.py: golden
+ *     vectors tests/golden/meta_exec_golden.npz (gen_meta_exec_golden.py); this file agrees to
+ *     <= 1e-6 on features, ungated probabilities and the LDP 448-vectors (tests/test_meta_graph.py).
+ *     Not covered by a saved graph: the threshold gates (net_CNN.py:175,187) and the LSTM cell;
+ *   - constants / strides / shapes against the same .meta (tests/golden/meta_constants.json),
  *   - tensor names / shapes / offsets against the reference's .index files,
  *   - an independent PyTorch-CPU restatement and an independent numpy float64 restatement
  *     (tests/golden/gen_golden.py), both written from the reference .py, agree with this

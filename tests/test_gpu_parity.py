@@ -193,3 +193,23 @@ def test_full_size_c2(pkg, oracle):
 def test_full_size_c3(pkg, oracle, qp):
     """BASELINE.json configs[2]: 3840x2160 x 50 frames (102,000 CTUs; sub-batches 1024 + 1016)."""
     _full_size_case(pkg, oracle, 3840, 2160, 50, qp, sample_frames=(0, 31))
+
+
+def test_against_reference_graph_golden(ctx, oracle):
+    """HIP path vs vectors produced by executing the reference's own serialized TF graphs
+    (tests/golden/meta_exec_golden.npz; tests/test_meta_graph.py explains them): <= 1e-5."""
+    import os
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "meta_exec_golden.npz"))
+    ctx.set_thresholds(-1.0, -1.0)  # the saved graph has no gates: compare ungated probabilities
+    for tag in ("ai_a", "ai_b"):
+        seed, gain, qp = gold[tag + "_seed_gain_qp"]
+        ctx.load_blob(oracle.synth_blob(int(seed), float(gain)))
+        got = ctx.predict_ctus(gold[tag + "_ctus"], int(qp))
+        assert np.abs(got - gold[tag + "_probs"]).max() <= 1e-5
+    seed, gain = gold["ldp_seed_gain"]
+    ctx.load_blob(oracle.synth_blob(int(seed), float(gain)))
+    ctus = gold["ldp_ctus"]
+    luma = np.ascontiguousarray(ctus.transpose(1, 0, 2).reshape(64, -1))
+    vec = ctx.resi_vectors(luma, 64 * ctus.shape[0], 64)
+    assert np.abs(vec - gold["ldp_vec"]).max() <= 1e-5
+    ctx.set_thresholds(0.5, 0.5)
