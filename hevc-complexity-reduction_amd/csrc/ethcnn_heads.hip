@@ -6,8 +6,8 @@
 // One wave = 16 CTUs, "transposed": MFMA rows = output features, columns = CTUs.
 //   FC2^T: A operand = W2 (16-k chunks by LDS-DMA, shared by the block's 4 waves, 3 stages),
 //          B operand = this wave's h1 rows, one float4 per lane per chunk (element e feeds MFMA
-//          step e -> k order 16c + 4g + e, the canonical FC order).  Heads run one after the other
-//          (16, 32, 64) so only one head's accumulators are live.
+//          step e -> k order 16c + 4g + e, the canonical FC order).  One block = one head of a
+//          64-CTU tile (blockIdx.y = head, 16 first): short per-block latency, three times the blocks.
 //   The FC2^T accumulator of lane (ctu, g) holds h2[ctu][16t + 4g + r]: exactly the B operand
 //   FC3^T needs for step (t, r) -- so FC2 -> FC3 chains in registers (same k order), no LDS,
 //   no HBM round trip.  FC3^T's A operand (W3, 3525 floats in all) comes straight from L1/L2.
@@ -212,9 +212,15 @@ __global__ __launch_bounds__(256) void k_heads(const float* __restrict__ H1, Hea
     const float* h1row = H1 + (size_t)ctu * kNVec;
     float* h2row = H2 ? H2 + (size_t)ctu * kNFc2 : nullptr;
     int* fl = flags + 2 * (gchunk(ctu0 + ctu, nctu, cpf) - gchunk(ctu0, nctu, cpf));
-    head_pass<2>(smem, h1row, hp, qn, lane, wvu, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
-    head_pass<1>(smem, h1row, hp, qn, lane, wvu, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
-    head_pass<0>(smem, h1row, hp, qn, lane, wvu, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
+    // blockIdx.y selects the head: the three heads of a 64-CTU tile are independent (each reads its own
+    // column slice of h1), so they run as separate blocks -- head 16 (16 K chunks) is dispatched first,
+    // the short heads 32 / 64 fill in behind it.  A third of the per-block latency, three times the blocks.
+    if (blockIdx.y == 0)
+        head_pass<2>(smem, h1row, hp, qn, lane, wvu, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
+    else if (blockIdx.y == 1)
+        head_pass<1>(smem, h1row, hp, qn, lane, wvu, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
+    else
+        head_pass<0>(smem, h1row, hp, qn, lane, wvu, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
 }
 
 void launch_heads(const Workspace& ws, const DeviceWeights& w, int n, float qn, int nctu, long ctu0, float thr1,
@@ -226,7 +232,7 @@ void launch_heads(const Workspace& ws, const DeviceWeights& w, int n, float qn, 
         hp.w3[h] = w.fc3_w[h];
         hp.b3[h] = w.fc3_b[h];
     }
-    hipLaunchKernelGGL(k_heads, dim3((n + 63) / 64), dim3(256), 0, s, ws.h1, hp, qn, n, nctu, chunks_per_frame(nctu),
+    hipLaunchKernelGGL(k_heads, dim3((n + 63) / 64, 3), dim3(256), 0, s, ws.h1, hp, qn, n, nctu, chunks_per_frame(nctu),
                        ctu0, thr1, thr2, ws.h2, ws.logits, ws.raw, d_probs, ws.flags);
 }
 
