@@ -460,8 +460,7 @@ static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, lo
     int rc = ensure_workspace(c, n, (int)nchunks);
     if (rc) return rc;
     const float qn = (float)qp * (1.0f / 51.0f);  // net_CNN.py:106
-    HIPCHK(c, hipMemsetAsync(c->ws.flags, 0, (size_t)nchunks * 2 * sizeof(int), c->stream));
-    { StageTimer t(c, ETHCNN_STAGE_TILE); launch_tile(d_luma, g, ctu0, n, c->ws, c->stream); }
+    { StageTimer t(c, ETHCNN_STAGE_TILE); launch_tile(d_luma, g, ctu0, n, c->ws, (int)nchunks * 2, c->stream); }
     { StageTimer t(c, ETHCNN_STAGE_TRUNK); launch_trunk(c->ws, c->dw, n, false, c->stream); }
     { StageTimer t(c, ETHCNN_STAGE_FC1); launch_fc1(c->ws, c->dw, n, c->ws.h1, c->stream); }
     Workspace wv = c->ws;
@@ -740,7 +739,7 @@ extern "C" int ethcnn_resi_vectors_device(ethcnn_ctx* c, const uint8_t* d_luma, 
         const int n = std::min(c->max_ctus, g.nctu - o);
         rc = ensure_workspace(c, n, 1);
         if (rc) return rc;
-        { StageTimer t(c, ETHCNN_STAGE_TILE); launch_tile(d_luma, g, o, n, c->ws, c->stream); }
+        { StageTimer t(c, ETHCNN_STAGE_TILE); launch_tile(d_luma, g, o, n, c->ws, 0, c->stream); }
         { StageTimer t(c, ETHCNN_STAGE_TRUNK); launch_trunk(c->ws, c->dw, n, true, c->stream); }
         { StageTimer t(c, ETHCNN_STAGE_FC1); launch_fc1(c->ws, c->dw, n, d_vec + (size_t)o * kNVec, c->stream); }
         HIPCHK(c, hipGetLastError());

@@ -27,8 +27,10 @@ struct FrameGeom {
     int cw, ch, nctu;  // CTUs per row / column / frame
 };
 
-// k0: luma frames -> xs/xm/xl for CTUs [ctu0, ctu0 + n) of the frame sequence
-void launch_tile(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, const Workspace& ws, hipStream_t s);
+// k0: luma frames -> xs/xm/xl for CTUs [ctu0, ctu0 + n) of the frame sequence; also clears the first
+// n_flags ints of ws.flags (the pass's gate predicates; 0 = leave them alone)
+void launch_tile(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, const Workspace& ws, int n_flags,
+                 hipStream_t s);
 // k1: xs/xm/xl -> feat
 void launch_trunk(const Workspace& ws, const DeviceWeights& w, int n, bool resi, hipStream_t s);
 // k2: feat -> h1 (bias + leaky-ReLU fused); out may be ws.h1 or a caller buffer (resi vectors)

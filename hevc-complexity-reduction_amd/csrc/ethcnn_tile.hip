@@ -26,10 +26,14 @@ template <bool FAST>
 __global__ __launch_bounds__(256) void k0_tile(const uint8_t* __restrict__ luma, int width, int height, long pitch,
                                                long frame_stride, int cw, int nctu, long ctu0, int n_total,
                                                uint4* __restrict__ XS, uint4* __restrict__ XM,
-                                               uint4* __restrict__ XL) {
+                                               uint4* __restrict__ XL, int* __restrict__ gate_flags, int n_flags) {
     __shared__ uint32_t tile[16 * kCtuPitch];
     const int t = threadIdx.x;
     const int grp = blockIdx.x, n0 = grp * 16;
+    // first kernel of a pass: clear the pass's gate predicates (set by the heads kernel, two
+    // kernels later) here instead of in a separate memset launch
+    if (grp == 0)
+        for (int i = t; i < n_flags; i += 256) gate_flags[i] = 0;
 
     // ---- load 16 CTUs (zero outside the frame / beyond n_total): thread -> (row, 16-B segment)
     {
@@ -133,16 +137,17 @@ __global__ __launch_bounds__(256) void k0_tile(const uint8_t* __restrict__ luma,
 #undef PX
 }
 
-void launch_tile(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, const Workspace& ws, hipStream_t s) {
+void launch_tile(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, const Workspace& ws, int n_flags,
+                 hipStream_t s) {
     const int blocks = (n + 15) / 16;
     const bool fast = (g.width % 16 == 0) && (g.pitch % 16 == 0) && (g.frame_stride % 16 == 0) &&
                       (reinterpret_cast<uintptr_t>(d_luma) % 16 == 0);
     if (fast)
         hipLaunchKernelGGL(k0_tile<true>, dim3(blocks), dim3(256), 0, s, d_luma, g.width, g.height, g.pitch,
-                           g.frame_stride, g.cw, g.nctu, ctu0, n, ws.xs, ws.xm, ws.xl);
+                           g.frame_stride, g.cw, g.nctu, ctu0, n, ws.xs, ws.xm, ws.xl, ws.flags, n_flags);
     else
         hipLaunchKernelGGL(k0_tile<false>, dim3(blocks), dim3(256), 0, s, d_luma, g.width, g.height, g.pitch,
-                           g.frame_stride, g.cw, g.nctu, ctu0, n, ws.xs, ws.xm, ws.xl);
+                           g.frame_stride, g.cw, g.nctu, ctu0, n, ws.xs, ws.xm, ws.xl, ws.flags, n_flags);
 }
 
 }  // namespace ethcnn
