@@ -1,0 +1,17 @@
+#!/bin/bash
+# GPU box: the HM encoder built by scripts/build_hm_inprocess.sh (predictor called in process through
+# the C ABI) encodes the small synthetic sequence; outputs land in gpurun_out/hm_inprocess/ for
+# scripts/hm_inprocess_check.py (run where the reference's prebuilt HM lives).
+set -eu
+REPO=$PWD
+python scripts/make_hm_case.py | tail -1
+D=$REPO/gpurun_out/hm_inprocess
+rm -rf $D; mkdir -p $D
+cp gpurun_out/hm/seq.yuv gpurun_out/hm/Thr_info.txt $D/
+cd $D
+ETHCNN_SYNTHETIC_SEED=9 ETHCNN_HEAD_GAIN=8.0 $REPO/build/hm_inprocess/TAppEncoderInProcess -c $REPO/scripts/hm_intra_test.cfg \
+    -i seq.yuv -wdt 416 -hgt 240 -fr 30 -f 4 -q 32 -b str.bin -o "" > encode.log 2>&1 || { tail -5 encode.log; exit 1; }
+grep -E "ethcnn|Total Time|Bytes written" encode.log
+cmp cu_depth.dat $REPO/gpurun_out/hm/cu_depth_gpu.dat && echo "cu_depth.dat (in-process) == cu_depth.dat (python launcher)"
+md5sum str.bin
+rm -f seq.yuv
