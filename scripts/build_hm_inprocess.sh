@@ -12,6 +12,7 @@ B="$REPO/build/hm_inprocess"
 rm -rf "$B"; mkdir -p "$B/obj"
 cp -r "$REF/source" "$B/source"
 chmod -R u+w "$B/source"
+cp "$B/source/App/TAppEncoder/TAppEncCfg.cpp" "$B/TAppEncCfg_unchanged.cpp"
 python3 - "$B/source/App/TAppEncoder/TAppEncCfg.cpp" <<'PY'
 import re, sys
 p = sys.argv[1]
@@ -30,5 +31,11 @@ echo "$SRCS" | tr ' ' '\n' | xargs -P 8 -I{} sh -c 'o=obj/$(echo {} | tr "/" "_"
 gcc -std=c99 -O2 -D_POSIX_C_SOURCE=200809L -I"$REPO/include" -c "$REPO/tools/hm_inprocess_hook.c" -o obj/hm_inprocess_hook.o
 g++ -o TAppEncoderInProcess obj/*.o -L"$REPO/hevc-complexity-reduction_amd/lib" -lethcnn -lpthread -ldl \
     -Wl,-rpath,'$ORIGIN/../../hevc-complexity-reduction_amd/lib' -Wl,-rpath,/opt/rocm/lib
-rm -rf "$B/source" "$B/obj"     # keep only the binary
+# the same objects with the UNCHANGED TAppEncCfg.cpp: the reference's encoder as is (its hook runs
+# `python video_to_cu_depth.py ...`), for the full drop-in run on the GPU box
+cp TAppEncCfg_unchanged.cpp source/App/TAppEncoder/TAppEncCfg.cpp
+g++ $FLAGS -c source/App/TAppEncoder/TAppEncCfg.cpp -o obj/source_App_TAppEncoder_TAppEncCfg.cpp.o
+rm -f obj/hm_inprocess_hook.o
+g++ -o TAppEncoderUnchanged obj/*.o -lpthread -ldl
+rm -rf "$B/source" "$B/obj" "$B/TAppEncCfg_unchanged.cpp"     # keep only the binaries
 ls -la "$B"

@@ -14,4 +14,13 @@ ETHCNN_SYNTHETIC_SEED=9 ETHCNN_HEAD_GAIN=8.0 $REPO/build/hm_inprocess/TAppEncode
 grep -E "ethcnn|Total Time|Bytes written" encode.log
 cmp cu_depth.dat $REPO/gpurun_out/hm/cu_depth_gpu.dat && echo "cu_depth.dat (in-process) == cu_depth.dat (python launcher)"
 md5sum str.bin
-rm -f seq.yuv
+# the reference's encoder UNCHANGED: its hook spawns `python video_to_cu_depth.py <yuv> <w> <h> <qp>` in the cwd
+U=$REPO/gpurun_out/hm_unchanged
+rm -rf $U; mkdir -p $U; cp seq.yuv Thr_info.txt $U/; cd $U
+ln -s $REPO/video_to_cu_depth.py video_to_cu_depth.py
+ETHCNN_SYNTHETIC_SEED=9 ETHCNN_HEAD_GAIN=8.0 $REPO/build/hm_inprocess/TAppEncoderUnchanged -c $REPO/scripts/hm_intra_test.cfg \
+    -i seq.yuv -wdt 416 -hgt 240 -fr 30 -f 4 -q 32 -b str.bin -o "" > encode.log 2>&1 || { tail -5 encode.log; exit 1; }
+grep -E "Predicting Time|Total Time|Bytes written" encode.log
+cmp str.bin $D/str.bin && echo "unchanged HM + drop-in launcher: bitstream == in-process build"
+md5sum str.bin
+rm -f seq.yuv $D/seq.yuv
