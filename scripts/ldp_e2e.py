@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """End-to-end Low-Delay-P run with the reference's REAL encoder side of the handshake:
-build/hm_ldp/TAppEncoderLDP (HM-16.5_Test_LDP built unchanged by scripts/build_hm_ldp.sh) encodes a
+oracle/_ref/hm_ldp/TAppEncoderLDP (HM-16.5_Test_LDP built unchanged by oracle/build_ref_hm.sh) encodes a
 synthetic moving sequence while a predictor daemon answers its command.dat / pred_start.sig requests.
 
     ldp_e2e.py gpu    <outdir>   daemon = hevc-complexity-reduction_amd/resi_to_cu_depth_LDP.serve (MI355X)
@@ -104,7 +104,7 @@ def main():
     th = threading.Thread(target=(gpu_daemon if mode == "gpu" else oracle_daemon), args=(work, FRAMES - 1, log), daemon=True)
     th.start()
     time.sleep(3.0 if mode == "gpu" else 0.5)  # the reference's daemon is started by hand before the encoder, too
-    exe = os.path.join(ROOT, "build", "hm_ldp", "TAppEncoderLDP")
+    exe = os.path.join(ROOT, "oracle", "_ref", "hm_ldp", "TAppEncoderLDP")
     t0 = time.time()
     r = subprocess.run([exe, "-c", os.path.join(ROOT, "scripts", "hm_ldp_test.cfg"), "-i", "seq.yuv", "-wdt", str(W), "-hgt", str(H),
                         "-fr", "30", "-f", str(FRAMES), "-q", str(QP), "-b", "str.bin", "-o", ""],

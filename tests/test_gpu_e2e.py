@@ -1,0 +1,71 @@
+"""-m gpu: end to end with the reference's OWN encoders (oracle/_ref, built from the sources under
+/root/reference by oracle/build_ref_hm.sh in the build container; the binaries travel to the GPU
+box).  Skipped when they are absent."""
+import hashlib
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref")
+HM_AI = os.path.join(REF, "hm_ai", "TAppEncoderUnchanged")
+HM_INPROC = os.path.join(REF, "hm_ai", "TAppEncoderInProcess")
+HM_LDP = os.path.join(REF, "hm_ldp", "TAppEncoderLDP")
+
+
+def _encode(exe, cwd, w, h, frames, qp, env):
+    r = subprocess.run([exe, "-c", os.path.join(ROOT, "scripts", "hm_intra_test.cfg"), "-i", "seq.yuv", "-wdt", str(w), "-hgt", str(h),
+                        "-fr", "30", "-f", str(frames), "-q", str(qp), "-b", "str.bin", "-o", ""],
+                       cwd=str(cwd), env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    return hashlib.md5(open(os.path.join(str(cwd), "str.bin"), "rb").read()).hexdigest(), r.stdout
+
+
+@pytest.mark.skipif(not (os.path.exists(HM_AI) and os.path.exists(HM_INPROC)), reason="oracle/_ref/hm_ai not built")
+def test_all_intra_drop_in_with_the_reference_encoder(oracle, tmp_path):
+    """The whole drop-in: the reference's unchanged HM runs `python video_to_cu_depth.py <yuv> <w> <h> <qp>`
+    (TAppEncCfg.cpp:2317-2321) in its cwd, where that name is a symlink to this repository's launcher;
+    cu_depth.dat is bit-exact vs the oracle, HM consumes it, and the in-process hook build (SURVEY 8f
+    row 3) produces the same file and the same bitstream."""
+    sys.path.insert(0, ROOT)
+    import bench
+    w, h, frames, qp, seed, gain = 416, 240, 3, 32, 9, 8.0
+    luma = bench.synth_luma(w, h, frames, 1)
+    yuv = np.concatenate([np.concatenate([luma[f].reshape(-1), np.full(w * h // 2, 128, np.uint8)]) for f in range(frames)])
+    env = dict(os.environ, ETHCNN_SYNTHETIC_SEED=str(seed), ETHCNN_HEAD_GAIN=str(gain), ETHCNN_HOME=ROOT)
+    md5 = {}
+    for tag, exe in (("unchanged", HM_AI), ("inprocess", HM_INPROC)):
+        d = tmp_path / tag
+        d.mkdir()
+        yuv.tofile(str(d / "seq.yuv"))
+        (d / "Thr_info.txt").write_text("0.5 0.5 0.5 0.5 0.5 0.5")
+        if tag == "unchanged":
+            os.symlink(os.path.join(ROOT, "video_to_cu_depth.py"), str(d / "video_to_cu_depth.py"))
+        md5[tag], out = _encode(exe, d, w, h, frames, qp, env)
+        got = np.fromfile(str(d / "cu_depth.dat"), dtype="<f4").reshape(-1, 21)
+        want = oracle.predict_frames(oracle.synth_blob(seed, gain), yuv, w, h, frames, qp, 0.5, 0.5, frame_stride=w * h * 3 // 2)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), tag
+        assert ("Predicting Time" in out) if tag == "unchanged" else ("ethcnn (in-process)" in out)
+    assert md5["unchanged"] == md5["inprocess"]
+
+
+@pytest.mark.skipif(not os.path.exists(HM_LDP), reason="oracle/_ref/hm_ldp not built")
+def test_low_delay_p_with_the_reference_encoder(tmp_path):
+    """scripts/ldp_e2e.py: the reference's unchanged HM-LDP encoder against the daemon on the GPU and
+    against the oracle-backed daemon on the host: identical per-frame cu_depth.dat / state.dat and
+    identical bitstreams (real motion-compensated residuals, trained LSTM weights, 5 recurrent steps)."""
+    res = {}
+    for mode in ("gpu", "oracle"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "ldp_e2e.py"), mode, str(tmp_path)],
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        res[mode] = json.load(open(str(tmp_path / (mode + ".json"))))
+    assert len(res["gpu"]["per_frame_crc"]) == 5
+    assert res["gpu"]["per_frame_crc"] == res["oracle"]["per_frame_crc"]
+    assert res["gpu"]["bitstream_md5"] == res["oracle"]["bitstream_md5"]
