@@ -126,7 +126,8 @@ struct ethcnn_ctx {
     int last_n = 0;  // CTUs of the last pass (debug_fetch)
     bool debug_capture = false;  // also store FC2 outputs, logits and ungated probabilities (1.7 KB/CTU of writes)
 
-    int profiling = 0;  // 0 off, 1 dominant kernel (FC1) only, 2 every stage
+    int profiling = 0;  // 0 off, 1 dominant kernel (FC1) on every 4th pass, 2 every stage
+    unsigned fc1_sample = 0;
     struct Ev { hipEvent_t a, b; int stage; };
     std::vector<Ev> pending;
     std::vector<hipEvent_t> ev_pool;
@@ -392,7 +393,7 @@ struct StageTimer {
     hipEvent_t a = nullptr, b = nullptr;
     bool on;
     StageTimer(ethcnn_ctx* c_, int st) : c(c_), stage(st) {
-        on = c->profiling >= (st == ETHCNN_STAGE_FC1 ? 1 : 2);
+        on = c->profiling >= 2 || (c->profiling == 1 && st == ETHCNN_STAGE_FC1 && (c->fc1_sample++ & 3) == 0);
         if (on) {
             a = get_event(c);
             b = get_event(c);
@@ -403,6 +404,7 @@ struct StageTimer {
         if (on) {
             (void)hipEventRecord(b, c->stream);
             c->pending.push_back({a, b, stage});
+            c->times.timed[stage]++;
         }
         c->times.launches[stage]++;
     }
@@ -421,6 +423,7 @@ extern "C" int ethcnn_set_profiling(ethcnn_ctx* c, int on) {
     if (!c) return ETHCNN_ERR_ARG;
     drain_events(c);
     c->profiling = on < 0 ? 0 : (on > 2 ? 2 : on);
+    c->fc1_sample = 0;  // the first pass after this call is a timed one
     return ETHCNN_OK;
 }
 extern "C" int ethcnn_get_stage_times(ethcnn_ctx* c, ethcnn_stage_times* out) {

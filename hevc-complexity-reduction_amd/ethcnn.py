@@ -33,7 +33,8 @@ class Options(ctypes.Structure):
 
 
 class StageTimes(ctypes.Structure):
-    _fields_ = [("ms", ctypes.c_double * 5), ("launches", ctypes.c_int64 * 5), ("ctus", ctypes.c_int64)]
+    _fields_ = [("ms", ctypes.c_double * 5), ("launches", ctypes.c_int64 * 5), ("ctus", ctypes.c_int64),
+                ("timed", ctypes.c_int64 * 5)]
 
 
 class CkptEntry(ctypes.Structure):
@@ -387,7 +388,8 @@ class EthCnn(object):
     def stage_times(self):
         st = StageTimes()
         self._chk(self.lib.ethcnn_get_stage_times(self.h, ctypes.byref(st)))
-        return {"ms": dict(zip(STAGES, list(st.ms))), "launches": dict(zip(STAGES, list(st.launches))), "ctus": st.ctus}
+        return {"ms": dict(zip(STAGES, list(st.ms))), "launches": dict(zip(STAGES, list(st.launches))), "ctus": st.ctus,
+                "timed": dict(zip(STAGES, list(st.timed)))}
 
     def set_debug_capture(self, on=True):
         """store FC2 outputs, logits and ungated probabilities of the following passes (debug_fetch)"""

@@ -154,9 +154,10 @@ typedef struct ethcnn_stage_times {
     double ms[ETHCNN_NSTAGES];       /* accumulated kernel time per stage since reset */
     int64_t launches[ETHCNN_NSTAGES];
     int64_t ctus;                    /* CTUs processed since reset */
+    int64_t timed[ETHCNN_NSTAGES];   /* launches whose time is in ms[] (level 1 samples every 4th FC1 stage) */
 } ethcnn_stage_times;
-int ethcnn_set_profiling(ethcnn_ctx* ctx, int level); /* 0 off; 1 events around the dominant kernel (FC1) only;
-                                                          2 around every launch (each event pair costs ~5 us of stream time) */
+int ethcnn_set_profiling(ethcnn_ctx* ctx, int level); /* 0 off; 1 events around the dominant kernel (FC1) on every 4th
+                                                          pass (an event pair costs ~12 us of stream time); 2 around every launch */
 int ethcnn_get_stage_times(ethcnn_ctx* ctx, ethcnn_stage_times* out); /* synchronizes */
 int ethcnn_reset_stage_times(ethcnn_ctx* ctx);
 
