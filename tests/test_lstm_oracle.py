@@ -109,3 +109,21 @@ def test_lstm_bundle_errors(pkg, tmp_path):
     with pytest.raises(e.EthCnnError) as ei:
         e.read_ckpt_lstm_blob(str(tmp_path / "c.dat"))
     assert "crc32c" in str(ei.value)
+
+
+def test_trained_weights_fit_the_i_j_f_o_gate_order(lstm):
+    """Circumstantial check of TF's LSTMCell gate layout (i, j, f, o = input, candidate, forget, output
+    quarters of the fused kernel/bias) on the reference's trained weights: in all three cells the
+    candidate quarter (the only tanh branch) has clearly the largest bias spread and kernel column norm,
+    and the forget quarter (which gets +1.0 at run time) the most negative mean bias.  With PyTorch's
+    (i, f, g, o) layout the odd quarter out would be the third, not the second."""
+    blob = np.fromfile(REAL + ".data-00000-of-00001", dtype=np.float32)
+    tv = lstm.lstm_views(blob)
+    for tag, n in (("64", 64), ("32", 128), ("16", 256)):
+        b = tv["RNN%s/multi_rnn_cell/cell_0/lstm_cell/bias" % tag]
+        K = tv["RNN%s/multi_rnn_cell/cell_0/lstm_cell/kernel" % tag]
+        std = [float(b[i * n:(i + 1) * n].std()) for i in range(4)]
+        norm = [float(np.linalg.norm(K[:, i * n:(i + 1) * n], axis=0).mean()) for i in range(4)]
+        mean = [float(b[i * n:(i + 1) * n].mean()) for i in range(4)]
+        assert int(np.argmax(std)) == 1 and int(np.argmax(norm)) == 1, (tag, std, norm)
+        assert int(np.argmin(mean)) == 2, (tag, mean)
