@@ -213,3 +213,26 @@ def test_against_reference_graph_golden(ctx, oracle):
     vec = ctx.resi_vectors(luma, 64 * ctus.shape[0], 64)
     assert np.abs(vec - gold["ldp_vec"]).max() <= 1e-5
     ctx.set_thresholds(0.5, 0.5)
+
+
+def test_empty_and_degenerate_inputs(pkg, ctx, oracle, tmp_path):
+    """zero frames, an empty YUV file (the reference writes an empty cu_depth.dat and exits 0), a
+    1x1-pixel frame, bad geometry"""
+    e = pkg.ethcnn
+    blob = oracle.synth_blob(2, 8.0)
+    ctx.load_blob(blob)
+    assert ctx.predict_luma(np.zeros(0, np.uint8), 64, 64, 0, 32).shape == (0, 21)
+    yuv = tmp_path / "empty.yuv"
+    yuv.write_bytes(b"")
+    assert ctx.predict_yuv_file(str(yuv), 416, 240, 32, str(tmp_path / "cu_depth.dat")) == 0
+    assert (tmp_path / "cu_depth.dat").stat().st_size == 0
+    one = np.array([[200]], dtype=np.uint8)  # a single pixel: one CTU, 4095 zero-padded samples
+    got = ctx.predict_luma(one, 1, 1, 1, 32)
+    assert np.array_equal(_bits(got), _bits(oracle.predict_frames(blob, one, 1, 1, 1, 32, 0.5, 0.5, mode=0)))
+    for w, h, pitch in ((0, 64, 64), (64, 0, 64), (-3, 64, 64), (64, 64, 32)):
+        with pytest.raises((e.EthCnnError, ValueError)):
+            ctx.predict_luma(np.zeros(64 * 64, np.uint8), w, h, 1, 32, pitch=pitch)
+    with pytest.raises(e.EthCnnError):  # file size not a multiple of the frame size (video_to_cu_depth.py:137 assert)
+        yuv.write_bytes(b"\0" * 1000)
+        ctx.predict_yuv_file(str(yuv), 416, 240, 32, str(tmp_path / "x.dat"))
+    assert not (tmp_path / "x.dat").exists()
