@@ -190,23 +190,13 @@ def main():
             if world == 1 and not args.no_cpu_baseline:
                 result["cpu_baseline"] = cpu_baseline_ldp(luma, W, H, QP, args.cpu_seconds)
             result["parity_first_frames_bit_exact"] = ldp_parity(ctx, luma, W, H, QP)
-            print(json.dumps(result))
-            sys.stdout.flush()
-            ctx.close()
-            return 0
-        if world == 1 and not args.no_host_scopes:
+        if not ldp and world == 1 and not args.no_host_scopes:
             result["host_scopes"] = host_scopes(ctx, luma, W, H, NF, QP)
-        if world == 1 and not args.no_cpu_baseline:
+        if not ldp and world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(luma, W, H, QP, args.cpu_seconds)
         # sanity: the benchmark output is the real thing (first frame vs oracle), outside the timed region
-        try:
-            sys.path.insert(0, os.path.join(ROOT, "oracle"))
-            import ethcnn_np as oracle
-            got = d_out.download(np.float32, nctu * 21).reshape(nctu, 21)
-            want = oracle.predict_frames(ctx.get_blob(), luma[0], W, H, 1, QP, 0.5, 0.5, mode=0)
-            result["parity_first_frame_bit_exact"] = bool(np.array_equal(got.view(np.uint32), want.view(np.uint32)))
-        except Exception as exc:  # the oracle is a checker only; never fatal for the measurement
-            result["parity_first_frame_bit_exact"] = "unchecked: %s" % exc
+        if not ldp:
+            result["parity_first_frame_bit_exact"] = first_frame_parity(ctx, d_out, luma, W, H, QP, nctu)
         print(json.dumps(result))
         sys.stdout.flush()
     d_in.free()
@@ -216,6 +206,18 @@ def main():
         dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
     return 0
+
+
+def first_frame_parity(ctx, d_out, luma, W, H, QP, nctu):
+    try:
+        import numpy as np
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import ethcnn_np as oracle
+        got = d_out.download(np.float32, nctu * 21).reshape(nctu, 21)
+        want = oracle.predict_frames(ctx.get_blob(), luma[0], W, H, 1, QP, 0.5, 0.5, mode=0)
+        return bool(np.array_equal(got.view(np.uint32), want.view(np.uint32)))
+    except Exception as exc:  # the oracle is a checker only; never fatal for the measurement
+        return "unchecked: %s" % exc
 
 
 def ldp_parity(ctx, luma, W, H, QP):
