@@ -126,7 +126,7 @@ struct ethcnn_ctx {
     int last_n = 0;  // CTUs of the last pass (debug_fetch)
     bool debug_capture = false;  // also store FC2 outputs, logits and ungated probabilities (1.7 KB/CTU of writes)
 
-    int profiling = 0;  // 0 off, 1 dominant kernel (FC1) on every 4th pass, 2 every stage
+    int profiling = 0;  // 0 off, 1 dominant kernel (FC1) on every 3rd pass, 2 every stage
     unsigned fc1_sample = 0;
     struct Ev { hipEvent_t a, b; int stage; };
     std::vector<Ev> pending;
@@ -392,8 +392,9 @@ struct StageTimer {
     int stage;
     hipEvent_t a = nullptr, b = nullptr;
     bool on;
-    StageTimer(ethcnn_ctx* c_, int st) : c(c_), stage(st) {
-        on = c->profiling >= 2 || (c->profiling == 1 && st == ETHCNN_STAGE_FC1 && (c->fc1_sample++ & 3) == 0);
+    long ctus;
+    StageTimer(ethcnn_ctx* c_, int st, long n = 0) : c(c_), stage(st), ctus(n) {
+        on = c->profiling >= 2 || (c->profiling == 1 && st == ETHCNN_STAGE_FC1 && (c->fc1_sample++ % 3) == 0);
         if (on) {
             a = get_event(c);
             b = get_event(c);
@@ -405,6 +406,7 @@ struct StageTimer {
             (void)hipEventRecord(b, c->stream);
             c->pending.push_back({a, b, stage});
             c->times.timed[stage]++;
+            c->times.timed_ctus[stage] += ctus;
         }
         c->times.launches[stage]++;
     }
@@ -463,9 +465,9 @@ static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, lo
     int rc = ensure_workspace(c, n, (int)nchunks);
     if (rc) return rc;
     const float qn = (float)qp * (1.0f / 51.0f);  // net_CNN.py:106
-    { StageTimer t(c, ETHCNN_STAGE_TILE); launch_tile(d_luma, g, ctu0, n, c->ws, (int)nchunks * 2, c->stream); }
+    { StageTimer t(c, ETHCNN_STAGE_TILE, n); launch_tile(d_luma, g, ctu0, n, c->ws, (int)nchunks * 2, c->stream); }
     { StageTimer t(c, ETHCNN_STAGE_TRUNK); launch_trunk(c->ws, c->dw, n, false, c->stream); }
-    { StageTimer t(c, ETHCNN_STAGE_FC1); launch_fc1(c->ws, c->dw, n, c->ws.h1, c->stream); }
+    { StageTimer t(c, ETHCNN_STAGE_FC1, n); launch_fc1(c->ws, c->dw, n, c->ws.h1, c->stream); }
     Workspace wv = c->ws;
     if (!c->debug_capture) wv.h2 = wv.logits = wv.raw = nullptr;
     { StageTimer t(c, ETHCNN_STAGE_HEADS); launch_heads(wv, c->dw, n, qn, g.nctu, ctu0, c->thr1, c->thr2, d_probs_pass, c->stream); }
@@ -742,9 +744,9 @@ extern "C" int ethcnn_resi_vectors_device(ethcnn_ctx* c, const uint8_t* d_luma, 
         const int n = std::min(c->max_ctus, g.nctu - o);
         rc = ensure_workspace(c, n, 1);
         if (rc) return rc;
-        { StageTimer t(c, ETHCNN_STAGE_TILE); launch_tile(d_luma, g, o, n, c->ws, 0, c->stream); }
+        { StageTimer t(c, ETHCNN_STAGE_TILE, n); launch_tile(d_luma, g, o, n, c->ws, 0, c->stream); }
         { StageTimer t(c, ETHCNN_STAGE_TRUNK); launch_trunk(c->ws, c->dw, n, true, c->stream); }
-        { StageTimer t(c, ETHCNN_STAGE_FC1); launch_fc1(c->ws, c->dw, n, d_vec + (size_t)o * kNVec, c->stream); }
+        { StageTimer t(c, ETHCNN_STAGE_FC1, n); launch_fc1(c->ws, c->dw, n, d_vec + (size_t)o * kNVec, c->stream); }
         HIPCHK(c, hipGetLastError());
         c->times.ctus += n;
         c->last_n = n;

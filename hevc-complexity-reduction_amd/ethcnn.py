@@ -34,7 +34,7 @@ class Options(ctypes.Structure):
 
 class StageTimes(ctypes.Structure):
     _fields_ = [("ms", ctypes.c_double * 5), ("launches", ctypes.c_int64 * 5), ("ctus", ctypes.c_int64),
-                ("timed", ctypes.c_int64 * 5)]
+                ("timed", ctypes.c_int64 * 5), ("timed_ctus", ctypes.c_int64 * 5)]
 
 
 class CkptEntry(ctypes.Structure):
@@ -389,7 +389,7 @@ class EthCnn(object):
         st = StageTimes()
         self._chk(self.lib.ethcnn_get_stage_times(self.h, ctypes.byref(st)))
         return {"ms": dict(zip(STAGES, list(st.ms))), "launches": dict(zip(STAGES, list(st.launches))), "ctus": st.ctus,
-                "timed": dict(zip(STAGES, list(st.timed)))}
+                "timed": dict(zip(STAGES, list(st.timed))), "timed_ctus": dict(zip(STAGES, list(st.timed_ctus)))}
 
     def set_debug_capture(self, on=True):
         """store FC2 outputs, logits and ungated probabilities of the following passes (debug_fetch)"""
