@@ -4,6 +4,7 @@ oracle/_ref/hm_ldp/TAppEncoderLDP (HM-16.5_Test_LDP built unchanged by oracle/bu
 synthetic moving sequence while a predictor daemon answers its command.dat / pred_start.sig requests.
 
     ldp_e2e.py gpu    <outdir>   daemon = hevc-complexity-reduction_amd/resi_to_cu_depth_LDP.serve (MI355X)
+    ldp_e2e.py gpu-cli <outdir>  same, started as a separate process through the root launcher resi_to_cu_depth_LDP.py
     ldp_e2e.py oracle <outdir>   daemon = the same protocol answered by the CPU oracle (test infrastructure)
 
 Both write <outdir>/<mode>.json: bitstream md5 + a crc32 of every frame's cu_depth.dat / state.dat.
@@ -101,9 +102,16 @@ def main():
     for ext in (".index", ".data-00000-of-00001"):
         shutil.copy(GOLD + ext, os.path.join(work, "model_LDP_200000_qp32.dat" + ext))
     log = []
-    th = threading.Thread(target=(gpu_daemon if mode == "gpu" else oracle_daemon), args=(work, FRAMES - 1, log), daemon=True)
+    cli = None
+    if mode == "gpu-cli":  # the daemon exactly as a user starts it: `python resi_to_cu_depth_LDP.py` in the encoder's directory
+        os.symlink(os.path.join(ROOT, "resi_to_cu_depth_LDP.py"), os.path.join(work, "resi_to_cu_depth_LDP.py"))
+        cli = subprocess.Popen([sys.executable, "resi_to_cu_depth_LDP.py", "--max-frames", str(FRAMES - 1), "--idle-timeout", "300"],
+                               cwd=work, env=dict(os.environ, ETHCNN_SYNTHETIC_SEED=str(SEED)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        th = threading.Thread(target=cli.wait, daemon=True)
+    else:
+        th = threading.Thread(target=(gpu_daemon if mode == "gpu" else oracle_daemon), args=(work, FRAMES - 1, log), daemon=True)
     th.start()
-    time.sleep(3.0 if mode == "gpu" else 0.5)  # the reference's daemon is started by hand before the encoder, too
+    time.sleep(6.0 if mode == "gpu-cli" else (3.0 if mode == "gpu" else 0.5))  # the reference's daemon is started by hand before the encoder, too
     exe = os.path.join(ROOT, "oracle", "_ref", "hm_ldp", "TAppEncoderLDP")
     t0 = time.time()
     r = subprocess.run([exe, "-c", os.path.join(ROOT, "scripts", "hm_ldp_test.cfg"), "-i", "seq.yuv", "-wdt", str(W), "-hgt", str(H),

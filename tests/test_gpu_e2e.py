@@ -61,7 +61,7 @@ def test_low_delay_p_with_the_reference_encoder(tmp_path):
     against the oracle-backed daemon on the host: identical per-frame cu_depth.dat / state.dat and
     identical bitstreams (real motion-compensated residuals, trained LSTM weights, 5 recurrent steps)."""
     res = {}
-    for mode in ("gpu", "oracle"):
+    for mode in ("gpu", "gpu-cli", "oracle"):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "ldp_e2e.py"), mode, str(tmp_path)],
                            capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
@@ -69,3 +69,4 @@ def test_low_delay_p_with_the_reference_encoder(tmp_path):
     assert len(res["gpu"]["per_frame_crc"]) == 5
     assert res["gpu"]["per_frame_crc"] == res["oracle"]["per_frame_crc"]
     assert res["gpu"]["bitstream_md5"] == res["oracle"]["bitstream_md5"]
+    assert res["gpu-cli"]["bitstream_md5"] == res["oracle"]["bitstream_md5"]  # the daemon as a separate process (root launcher)
