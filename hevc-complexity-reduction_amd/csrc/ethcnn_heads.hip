@@ -4,7 +4,7 @@
 // gfx950, v_mfma_f32_16x16x4_f32.
 //
 // One wave = 16 CTUs, "transposed": MFMA rows = output features, columns = CTUs.
-//   FC2^T: A operand = W2 (16-k chunks by LDS-DMA, shared by the block's 4 waves, 3 stages),
+//   FC2^T: A operand = W2 (16-k chunks by LDS-DMA, shared by the block's 4 waves, 2 stages),
 //          B operand = this wave's h1 rows, one float4 per lane per chunk (element e feeds MFMA
 //          step e -> k order 16c + 4g + e, the canonical FC order).  One block = one head of a
 //          64-CTU tile (blockIdx.y = head, 16 first): short per-block latency, three times the blocks.
@@ -71,10 +71,12 @@ struct Hd {
     static constexpr bool COLSWZ = (N2 % 32 == 0);
 };
 constexpr int kHeadsStage = 16 * 192 + 4 * 256;  // floats per LDS stage: widest W2 chunk + 4 waves' h1 pieces
+constexpr int kHeadsStages = 2;  // prefetch distance 1: 32 KB of LDS and 105 VGPRs per block -> 4 blocks per CU
 
-// One head for this wave's 16 CTUs.  3 LDS stages, prefetch distance 2, every operand by LDS-DMA
-// (inline asm: hipcc neither drains nor counts it), counted vmcnt + raw barrier -- the FC1 pipeline
-// of ethcnn_dense.hip at the heads' sizes.
+// One head for this wave's 16 CTUs.  2 LDS stages, prefetch distance 1, every operand by LDS-DMA
+// (inline asm: hipcc neither drains nor counts it), explicit vmcnt + raw barrier -- the FC1 pipeline
+// of ethcnn_dense.hip at the heads' sizes; four blocks per CU cover the DMA latency for each other
+// (3 stages / 3 blocks per CU measured 7 % slower on 102,000 CTUs).
 template <int H>
 __device__ __forceinline__ void head_pass(float* smem, const float* __restrict__ h1row, const HeadsParams& hp, float qn,
                                           int lane, unsigned wvu, bool valid, int ctu, float* __restrict__ h2row,
@@ -129,15 +131,13 @@ __device__ __forceinline__ void head_pass(float* smem, const float* __restrict__
 
     __builtin_amdgcn_s_barrier();  // the previous head's last stage has been consumed by every wave
     HP_ISSUE(0, 0);
-    HP_ISSUE(1, 1);
-    HP_WAIT(D::ISSUE);
+    HP_WAIT(0);
     __builtin_amdgcn_s_barrier();
     int st = 0;
 #pragma unroll 1
     for (int kc = 0; kc < D::NK; ++kc) {
-        int st2 = st + 2;
-        if (st2 >= 3) st2 -= 3;
-        if (kc + 2 < D::NK) { HP_ISSUE(kc + 2, st2); }
+        const int st2 = st ^ 1;
+        if (kc + 1 < D::NK) { HP_ISSUE(kc + 1, st2); }
         const float4 av = *reinterpret_cast<const float4*>(smem + st * kHeadsStage + 16 * 192 + wvu * 256 + lane * 4);
         const float* bs = smem + st * kHeadsStage + 4 * g * D::N2;
 #pragma unroll
@@ -146,21 +146,15 @@ __device__ __forceinline__ void head_pass(float* smem, const float* __restrict__
 #pragma unroll
             for (int j = 0; j < D::NT; ++j) acc[j] = MFMA16(bs[brow[e] + bcol[j]], hv, acc[j]);  // rows = W2 columns
         }
-        if (kc + 2 < D::NK) { HP_WAIT(D::ISSUE); } else { HP_WAIT(0); }
+        HP_WAIT(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        st = (st == 2) ? 0 : st + 1;
+        st = st2;
     }
 #undef HP_DMA
 #undef HP_ISSUE
 #undef HP_WAIT
 
-    // FC3^T A operand: W3[k = 16 j + 4 g + r][out = col]; all loads issued before the first use
-    float w3r[D::NT][4];
-#pragma unroll
-    for (int j = 0; j < D::NT; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) w3r[j][r] = (col < D::N3) ? W3[(16 * j + 4 * g + r) * D::N3 + col] : 0.0f;
     // FC2 epilogue in place: lane (ctu = col, g) holds h2[ctu][16 j + 4 g + r]
 #pragma unroll
     for (int j = 0; j < D::NT; ++j) {
@@ -175,10 +169,22 @@ __device__ __forceinline__ void head_pass(float* smem, const float* __restrict__
     }
     // FC3^T: rows = outputs (N3 of 16 used), columns = CTUs; step (j, r) consumes k = 16 j + 4 g + r
     f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {   // W3 operands fetched one tile ahead of their use (8 VGPRs instead of 4 NT)
+        float wc[4], wn[4];
 #pragma unroll
-    for (int j = 0; j < D::NT; ++j)
+        for (int r = 0; r < 4; ++r) wc[r] = (col < D::N3) ? W3[(4 * g + r) * D::N3 + col] : 0.0f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) z = MFMA16(w3r[j][r], acc[j][r], z);
+        for (int j = 0; j < D::NT; ++j) {
+            if (j + 1 < D::NT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) wn[r] = (col < D::N3) ? W3[(16 * (j + 1) + 4 * g + r) * D::N3 + col] : 0.0f;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z = MFMA16(wc[r], acc[j][r], z);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wc[r] = wn[r];
+        }
+    }
     // lane (ctu = col, g) holds outputs 4 g + r
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -202,7 +208,7 @@ __global__ __launch_bounds__(256) void k_heads(const float* __restrict__ H1, Hea
                                                int cpf, long ctu0, float thr1, float thr2, float* __restrict__ H2,
                                                float* __restrict__ logits, float* __restrict__ raw,
                                                float* __restrict__ probs, int* __restrict__ flags) {
-    __shared__ __attribute__((aligned(16))) float smem[3 * kHeadsStage];  // the ONLY LDS object (48 KB)
+    __shared__ __attribute__((aligned(16))) float smem[kHeadsStages * kHeadsStage];  // the ONLY LDS object (32 KB)
     const int lane = threadIdx.x & 63;
     const unsigned wvu = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int col = lane & 15;
