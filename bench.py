@@ -64,8 +64,8 @@ def synth_luma(width, height, frames, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
@@ -81,17 +81,29 @@ def main():
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libethcnn has no CPU fallback)")
+    # test hooks for exercising the multi-rank control flow on a ONE-GPU box (scripts/gpu_dist_smoke.sh):
+    # BENCH_FORCE_DEVICE puts every rank on that device, BENCH_DIST_BACKEND=gloo replaces RCCL (which
+    # refuses two ranks on one GPU).  Never set by the driver.
+    if os.environ.get("BENCH_FORCE_DEVICE") is not None:
+        local_rank = int(os.environ["BENCH_FORCE_DEVICE"])
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     def barrier():
         if dist is not None:
-            dist.barrier(device_ids=[local_rank])
+            if backend == "nccl":
+                dist.barrier(device_ids=[local_rank])
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     pkg = importlib.import_module("hevc-complexity-reduction_amd")
@@ -149,7 +161,7 @@ def main():
     st_all = ctx.stage_times()
     ctx.set_profiling(0)
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -204,7 +216,7 @@ def main():
     d_out.free()
     ctx.close()
     if dist is not None:
-        dist.barrier(device_ids=[local_rank])
+        barrier()
         dist.destroy_process_group()
     return 0
 
