@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--ramp-ms", type=float, default=250.0, help="untimed load before the warm-up steps (GPU clock ramp)")
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
@@ -138,6 +139,14 @@ def main():
         ctx._chk(ctx.lib.ethcnn_lstm_step_device(ctx.h, d_vec.ptr, d_state[i & 1].ptr if i > 0 else None, nctu, QP,
                                                  i + 1, d_state[(i + 1) & 1].ptr, d_out.ptr))
 
+    # clock ramp: the GPU reaches its sustained clocks only after ~100 ms of load (measured: a 20-step timed
+    # region right after 5 warm-up steps runs 6 % slower than the same region after 40); bring it there
+    # first, untimed, then do the W warm-up steps the contract asks for
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < args.ramp_ms * 1e-3:
+        for _ in range(8):
+            step()
+        ctx.synchronize()
     for _ in range(args.warmup):
         step()
     ctx.synchronize()
