@@ -534,7 +534,7 @@ static int ensure_staging(ethcnn_ctx* c, size_t in_bytes, size_t out_bytes) {
 static HostPool* host_pool(ethcnn_ctx* c) {
     if (!c->pool) {
         int nt = std::min(16, std::max(1, (int)std::thread::hardware_concurrency() / 2));
-        if (const char* e = std::getenv("ETHCNN_HOST_THREADS")) nt = std::max(1, std::min(64, std::atoi(e)));
+        if (const char* e = std::getenv("ETHCNN_HOST_THREADS")) nt = std::max(1, std::min(32, std::atoi(e)));  // 64+ threads measured slower (scripts/s3_threads.py)
         c->pool = new HostPool(nt);
     }
     return c->pool;
