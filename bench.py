@@ -3,8 +3,9 @@
 
 A "step" = one pass of the whole hot path (k0 tile -> k1 trunk -> FC1 -> FC2 -> head ->
 gates) over one batch of synthetic luma frames ALREADY RESIDENT IN HBM, producing the
-cu_depth.dat payload in HBM.  Default workload = BASELINE.json configs[1]
-("All-Intra 1920x1080 QP32, 50 frames synthetic YUV"); --workload picks another config.
+cu_depth.dat payload in HBM.  Default workload = BASELINE.json configs[2] at QP32
+("All-Intra 3840x2160 QP32, 50 frames": the largest single-GPU configuration and the one
+north_star sets its target on); --workload picks another config (c2 = configs[1], ...).
 N > 1: frames shard across ranks with no data-path collective (weak scaling: every rank
 runs the same per-GPU workload on its own frames); torch.distributed is used only for the
 timing barrier and the max-over-ranks reduction.
@@ -13,7 +14,10 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with two extra o
   roofline      dominant kernel = FC1 (77.6 % of the MACs): algorithmic FLOP / HIP-event
                 kernel time vs the fp32-MFMA peak of MI355X_MICROARCH.md (157.3 TFLOP/s)
   cpu_baseline  the CPU oracle (a port of the reference's TF-CPU path; TensorFlow itself
-                cannot run here) timed on the host cores on a bounded sample
+                cannot run here) timed on all host cores on a bounded sample; `cpu_baselines`
+                lists it again beside the same oracle on 1 thread, the oracle at the reference's
+                own timed scope (file -> cu_depth.dat) and the structure-faithful TF-CPU proxy
+                (oracle/tf_cpu_proxy.py: per-CTU Python tiling loop, 1024-CTU feeds, torch-CPU ops)
 """
 import argparse
 import importlib
@@ -67,9 +71,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--ramp-ms", type=float, default=250.0, help="untimed load before the warm-up steps (GPU clock ramp)")
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=24.0, help="target CPU time of ALL baseline samples together")
     ap.add_argument("--no-host-scopes", action="store_true", help="skip the PCIe / file-inclusive side measurements")
     args = ap.parse_args()
 
@@ -212,10 +216,13 @@ def main():
             if world == 1 and not args.no_cpu_baseline:
                 result["cpu_baseline"] = cpu_baseline_ldp(luma, W, H, QP, args.cpu_seconds)
             result["parity_first_frames_bit_exact"] = ldp_parity(ctx, luma, W, H, QP)
-        if not ldp and world == 1 and not args.no_host_scopes:
-            result["host_scopes"] = host_scopes(ctx, luma, W, H, NF, QP)
-        if not ldp and world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(luma, W, H, QP, args.cpu_seconds)
+        if not ldp and world == 1 and not (args.no_host_scopes and args.no_cpu_baseline):
+            with YuvFile(luma, W, H) as yuv:
+                if not args.no_host_scopes:
+                    result["host_scopes"] = host_scopes(ctx, luma, W, H, NF, QP, yuv)
+                if not args.no_cpu_baseline:
+                    result["cpu_baselines"] = cpu_baselines(luma, W, H, QP, args.cpu_seconds, yuv)
+                    result["cpu_baseline"] = dict(result["cpu_baselines"][0])
         # sanity: the benchmark output is the real thing (first frame vs oracle), outside the timed region
         if not ldp:
             result["parity_first_frame_bit_exact"] = first_frame_parity(ctx, d_out, luma, W, H, QP, nctu)
@@ -291,58 +298,122 @@ def pmc_traffic(workload):
         return {"traffic": None}
 
 
-def host_scopes(ctx, luma, W, H, NF, QP):
+class YuvFile:
+    """the batch as an 8-bit 4:2:0 file (chroma = 128) on tmpfs, shared by the file-scope measurements"""
+
+    def __init__(self, luma, W, H):
+        import tempfile
+        import numpy as np
+        self.dir = tempfile.mkdtemp(prefix="ethcnn_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        self.path = os.path.join(self.dir, "seq.yuv")
+        chroma = np.full(W * H // 2, 128, dtype=np.uint8).tobytes()
+        with open(self.path, "wb") as f:
+            for k in range(luma.shape[0]):
+                f.write(luma[k].tobytes())
+                f.write(chroma)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        import shutil
+        shutil.rmtree(self.dir, ignore_errors=True)
+        return False
+
+
+def host_scopes(ctx, luma, W, H, NF, QP, yuv):
     """Side measurements OUTSIDE the timed region (never `value`): the same batch through the
     host entry points.  S2 = pageable host luma -> host probabilities (pinned staging, H2D,
     kernels, D2H); S3 = the reference's own scope ('Predicting Time', video_to_cu_depth.py:142-145):
-    4:2:0 file -> cu_depth.dat on a tmpfs-backed temp dir."""
-    import tempfile
-    import numpy as np
+    4:2:0 file -> cu_depth.dat on a tmpfs-backed temp dir.  Best of 3 (single shots are noisy)."""
     nctu = ((W + 63) // 64) * ((H + 63) // 64)
     out = {}
     ctx.predict_luma(luma, W, H, NF, QP)  # warm the staging buffers
-    t0 = time.perf_counter()
-    ctx.predict_luma(luma, W, H, NF, QP)
-    out["s2_host_to_host_ctus_per_s"] = NF * nctu / (time.perf_counter() - t0)
-    d = tempfile.mkdtemp(prefix="ethcnn_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
-    try:
-        yuv = os.path.join(d, "seq.yuv")
-        chroma = np.full(W * H // 2, 128, dtype=np.uint8)
-        with open(yuv, "wb") as f:
-            for k in range(NF):
-                f.write(luma[k].tobytes())
-                f.write(chroma.tobytes())
-        ctx.predict_yuv_file(yuv, W, H, QP, os.path.join(d, "cu_depth.dat"))
+    best = 1e30
+    for _ in range(3):
         t0 = time.perf_counter()
-        ctx.predict_yuv_file(yuv, W, H, QP, os.path.join(d, "cu_depth.dat"))
-        out["s3_file_to_file_ctus_per_s"] = NF * nctu / (time.perf_counter() - t0)
-    finally:
-        import shutil
-        shutil.rmtree(d, ignore_errors=True)
+        ctx.predict_luma(luma, W, H, NF, QP)
+        best = min(best, time.perf_counter() - t0)
+    out["s2_host_to_host_ctus_per_s"] = NF * nctu / best
+    out["s2_h2d_gbps"] = NF * W * H / best / 1e9
+    dat = os.path.join(yuv.dir, "cu_depth.dat")
+    ctx.predict_yuv_file(yuv.path, W, H, QP, dat)
+    best = 1e30
+    for _ in range(3):
+        t0 = time.perf_counter()
+        ctx.predict_yuv_file(yuv.path, W, H, QP, dat)
+        best = min(best, time.perf_counter() - t0)
+    out["s3_file_to_file_ctus_per_s"] = NF * nctu / best
+    out["s3_luma_gbps"] = NF * W * H / best / 1e9
+    out["note"] = "best of 3; PCIe Gen5 x16 ceiling ~ 12 M CTU/s at 4096 B/CTU"
     return out
 
 
-def cpu_baseline(luma, W, H, QP, target_seconds):
-    """The oracle (C port of the reference's CPU path, OpenMP over CTUs) on the host cores:
-    same scope as the GPU step (frames in memory -> probabilities in memory)."""
+def cpu_baselines(luma, W, H, QP, target_seconds, yuv):
+    """CPU baselines on the host cores of this box, each on a bounded sample of the same workload
+    (BASELINE.md section 4).  [0] is also reported as `cpu_baseline`:
+      [0] B1/S1  oracle (C port of the reference's CPU path, OpenMP over CTUs), all cores, frames in
+                 memory -> probabilities in memory (the scope of the GPU step);
+      [1] B1/S1  the same on ONE thread;
+      [2] B1/S3  the oracle at the reference's own timed scope: 4:2:0 file -> cu_depth.dat;
+      [3] B2/S3  the TF-CPU proxy: per-CTU Python tiling loop + 1024-CTU feeds through torch-CPU ops
+                 (video_to_cu_depth.py:61-73,88-106,142-145; TensorFlow itself cannot run here)."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ethcnn_np as oracle
     cores = os.cpu_count() or 1
     blob = oracle.synth_blob(1, 8.0)
+    NF = luma.shape[0]
     nctu = ((W + 63) // 64) * ((H + 63) // 64)
-    t0 = time.perf_counter()
-    oracle.predict_frames(blob, luma, W, H, luma.shape[0], QP, 0.5, 0.5, mode=0)  # warm: threads up, pages touched
-    per_pass = time.perf_counter() - t0
-    reps = int(max(1, min(200, round(target_seconds / max(per_pass, 1e-6)))))
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        oracle.predict_frames(blob, luma, W, H, luma.shape[0], QP, 0.5, 0.5, mode=0)
+    budget = {"all": 0.35 * target_seconds, "one": 0.2 * target_seconds, "s3": 0.15 * target_seconds, "proxy": 0.3 * target_seconds}
+    out = []
+
+    def timed_passes(frames, seconds, label, threads):
+        oracle.set_threads(threads)
+        t0 = time.perf_counter()
+        oracle.predict_frames(blob, luma[:frames], W, H, frames, QP, 0.5, 0.5, mode=0)  # warm: threads up, pages touched
+        per_pass = time.perf_counter() - t0
+        reps = int(max(1, min(200, round(seconds / max(per_pass, 1e-6)))))
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            oracle.predict_frames(blob, luma[:frames], W, H, frames, QP, 0.5, 0.5, mode=0)
+        dt = time.perf_counter() - t0
+        n = reps * frames * nctu
+        return {"value": n / dt, "unit": "CTU/s", "cores": threads, "kind": "port", "scope": "S1 memory -> memory", "name": label,
+                "sample": "%d pass(es) over %d frame(s) of %dx%d (%d CTUs), oracle/ethcnn_oracle.c canonical mode, OpenMP over the "
+                          "CTUs of a frame group, %.1f s" % (reps, frames, W, H, n, dt)}
+
+    out.append(timed_passes(NF, budget["all"], "B1 oracle, all host threads", cores))
+    # one thread: ~0.5 k CTU/s -> one frame is seconds of work; never more than one frame, one pass
+    one = timed_passes(1, 0.0, "B1 oracle, 1 thread", 1)
+    out.append(one)
+    oracle.set_threads(cores)
+    # S3, oracle: read the file, predict, write cu_depth.dat (the reference's 'Predicting Time' scope)
+    dat = os.path.join(yuv.dir, "cpu_cu_depth.dat")
+    reps, t0 = 0, time.perf_counter()
+    while reps == 0 or time.perf_counter() - t0 < budget["s3"]:
+        buf = np.fromfile(yuv.path, dtype=np.uint8)
+        P = oracle.predict_frames(blob, buf, W, H, NF, QP, 0.5, 0.5, mode=0, frame_stride=W * H * 3 // 2)
+        P.tofile(dat)
+        reps += 1
     dt = time.perf_counter() - t0
-    n = reps * luma.shape[0] * nctu
-    return {"value": n / dt, "unit": "CTU/s", "cores": cores, "kind": "port",
-            "sample": "%d pass(es) over the same %d frames of %dx%d (%d CTUs), oracle/ethcnn_oracle.c canonical mode, "
-                      "OpenMP over all CTUs of a frame group, %.1f s" % (reps, luma.shape[0], W, H, n, dt)}
+    out.append({"value": reps * NF * nctu / dt, "unit": "CTU/s", "cores": cores, "kind": "port", "name": "B1 oracle, all host threads, file scope",
+                "scope": "S3 4:2:0 file -> cu_depth.dat (video_to_cu_depth.py:142-145)",
+                "sample": "%d pass(es) over the %d-frame %dx%d file on tmpfs, %.1f s" % (reps, NF, W, H, dt)})
+    try:
+        import tf_cpu_proxy as proxy
+        import torch
+        # 64 threads: more does not help ops this small (and 256 oversubscribe); the count used is reported
+        pt = min(cores, 64)
+        proxy.predict_file(blob, yuv.path, W, H, QP, dat, max_frames=1, threads=pt)  # warm
+        frames, ctus, dt = proxy.predict_file(blob, yuv.path, W, H, QP, dat, max_seconds=budget["proxy"], threads=pt)
+        out.append({"value": ctus / dt, "unit": "CTU/s", "cores": pt, "kind": "port", "name": "B2 TF-CPU proxy (torch-CPU ops, reference-shaped driver)",
+                    "scope": "S3 4:2:0 file -> cu_depth.dat (video_to_cu_depth.py:142-145)",
+                    "sample": "first %d frame(s) of the %dx%d file (%d CTUs): per-CTU Python tiling loop, <=1024-CTU feeds, torch %s CPU, "
+                              "%d threads, %.1f s" % (frames, W, H, ctus, torch.__version__, pt, dt)})
+    except Exception as exc:  # a baseline is a side measurement: never fatal
+        out.append({"name": "B2 TF-CPU proxy", "error": str(exc)})
+    return out
 
 
 if __name__ == "__main__":

@@ -128,7 +128,7 @@ struct ethcnn_ctx {
 
     int profiling = 0;  // 0 off, 1 dominant kernel (FC1) on every 3rd pass, 2 every stage
     unsigned fc1_sample = 0;
-    struct Ev { hipEvent_t a, b; int stage; };
+    struct Ev { hipEvent_t a, b; int stage; long ctus; };
     std::vector<Ev> pending;
     std::vector<hipEvent_t> ev_pool;
     ethcnn_stage_times times{};
@@ -224,7 +224,7 @@ extern "C" int ethcnn_create(ethcnn_ctx** out, const ethcnn_options* opt) {
     if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->copy_in, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->copy_out, hipStreamNonBlocking) != hipSuccess) {
-        delete c;
+        ethcnn_destroy(c);  // releases whichever streams were created
         return set_err(nullptr, ETHCNN_ERR_DEVICE, "cannot create HIP streams on device %d", dev);
     }
     *out = c;
@@ -384,7 +384,7 @@ static hipEvent_t get_event(ethcnn_ctx* c) {
         return e;
     }
     hipEvent_t e = nullptr;
-    (void)hipEventCreate(&e);
+    if (hipEventCreate(&e) != hipSuccess) e = nullptr;
     return e;
 }
 struct StageTimer {
@@ -398,13 +398,22 @@ struct StageTimer {
         if (on) {
             a = get_event(c);
             b = get_event(c);
-            (void)hipEventRecord(a, c->stream);
+            if (!a || !b || hipEventRecord(a, c->stream) != hipSuccess) fail();
         }
     }
+    // a timing failure never fails the pass; it is counted (ethcnn_stage_times.timing_errors) so a
+    // reader of the stage times knows the sample is incomplete
+    void fail() {
+        on = false;
+        c->times.timing_errors++;
+        if (a) c->ev_pool.push_back(a);
+        if (b) c->ev_pool.push_back(b);
+        a = b = nullptr;
+    }
     ~StageTimer() {
+        if (on && hipEventRecord(b, c->stream) != hipSuccess) fail();
         if (on) {
-            (void)hipEventRecord(b, c->stream);
-            c->pending.push_back({a, b, stage});
+            c->pending.push_back({a, b, stage, ctus});
             c->times.timed[stage]++;
             c->times.timed_ctus[stage] += ctus;
         }
@@ -414,8 +423,13 @@ struct StageTimer {
 static void drain_events(ethcnn_ctx* c) {
     for (auto& p : c->pending) {
         float ms = 0.f;
-        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess)
+        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
             c->times.ms[p.stage] += ms;
+        } else {  // keep ms / timed / timed_ctus consistent: the failed pair leaves the sample
+            c->times.timing_errors++;
+            c->times.timed[p.stage]--;
+            c->times.timed_ctus[p.stage] -= p.ctus;
+        }
         c->ev_pool.push_back(p.a);
         c->ev_pool.push_back(p.b);
     }
@@ -758,9 +772,10 @@ extern "C" int ethcnn_resi_vectors(ethcnn_ctx* c, const uint8_t* luma, int w, in
     if (!c || !luma || !vec) return c ? set_err(c, ETHCNN_ERR_ARG, "null pointer") : ETHCNN_ERR_ARG;
     if (w <= 0 || h <= 0 || pitch < w) return set_err(c, ETHCNN_ERR_ARG, "bad geometry");
     const int nctu = ((w + 63) / 64) * ((h + 63) / 64);
-    int rc = ensure_staging(c, (size_t)pitch * h, (size_t)nctu * kNVec * 4);
+    const size_t lbytes = (size_t)(h - 1) * pitch + w;  // the meaningful bytes of a pitched plane: the last row ends at w
+    int rc = ensure_staging(c, lbytes, (size_t)nctu * kNVec * 4);
     if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->d_in[0], luma, (size_t)pitch * h, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_in[0], luma, lbytes, hipMemcpyHostToDevice, c->stream));
     rc = ethcnn_resi_vectors_device(c, c->d_in[0], w, h, pitch, c->d_out[0]);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(vec, c->d_out[0], (size_t)nctu * kNVec * 4, hipMemcpyDeviceToHost, c->stream));
@@ -863,12 +878,13 @@ extern "C" int ethcnn_ldp_predict_frame(ethcnn_ctx* c, const uint8_t* luma, int 
     if (!c->have_weights) return set_err(c, ETHCNN_ERR_NOWEIGHTS, "no CNN weights loaded");
     if (!c->have_lstm) return set_err(c, ETHCNN_ERR_NOWEIGHTS, "no LSTM weights loaded");
     const int nctu = ((w + 63) / 64) * ((h + 63) / 64);
-    int rc = ensure_staging(c, (size_t)pitch * h, (size_t)nctu * kNVec * 4);
+    const size_t lbytes = (size_t)(h - 1) * pitch + w;
+    int rc = ensure_staging(c, lbytes, (size_t)nctu * kNVec * 4);
     if (rc) return rc;
     rc = ensure_lstm_buffers(c, nctu);
     if (rc) return rc;
     const size_t sbytes = (size_t)nctu * 2 * kNVec * 4;
-    HIPCHK(c, hipMemcpyAsync(c->d_in[0], luma, (size_t)pitch * h, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_in[0], luma, lbytes, hipMemcpyHostToDevice, c->stream));
     if (state_in) HIPCHK(c, hipMemcpyAsync(c->d_state[0], state_in, sbytes, hipMemcpyHostToDevice, c->stream));
     rc = ethcnn_resi_vectors_device(c, c->d_in[0], w, h, pitch, c->d_vec);
     if (rc) return rc;

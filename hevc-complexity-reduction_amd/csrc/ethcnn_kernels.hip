@@ -23,12 +23,6 @@
 
 namespace ethcnn {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
-
-__device__ __forceinline__ float lrelu(float h) { return fmaxf(0.2f * h, h); }
-
 int chunks_per_frame(int nctu) { return (nctu + kSubBatch - 1) / kSubBatch; }
 
 // (k4: the fused FC2 + FC3 + sigmoid heads kernel lives in ethcnn_heads.hip)

@@ -114,7 +114,8 @@ static bool read_file(const std::string& path, std::vector<uint8_t>& out) {
 
 // block at [off, off+size) followed by 1-byte type + 4-byte masked crc
 static bool get_block(const std::vector<uint8_t>& file, uint64_t off, uint64_t size, Cur& out, std::string& why) {
-    if (off + size + 5 > file.size()) { why = "block handle out of range"; return false; }
+    // overflow-safe: off and size are varints from the file
+    if (off > file.size() || size > file.size() - off || file.size() - off - size < 5) { why = "block handle out of range"; return false; }
     const uint8_t* b = file.data() + off;
     if (b[size] != 0) { why = "compressed index block (unsupported)"; return false; }
     uint32_t stored;

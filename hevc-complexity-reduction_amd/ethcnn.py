@@ -34,7 +34,7 @@ class Options(ctypes.Structure):
 
 class StageTimes(ctypes.Structure):
     _fields_ = [("ms", ctypes.c_double * 5), ("launches", ctypes.c_int64 * 5), ("ctus", ctypes.c_int64),
-                ("timed", ctypes.c_int64 * 5), ("timed_ctus", ctypes.c_int64 * 5)]
+                ("timed", ctypes.c_int64 * 5), ("timed_ctus", ctypes.c_int64 * 5), ("timing_errors", ctypes.c_int64)]
 
 
 class CkptEntry(ctypes.Structure):
@@ -321,6 +321,9 @@ class EthCnn(object):
     def resi_vectors(self, luma, width, height, pitch=None):
         luma = np.ascontiguousarray(luma, dtype=np.uint8)
         pitch = width if pitch is None else pitch
+        need = (height - 1) * pitch + width if width > 0 and height > 0 else 0
+        if luma.size < need:
+            raise ValueError("luma buffer too small: %d < %d" % (luma.size, need))
         out = np.empty((ctus_per_frame(width, height), NVEC), dtype=np.float32)
         self._chk(self.lib.ethcnn_resi_vectors(self.h, luma.ctypes.data, width, height, pitch, out.ctypes.data_as(_fp)))
         return out
@@ -366,6 +369,9 @@ class EthCnn(object):
         """one frame of resi.yuv luma -> (probs [nctu,21], state_out [nctu,2,448])"""
         luma = np.ascontiguousarray(luma, dtype=np.uint8)
         pitch = width if pitch is None else pitch
+        need = (height - 1) * pitch + width if width > 0 and height > 0 else 0
+        if luma.size < need:
+            raise ValueError("luma buffer too small: %d < %d" % (luma.size, need))
         n = ctus_per_frame(width, height)
         probs = np.empty((n, NOUT), dtype=np.float32)
         state = np.empty((n, 2, NVEC), dtype=np.float32)
@@ -389,7 +395,8 @@ class EthCnn(object):
         st = StageTimes()
         self._chk(self.lib.ethcnn_get_stage_times(self.h, ctypes.byref(st)))
         return {"ms": dict(zip(STAGES, list(st.ms))), "launches": dict(zip(STAGES, list(st.launches))), "ctus": st.ctus,
-                "timed": dict(zip(STAGES, list(st.timed))), "timed_ctus": dict(zip(STAGES, list(st.timed_ctus)))}
+                "timed": dict(zip(STAGES, list(st.timed))), "timed_ctus": dict(zip(STAGES, list(st.timed_ctus))),
+                "timing_errors": st.timing_errors}
 
     def set_debug_capture(self, on=True):
         """store FC2 outputs, logits and ungated probabilities of the following passes (debug_fetch)"""

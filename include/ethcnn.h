@@ -156,6 +156,7 @@ typedef struct ethcnn_stage_times {
     int64_t ctus;                    /* CTUs processed since reset */
     int64_t timed[ETHCNN_NSTAGES];   /* launches whose time is in ms[] (level 1 samples every 3rd FC1 stage) */
     int64_t timed_ctus[ETHCNN_NSTAGES]; /* CTUs of those launches: rate = work(timed_ctus) / ms */
+    int64_t timing_errors;           /* event create/record/elapsed failures: those launches are not in ms[]/timed[] */
 } ethcnn_stage_times;
 int ethcnn_set_profiling(ethcnn_ctx* ctx, int level); /* 0 off; 1 events around the dominant kernel (FC1) on every 3rd
                                                           pass (an event pair costs ~12 us of stream time); 2 around every launch */

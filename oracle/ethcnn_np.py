@@ -130,6 +130,7 @@ def lib():
                                             ctypes.c_float, ctypes.c_float, ctypes.c_int, fp]
         L.oracle_resi_vectors.argtypes = [fp, up, ctypes.c_int, ctypes.c_int, ctypes.c_long,
                                           ctypes.c_int, fp]
+        L.oracle_set_threads.argtypes = [ctypes.c_int]
         L.oracle_expf_export.argtypes = [ctypes.c_float]
         L.oracle_expf_export.restype = ctypes.c_float
         _lib = L
@@ -142,6 +143,11 @@ def _f(a):
 
 def _u(a):
     return a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
+
+
+def set_threads(n):
+    """OpenMP team size of the C oracle; returns the previous maximum."""
+    return int(lib().oracle_set_threads(int(n)))
 
 
 def _blob(blob):

@@ -79,6 +79,14 @@ static const int OFF_FC3B[3] = {5152640 / 4, 5151072 / 4, 5138656 / 4};
 
 int oracle_blob_floats(void) { return BLOB_FLOATS; }
 
+/* OpenMP team size for the calls below (bench.py's cpu_baseline reports 1 thread and all cores) */
+#ifdef _OPENMP
+#include <omp.h>
+int oracle_set_threads(int n) { const int old = omp_get_max_threads(); if (n > 0) omp_set_num_threads(n); return old; }
+#else
+int oracle_set_threads(int n) { (void)n; return 1; }
+#endif
+
 static inline float c255(void) { return 1.0f / 255.0f; }  /* 0x3b808081, .meta 'scalar'   */
 static inline float c51(void) { return 1.0f / 51.0f; }    /* 0x3ca0a0a1, .meta 'scalar_1' */
 

@@ -1,37 +1,46 @@
 #!/bin/bash
-# Round evidence in one gpurun call: gpu tests, smoke, benches, rocprofv3 kernel-trace stats,
-# HBM-traffic PMC passes, HM replay case.  Everything lands in gpurun_out/.
+# Round evidence in one gpurun call: gpu tests, smoke, benches, rocprofv3 kernel-trace stats and the
+# HBM-traffic / MFMA-busy PMC passes of the DEFAULT bench workload (c3 = 3840x2160 QP32 x 50).
+# Everything lands in gpurun_out/; scripts/collect_round.sh copies the judged summaries to profiles/.
+#   SKIP_TESTS=1  skip pytest (when the call is about numbers only)
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 REPO=$PWD
-python -m pytest tests -m gpu -x -q 2>&1 | tail -4
-python __graft_entry__.py smoke 2>&1 | tail -3
-python bench.py > gpurun_out/bench_c2.json 2> gpurun_out/bench_c2.err || tail -5 gpurun_out/bench_c2.err
-python bench.py --workload c3 --no-cpu-baseline > gpurun_out/bench_c3.json 2> gpurun_out/bench_c3.err || tail -5 gpurun_out/bench_c3.err
+WL=${WL:-c3}
+if [ -z "${SKIP_TESTS:-}" ]; then
+  python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+  python __graft_entry__.py smoke 2>&1 | tail -3
+fi
+python bench.py > gpurun_out/bench_c3.json 2> gpurun_out/bench_c3.err || tail -5 gpurun_out/bench_c3.err
+python bench.py --workload c2 --no-cpu-baseline > gpurun_out/bench_c2.json 2> gpurun_out/bench_c2.err || tail -5 gpurun_out/bench_c2.err
 python bench.py --workload c4 --no-cpu-baseline --steps 5 > gpurun_out/bench_c4.json 2> gpurun_out/bench_c4.err || tail -5 gpurun_out/bench_c4.err
 python bench.py --workload c5 --steps 200 --warmup 20 --cpu-seconds 8 > gpurun_out/bench_c5.json 2> gpurun_out/bench_c5.err || tail -5 gpurun_out/bench_c5.err
 python scripts/summarize.py "gpurun_out/bench_c*.json"
+python - <<'PY'
+import json
+d = json.load(open("gpurun_out/bench_c3.json"))
+for e in d.get("cpu_baselines", []): print("cpu:", {k: e.get(k) for k in ("name", "value", "cores", "scope")})
+print("host_scopes:", d.get("host_scopes"))
+PY
 python scripts/latency.py > gpurun_out/latency.txt 2>&1; cat gpurun_out/latency.txt
 python scripts/latency_ldp.py --cpu > gpurun_out/latency_ldp.txt 2>&1; cat gpurun_out/latency_ldp.txt
-python - <<'PY'
-import json; d=json.load(open("gpurun_out/bench_c2.json")); print("cpu_baseline:", d.get("cpu_baseline"))
-PY
-python scripts/make_hm_case.py 2>&1 | tail -2
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_c2 -o c2 -- python $REPO/bench.py --no-cpu-baseline --no-host-scopes > $REPO/gpurun_out/prof_c2.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_$WL -o $WL -- python $REPO/bench.py --workload $WL --no-cpu-baseline --no-host-scopes > $REPO/gpurun_out/prof_$WL.log 2>&1
 for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   tag=$(echo $pmc | tr ' ' '_' | cut -c1-30)
-  rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d $REPO/gpurun_out/pmc_c2_$tag -o p -- python $REPO/bench.py --no-cpu-baseline --no-host-scopes --steps 5 --warmup 1 > $REPO/gpurun_out/pmc_c2_$tag.log 2>&1
+  rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d $REPO/gpurun_out/pmc_${WL}_$tag -o p -- python $REPO/bench.py --workload $WL --no-cpu-baseline --no-host-scopes --steps 5 --warmup 1 > $REPO/gpurun_out/pmc_${WL}_$tag.log 2>&1
 done
 cd $REPO
-python - <<'PY'
+WL=$WL python - <<'PY'
 # FC1 HBM traffic per step (= per FC1 stage "launch" of bench.py: the 128x112 main dispatch + the
 # remainder dispatch) from the FETCH_SIZE / WRITE_SIZE passes (KB as reported; FETCH x2 on gfx950)
-import csv, glob, json
+import csv, glob, json, os
+wl = os.environ["WL"]
+n = json.load(open("gpurun_out/bench_%s.json" % wl))["config"]["ctus_per_step_per_gpu"]
 def per_step(tag, counter):
     tot, steps = 0.0, 0
-    for f in glob.glob("gpurun_out/pmc_c2_%s/**/*counter_collection.csv" % tag, recursive=True):
+    for f in glob.glob("gpurun_out/pmc_%s_%s/**/*counter_collection.csv" % (wl, tag), recursive=True):
         for r in csv.DictReader(open(f)):
             if "k_fc1" in r["Kernel_Name"] and r["Counter_Name"] == counter:
                 tot += float(r["Counter_Value"])
@@ -39,16 +48,15 @@ def per_step(tag, counter):
     return (tot / steps, steps) if steps else (None, 0)
 (fe, n1), (wr, n2) = per_step("FETCH_SIZE","FETCH_SIZE"), per_step("WRITE_SIZE","WRITE_SIZE")
 if fe is not None and wr is not None:
-    n = 25500
-    out = {"c2": {"bytes_per_launch": int(fe*1024*2 + wr*1024), "fetch_size_kb_reported": fe, "write_size_kb_reported": wr,
-                  "steps_averaged": n1, "algorithmic_bytes_per_launch": n*2688*4 + 2688*448*4 + n*448*4,
-                  "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of `python bench.py --no-cpu-baseline --no-host-scopes --steps 5 --warmup 1` (scripts/gpu_round.sh), summed over the FC1 dispatches of a step; FETCH_SIZE x2 (gfx950 correction)"}}
-    json.dump(out, open("gpurun_out/fc1_traffic.json","w"), indent=1); print("fc1 traffic:", out)
+    out = {wl: {"bytes_per_launch": int(fe*1024*2 + wr*1024), "fetch_size_kb_reported": fe, "write_size_kb_reported": wr,
+                "steps_averaged": n1, "algorithmic_bytes_per_launch": n*2688*4 + 2688*448*4 + n*448*4,
+                "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of `python bench.py --workload %s --no-cpu-baseline --no-host-scopes --steps 5 --warmup 1` (scripts/gpu_round.sh), summed over the FC1 dispatches of a step; FETCH_SIZE x2 (gfx950 correction)" % wl}}
+    json.dump(out, open("gpurun_out/fc1_traffic_%s.json" % wl,"w"), indent=1); print("fc1 traffic:", out)
 PY
-head -12 gpurun_out/prof_c2/c2_kernel_stats.csv
+head -12 gpurun_out/prof_$WL/${WL}_kernel_stats.csv
 python - <<'PY'
 import csv, glob, collections
-for f in sorted(glob.glob("gpurun_out/pmc_c2_*/**/*counter_collection.csv", recursive=True)):
+for f in sorted(glob.glob("gpurun_out/pmc_c*/**/*counter_collection.csv", recursive=True)):
     agg=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.Counter()
     for r in csv.DictReader(open(f)):
         k=r["Kernel_Name"][:48]

@@ -16,6 +16,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A plain `pytest tests` on a machine with NO GPU hardware at all (no /dev/kfd: the build container, CPU-only
+    CI) skips the gpu-marked tests instead of failing them.  On a GPU box nothing is skipped: a missing library or a
+    broken device still fails loudly (the product has no CPU fallback)."""
+    if os.path.exists("/dev/kfd"):
+        return
+    skip = pytest.mark.skip(reason="no GPU hardware on this machine (/dev/kfd absent); run with -m gpu on an MI355X box")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def pkg():
     """The product package (hyphenated directory name -> importlib)."""

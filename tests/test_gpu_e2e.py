@@ -1,6 +1,7 @@
 """-m gpu: end to end with the reference's OWN encoders (oracle/_ref, built from the sources under
 /root/reference by oracle/build_ref_hm.sh in the build container; the binaries travel to the GPU
-box).  Skipped when they are absent."""
+box).  When build() made them (marker oracle/_build/ref_hm_built.marker) their absence is a FAILURE; only a checkout
+that never saw /root/reference skips."""
 import hashlib
 import json
 import os
@@ -17,6 +18,16 @@ REF = os.path.join(ROOT, "oracle", "_ref")
 HM_AI = os.path.join(REF, "hm_ai", "TAppEncoderUnchanged")
 HM_INPROC = os.path.join(REF, "hm_ai", "TAppEncoderInProcess")
 HM_LDP = os.path.join(REF, "hm_ldp", "TAppEncoderLDP")
+MARKER = os.path.join(ROOT, "oracle", "_build", "ref_hm_built.marker")
+
+
+def _need(*exes):
+    missing = [e for e in exes if not os.path.exists(e)]
+    if not missing:
+        return
+    if os.path.exists(MARKER) or os.path.isdir("/root/reference"):
+        pytest.fail("reference HM binaries were built by build() but are missing here: %s" % ", ".join(missing))
+    pytest.skip("oracle/_ref was never built (no /root/reference at build time)")
 
 
 def _encode(exe, cwd, w, h, frames, qp, env):
@@ -27,12 +38,12 @@ def _encode(exe, cwd, w, h, frames, qp, env):
     return hashlib.md5(open(os.path.join(str(cwd), "str.bin"), "rb").read()).hexdigest(), r.stdout
 
 
-@pytest.mark.skipif(not (os.path.exists(HM_AI) and os.path.exists(HM_INPROC)), reason="oracle/_ref/hm_ai not built")
 def test_all_intra_drop_in_with_the_reference_encoder(oracle, tmp_path):
     """The whole drop-in: the reference's unchanged HM runs `python video_to_cu_depth.py <yuv> <w> <h> <qp>`
     (TAppEncCfg.cpp:2317-2321) in its cwd, where that name is a symlink to this repository's launcher;
     cu_depth.dat is bit-exact vs the oracle, HM consumes it, and the in-process hook build (SURVEY 8f
     row 3) produces the same file and the same bitstream."""
+    _need(HM_AI, HM_INPROC)
     sys.path.insert(0, ROOT)
     import bench
     w, h, frames, qp, seed, gain = 416, 240, 3, 32, 9, 8.0
@@ -55,11 +66,11 @@ def test_all_intra_drop_in_with_the_reference_encoder(oracle, tmp_path):
     assert md5["unchanged"] == md5["inprocess"]
 
 
-@pytest.mark.skipif(not os.path.exists(HM_LDP), reason="oracle/_ref/hm_ldp not built")
 def test_low_delay_p_with_the_reference_encoder(tmp_path):
     """scripts/ldp_e2e.py: the reference's unchanged HM-LDP encoder against the daemon on the GPU and
     against the oracle-backed daemon on the host: identical per-frame cu_depth.dat / state.dat and
     identical bitstreams (real motion-compensated residuals, trained LSTM weights, 5 recurrent steps)."""
+    _need(HM_LDP)
     res = {}
     for mode in ("gpu", "gpu-cli", "oracle"):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "ldp_e2e.py"), mode, str(tmp_path)],

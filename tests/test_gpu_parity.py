@@ -189,10 +189,51 @@ def test_full_size_c2(pkg, oracle):
     _full_size_case(pkg, oracle, 1920, 1080, 50, 32, sample_frames=(0, 17, 49))
 
 
-@pytest.mark.parametrize("qp", [22, 37])
+@pytest.mark.parametrize("qp", [22, 27, 32, 37])
 def test_full_size_c3(pkg, oracle, qp):
-    """BASELINE.json configs[2]: 3840x2160 x 50 frames (102,000 CTUs; sub-batches 1024 + 1016)."""
+    """BASELINE.json configs[2]: 3840x2160 x 50 frames (102,000 CTUs; sub-batches 1024 + 1016), all four
+    QP bands of the QP-conditioned heads."""
     _full_size_case(pkg, oracle, 3840, 2160, 50, qp, sample_frames=(0, 31))
+
+
+def test_c4_qp27_file_sharded_8_ways(pkg, oracle, tmp_path):
+    """BASELINE.json configs[3] geometry and QP (4928x3264 QP27; 3927 CTUs per frame = 3 x 1024 + 855) as a real
+    4:2:0 file of 9 frames: unsharded file -> cu_depth.dat, the same file as 8 `ethcnn_predict_yuv_shard` frame
+    ranges (one of them 2 frames, as 425 frames over 8 GPUs are uneven too) into a pre-sized output, byte-identical;
+    sampled frames bit-exact vs the oracle.  (The full 425-frame job: scripts/c4_full.py.)"""
+    import bench
+    w, h, frames, qp = 4928, 3264, 9, 27
+    nctu = pkg.ethcnn.ctus_per_frame(w, h)
+    assert nctu == 3927
+    luma = bench.synth_luma(w, h, frames, seed=404)
+    yuv = str(tmp_path / "c4.yuv")
+    chroma = np.full(w * h // 2, 128, np.uint8).tobytes()
+    with open(yuv, "wb") as f:
+        for k in range(frames):
+            f.write(luma[k].tobytes())
+            f.write(chroma)
+    blob = oracle.synth_blob(1, 8.0)
+    c = pkg.EthCnn(device=0)
+    c.load_blob(blob)
+    c.set_thresholds(0.5, 0.5)
+    whole = str(tmp_path / "whole.dat")
+    assert c.predict_yuv_file(yuv, w, h, qp, whole) == frames
+    sharded = str(tmp_path / "sharded.dat")
+    with open(sharded, "wb") as f:
+        f.truncate(frames * nctu * 84)
+    from importlib import import_module
+    sharding = import_module("hevc-complexity-reduction_amd.sharding")
+    ranges = [sharding.frame_range(frames, 8, r) for r in range(8)]
+    assert ranges[0][0] == 0 and ranges[-1][1] == frames and max(b - a for a, b in ranges) == 2
+    for a, b in reversed(ranges):  # any order: the ranges are disjoint
+        c.predict_yuv_shard(yuv, w, h, qp, sharded, a, b)
+    c.close()
+    A, B = open(whole, "rb").read(), open(sharded, "rb").read()
+    assert len(A) == frames * nctu * 84 and A == B
+    P = np.frombuffer(A, dtype="<f4").reshape(frames, nctu, 21)
+    for fidx in (0, 5, 8):
+        want = oracle.predict_frames(blob, luma[fidx], w, h, 1, qp, 0.5, 0.5, mode=0)
+        assert np.array_equal(_bits(P[fidx]), _bits(want)), "frame %d" % fidx
 
 
 def test_against_reference_graph_golden(ctx, oracle):
