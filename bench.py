@@ -226,6 +226,8 @@ def main():
         # sanity: the benchmark output is the real thing (first frame vs oracle), outside the timed region
         if not ldp:
             result["parity_first_frame_bit_exact"] = first_frame_parity(ctx, d_out, luma, W, H, QP, nctu)
+            if world == 1 and not args.no_cpu_baseline:
+                result["decision_stability"] = decision_stability(ctx, luma, W, H, QP)
         print(json.dumps(result))
         sys.stdout.flush()
     d_in.free()
@@ -246,6 +248,29 @@ def first_frame_parity(ctx, d_out, luma, W, H, QP, nctu):
         want = oracle.predict_frames(ctx.get_blob(), luma[0], W, H, 1, QP, 0.5, 0.5, mode=0)
         return bool(np.array_equal(got.view(np.uint32), want.view(np.uint32)))
     except Exception as exc:  # the oracle is a checker only; never fatal for the measurement
+        return "unchecked: %s" % exc
+
+
+def decision_stability(ctx, luma, W, H, QP, frames=2):
+    """knife-edge accounting on the first frames of the workload (oracle/stability.py; the full C3 x 4 QP x 2 gain
+    table is profiles/r02_decision_stability.json): outputs near a shipped threshold and thresholded decisions that
+    differ from the literal-TF-order fp32 and the float64 evaluations of the same graph"""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import stability
+        frames = min(frames, luma.shape[0])
+        t1, t2 = ctx.get_thresholds()
+        ctx.set_thresholds(-1.0, -1.0)
+        got = ctx.predict_luma(luma[:frames], W, H, frames, QP)
+        ctx.set_thresholds(t1, t2)
+        lit, f64 = stability.ungated_references(ctx.get_blob(), luma[:frames], W, H, frames, QP)
+        rep = stability.report(got, lit, f64)
+        near = {b: sum(d["within_" + b] for d in rep["thresholds"].values()) for b in ("1e-06", "1e-05", "0.0001")}
+        return {"sample": "first %d frame(s), %d outputs x %d shipped thresholds" % (frames, rep["outputs"], len(rep["thresholds"])),
+                "max_abs_vs_literal_fp32": rep["max_abs_vs_literal_fp32"], "max_abs_vs_float64": rep["max_abs_vs_float64"],
+                "flips_vs_literal_fp32": rep["flips_vs_literal_fp32_total"], "flips_vs_float64": rep["flips_vs_float64_total"],
+                "outputs_within_of_a_threshold": near}
+    except Exception as exc:
         return "unchecked: %s" % exc
 
 

@@ -23,6 +23,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import ethcnn_np as oracle  # noqa: E402  (only for the seeded weight generator + tensor table)
 import meta_graph as mg  # noqa: E402
+sys.path.insert(0, HERE)
+import ctu_gen  # noqa: E402
 
 
 def ctus_ai(rng, n):
@@ -57,6 +59,31 @@ def main():
     out["ldp_ctus"] = ctus
     out["ldp_vec"] = vec
     print("ldp ops executed:", sorted(ops))
+    # large sets: inputs regenerated from (seed, n) by tests/golden/ctu_gen.py, only the outputs are stored
+    nodes = mg.load_nodes(mg.AI_META)
+    for tag, seed, gain, qp, gseed, n in (("ai_c", 34, 1.0, 32, 7001, 1024), ("ai_d", 35, 8.0, 27, 7002, 1024),
+                                          ("ai_e", 36, 8.0, 37, 7003, 256)):
+        blob = oracle.synth_blob(seed, gain)
+        ctus = ctu_gen.make_ctus(gseed, n)
+        probs = np.empty((n, 21), dtype=np.float32)
+        feat8 = None
+        for s0 in range(0, n, 128):
+            p_, f_, _ = mg.run_ai_graph(nodes, dict(oracle.tensor_views(blob)), ctus[s0:s0 + 128], qp)
+            probs[s0:s0 + 128] = p_
+            if s0 == 0:
+                feat8 = f_[:8]
+        out[tag + "_seed_gain_qp"] = np.array([seed, gain, qp], dtype=np.float64)
+        out[tag + "_gen"] = np.array([gseed, n, ctu_gen.crc(ctus)], dtype=np.int64)
+        out[tag + "_probs"] = probs
+        out[tag + "_feat8"] = feat8
+        print(tag, n, "CTUs, p range", probs.min(), probs.max())
+    nodes = mg.load_nodes(mg.LDP_CNN_META)
+    blob = oracle.synth_blob(37, 1.0)
+    ctus = ctu_gen.make_ctus(7004, 256, residual=True)
+    vec, _ = mg.run_resi_graph(nodes, dict(oracle.tensor_views(blob)), ctus)
+    out["ldp_b_seed_gain"] = np.array([37, 1.0], dtype=np.float64)
+    out["ldp_b_gen"] = np.array([7004, 256, ctu_gen.crc(ctus)], dtype=np.int64)
+    out["ldp_b_vec"] = vec
     path = os.path.join(HERE, "meta_exec_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")

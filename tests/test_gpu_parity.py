@@ -241,18 +241,28 @@ def test_against_reference_graph_golden(ctx, oracle):
     (tests/golden/meta_exec_golden.npz; tests/test_meta_graph.py explains them): <= 1e-5."""
     import os
     gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "meta_exec_golden.npz"))
+    from test_meta_graph import _ctus
     ctx.set_thresholds(-1.0, -1.0)  # the saved graph has no gates: compare ungated probabilities
-    for tag in ("ai_a", "ai_b"):
+    total = 0
+    for tag in ("ai_a", "ai_b", "ai_c", "ai_d", "ai_e"):  # 2,388 CTUs incl. zero-padded edges, flat and saturated tiles
         seed, gain, qp = gold[tag + "_seed_gain_qp"]
         ctx.load_blob(oracle.synth_blob(int(seed), float(gain)))
-        got = ctx.predict_ctus(gold[tag + "_ctus"], int(qp))
-        assert np.abs(got - gold[tag + "_probs"]).max() <= 1e-5
-    seed, gain = gold["ldp_seed_gain"]
-    ctx.load_blob(oracle.synth_blob(int(seed), float(gain)))
-    ctus = gold["ldp_ctus"]
-    luma = np.ascontiguousarray(ctus.transpose(1, 0, 2).reshape(64, -1))
-    vec = ctx.resi_vectors(luma, 64 * ctus.shape[0], 64)
-    assert np.abs(vec - gold["ldp_vec"]).max() <= 1e-5
+        want = gold[tag + "_probs"]
+        got = ctx.predict_ctus(_ctus(gold, tag), int(qp))
+        total += got.shape[0]
+        assert np.abs(got - want).max() <= 1e-5
+        for thr in (0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8):  # thresholded decisions, away from the knife edge
+            far = np.abs(want - thr) > 1e-5
+            assert np.array_equal((got > thr)[far], (want > thr)[far])
+            assert far.mean() > 0.99
+    assert total >= 2000
+    for tag in ("ldp", "ldp_b"):
+        seed, gain = gold[tag + "_seed_gain"]
+        ctx.load_blob(oracle.synth_blob(int(seed), float(gain)))
+        ctus = _ctus(gold, tag)
+        luma = np.ascontiguousarray(ctus.transpose(1, 0, 2).reshape(64, -1))
+        vec = ctx.resi_vectors(luma, 64 * ctus.shape[0], 64)
+        assert np.abs(vec - gold[tag + "_vec"]).max() <= 1e-5
     ctx.set_thresholds(0.5, 0.5)
 
 
