@@ -289,6 +289,48 @@ static void ctu_fc1(const float* F, const float* blob, int mode, float* H1) {
     }
 }
 
+/* The same FC1 for a block of up to FC1_CB CTUs at once: every (CTU, output) accumulator is the SAME fmaf chain in the
+ * SAME k order as ctu_fc1 (bit-identical results; tests/test_oracle_golden.py compares them) -- only the loop nest differs:
+ * a 16-output tile of W1 is swept once per CTU block instead of once per CTU, with the accumulators in registers, so
+ * the 4.8 MB of FC1 weights are streamed 1/8 as often.  Without this the all-core CPU baseline of bench.py is
+ * weight-bandwidth-bound (22 k CTU/s on 256 threads vs 7 k on one). */
+#define FC1_CB 8
+#if defined(__AVX2__) && defined(__FMA__)
+#include <immintrin.h>
+static void block_fc1(const float* F /* [nb][NFEAT] */, int nb, const float* blob, int mode, float* H1 /* [nb][NH1] */) {
+    int o = 0;
+    for (int h = 0; h < 3; ++h) {
+        const int n1 = N1[h];
+        const float* W = blob + OFF_FC1W[h];
+        const float* b = blob + OFF_FC1B[h];
+        for (int f0 = 0; f0 < n1; f0 += 16) {
+            __m256 acc[FC1_CB][2];
+            for (int c = 0; c < FC1_CB; ++c) acc[c][0] = acc[c][1] = _mm256_setzero_ps();
+            for (int t = 0; t < NFEAT; ++t) {
+                const int k = fc_k(t, mode);
+                const __m256 w0 = _mm256_loadu_ps(W + (size_t)k * n1 + f0), w1 = _mm256_loadu_ps(W + (size_t)k * n1 + f0 + 8);
+                for (int c = 0; c < nb; ++c) {
+                    const __m256 a = _mm256_broadcast_ss(F + (size_t)c * NFEAT + k);
+                    acc[c][0] = _mm256_fmadd_ps(a, w0, acc[c][0]); /* one rounding: fmaf per lane */
+                    acc[c][1] = _mm256_fmadd_ps(a, w1, acc[c][1]);
+                }
+            }
+            for (int c = 0; c < nb; ++c) {
+                float tmp[16];
+                _mm256_storeu_ps(tmp, acc[c][0]);
+                _mm256_storeu_ps(tmp + 8, acc[c][1]);
+                for (int j = 0; j < 16; ++j) H1[(size_t)c * NH1 + o + f0 + j] = lrelu(tmp[j] + b[f0 + j]);
+            }
+        }
+        o += n1;
+    }
+}
+#else
+static void block_fc1(const float* F, int nb, const float* blob, int mode, float* H1) {
+    for (int c = 0; c < nb; ++c) ctu_fc1(F + (size_t)c * NFEAT, blob, mode, H1 + (size_t)c * NH1);
+}
+#endif
+
 /* FC2 + FC3 + sigmoid: probs_raw[21] (before the batch gates), optional logits[21]. */
 static void ctu_heads(const float* H1, const float* blob, float qn, int mode, float* probs, float* logits) {
     int o1 = 0, o3 = 0;
@@ -410,12 +452,13 @@ int oracle_predict_frames(const float* blob, const uint8_t* luma, int w, int h, 
         for (int f = 0; f < nf; ++f)
             oracle_tile_frame(luma + (size_t)(f0 + f) * frame_stride, w, h, pitch, ctus + (size_t)f * nctu * 4096);
         float* P = probs + (size_t)f0 * nctu * NOUT;
-#pragma omp parallel for schedule(dynamic, 2)
-        for (int i = 0; i < nf * nctu; ++i) {
-            float F[NFEAT], H1[NH1];
-            ctu_features(ctus + (size_t)i * 4096, blob, mode, 0, o1, o2, o3, F);
-            ctu_fc1(F, blob, mode, H1);
-            ctu_heads(H1, blob, qn, mode, P + (size_t)i * NOUT, (float*)0);
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int i0 = 0; i0 < nf * nctu; i0 += FC1_CB) {
+            float F[FC1_CB][NFEAT], H1[FC1_CB][NH1];
+            const int nb = (nf * nctu - i0 < FC1_CB) ? nf * nctu - i0 : FC1_CB;
+            for (int c = 0; c < nb; ++c) ctu_features(ctus + (size_t)(i0 + c) * 4096, blob, mode, 0, o1, o2, o3, F[c]);
+            block_fc1(&F[0][0], nb, blob, mode, &H1[0][0]);
+            for (int c = 0; c < nb; ++c) ctu_heads(H1[c], blob, qn, mode, P + (size_t)(i0 + c) * NOUT, (float*)0);
         }
         for (int f = 0; f < nf; ++f) oracle_gates(P + (size_t)f * nctu * NOUT, nctu, 1024, thr1, thr2);
     }
@@ -432,11 +475,12 @@ int oracle_resi_vectors(const float* blob, const uint8_t* luma, int w, int h, lo
     uint8_t* ctus = (uint8_t*)malloc((size_t)nctu * 4096);
     if (!ctus) return -1;
     oracle_tile_frame(luma, w, h, pitch, ctus);
-#pragma omp parallel for schedule(dynamic, 4)
-    for (int i = 0; i < nctu; ++i) {
-        float F[NFEAT];
-        ctu_features(ctus + (size_t)i * 4096, blob, mode, 1, o1, o2, o3, F);
-        ctu_fc1(F, blob, mode, vec + (size_t)i * NH1);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int i0 = 0; i0 < nctu; i0 += FC1_CB) {
+        float F[FC1_CB][NFEAT];
+        const int nb = (nctu - i0 < FC1_CB) ? nctu - i0 : FC1_CB;
+        for (int c = 0; c < nb; ++c) ctu_features(ctus + (size_t)(i0 + c) * 4096, blob, mode, 1, o1, o2, o3, F[c]);
+        block_fc1(&F[0][0], nb, blob, mode, vec + (size_t)i0 * NH1);
     }
     free(ctus);
     return 0;

@@ -1,0 +1,41 @@
+#!/bin/bash
+# copies the judged summaries of the last scripts/gpu_round.sh call from gpurun_out/ (scratch) to profiles/ (tracked)
+# usage: scripts/collect_round.sh r02
+set -eu
+R=${1:-r02}
+cd "$(dirname "$0")/.."
+for wl in c2 c3 c4 c5; do [ -s gpurun_out/bench_$wl.json ] && cp gpurun_out/bench_$wl.json profiles/${R}_bench_$wl.json; done
+for wl in c2 c3; do
+  [ -s gpurun_out/prof_$wl/${wl}_kernel_stats.csv ] && cp gpurun_out/prof_$wl/${wl}_kernel_stats.csv profiles/${R}_rocprofv3_kernel_stats_$wl.csv
+done
+[ -s gpurun_out/latency.txt ] && cp gpurun_out/latency.txt profiles/${R}_latency.txt
+[ -s gpurun_out/latency_ldp.txt ] && cp gpurun_out/latency_ldp.txt profiles/${R}_latency_ldp.txt
+python - "$R" <<'PY'
+import csv, glob, collections, json, sys
+R = sys.argv[1]
+# per-kernel PMC averages of the default workload's passes
+lines = []
+for f in sorted(glob.glob("gpurun_out/pmc_c3_*/**/*counter_collection.csv", recursive=True)):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"][:60]
+        if "ethcnn" not in k: continue
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(k, r["Counter_Name"])] += 1
+    for k, d in agg.items():
+        lines.append("%-62s %s" % (k, {c: "%.5g" % (v / cnt[(k, c)]) for c, v in d.items()}))
+if lines:
+    open("profiles/%s_pmc_c3.txt" % R, "w").write(
+        "# rocprofv3 --pmc passes (one counter set per pass, --kernel-trace only) of `python bench.py --workload c3 --no-cpu-baseline\n"
+        "# --no-host-scopes --steps 5 --warmup 1` (scripts/gpu_round.sh); per-dispatch averages.  FETCH_SIZE / WRITE_SIZE in KB as\n"
+        "# reported (FETCH_SIZE x2 on gfx950 for bytes); SQ_* summed over the chip; GRBM_GUI_ACTIVE summed over the 8 XCDs.\n" + "\n".join(lines) + "\n")
+# FC1 traffic: merge the per-workload results into profiles/fc1_traffic.json
+try:
+    cur = json.load(open("profiles/fc1_traffic.json"))
+except Exception:
+    cur = {}
+for f in glob.glob("gpurun_out/fc1_traffic_*.json"):
+    cur.update(json.load(open(f)))
+json.dump(cur, open("profiles/fc1_traffic.json", "w"), indent=1)
+print("fc1_traffic workloads:", sorted(cur))
+PY
+ls profiles | grep "^$R" | tr '\n' ' '; echo

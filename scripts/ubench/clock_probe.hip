@@ -1,0 +1,145 @@
+// Microbenchmark 4: is the "cost" of VALU / VMEM beside fp32 MFMAs (mfma_valu / mfma_mix / mfma_vmem, all timed on the
+// wall at an ASSUMED 2.4 GHz) issue time on the matrix pipe, or a lower sustained CLOCK?  Every wave brackets its loop
+// with s_memtime (shader-clock ticks, MI355X_MICROARCH.md constants table) and s_memrealtime (constant 100 MHz), so
+//   cycles per MFMA   = d(memtime) / MFMAs per SIMD          (pipe occupancy in real shader cycles)
+//   effective clock   = d(memtime) / d(memrealtime) * 100 MHz
+// are both measured inside the kernel, next to the wall-clock rate.   hipcc --offload-arch=gfx950 -O3
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ unsigned long long memtime() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+__device__ __forceinline__ unsigned long long memrealtime() {
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+
+// KIND: 0 mfma16 only | 1 mfma16 + VPM v_fma each | 2 mfma32 only | 3 mfma32 + VPM v_fma each | 4 mfma16 + VPM ds_read_b32 each
+//       5 mfma16 + one global_load_lds_dwordx4 per 16 MFMAs (x VPM) | 6 VALU only (VPM per slot)
+//       10 / 11 / 14 / 15 = 0 / 1 / 4 / 5 with the accumulators in AGPRs (inline asm, "a" constraint): do VALU / LDS / VMEM
+//       still cost matrix-pipe time when the MFMA's C/D traffic is on the AccVGPR side of the register file?
+//       12 = AGPR accumulators AND the B operand read from an AGPR (the trunk's layer chaining without leaving the AGPRs)
+template <int KIND, int VPM>
+__global__ void k(unsigned long long* stamps, const float* src, int iters, float a0) {
+    __shared__ float lds[8192];
+    for (int i = threadIdx.x; i < 8192; i += blockDim.x) lds[i] = a0 + i;
+    __syncthreads();
+    f32x4 acc[4];
+    f32x16 big[2];
+    for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 16; ++j) big[i][j] = 0.f;
+    float v[8];
+    for (int i = 0; i < 8; ++i) v[i] = a0 + threadIdx.x * 0.001f + i;
+    const float a = a0 + (threadIdx.x & 7) * 0.25f, b = a0 * 0.5f + (threadIdx.x & 3);
+    float bacc = b;
+    if (KIND == 12) asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(bacc) : "v"(b));
+    const unsigned la = (threadIdx.x & 63) * 4;
+    const float* gp = src + (threadIdx.x & 63) * 4;
+    const unsigned ldsdst = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds + 16384 + (threadIdx.x >> 6) * 1024;
+    const unsigned long long t0 = memtime(), r0 = memrealtime();
+    for (int it = 0; it < iters; ++it) {
+        if (KIND == 5 || KIND == 15) {
+#pragma unroll
+            for (int q = 0; q < VPM; ++q) {
+                unsigned keep;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(ldsdst);
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(gp), "s"(dst) : "memory");
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            if (KIND == 0 || KIND == 1 || KIND == 4 || KIND == 5) acc[m & 3] = MFMA16(a, b, acc[m & 3]);
+            if (KIND == 10 || KIND == 11 || KIND == 14 || KIND == 15)
+                asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[m & 3]) : "v"(a), "v"(b));
+            if (KIND == 12) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[m & 3]) : "v"(a), "a"(bacc));
+            if ((KIND == 2 || KIND == 3) && (m & 1) == 0) big[(m >> 1) & 1] = MFMA32(a, b, big[(m >> 1) & 1]);  // same FLOP per slot pair
+            if (KIND == 1 || KIND == 3 || KIND == 6 || KIND == 11 || KIND == 12) {
+#pragma unroll
+                for (int q = 0; q < VPM; ++q) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[(m * VPM + q) & 7]) : "v"(a), "v"(b));
+            }
+            if (KIND == 4 || KIND == 14) {
+#pragma unroll
+                for (int q = 0; q < VPM; ++q) asm volatile("ds_read_b32 %0, %1" : "=v"(v[(m * VPM + q) & 7]) : "v"(la) : "memory");
+            }
+        }
+        if (KIND == 4 || KIND == 14) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (KIND == 5 || KIND == 15) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    const unsigned long long t1 = memtime(), r1 = memrealtime();
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 16; ++j) s += big[i][j];
+    for (int i = 0; i < 8; ++i) s += v[i];
+    if ((threadIdx.x & 63) == 0) {
+        const size_t w = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        stamps[2 * w] = t1 - t0;
+        stamps[2 * w + 1] = r1 - r0;
+    }
+    if (s == 12345.678f) stamps[0] = (unsigned long long)s;
+}
+
+template <int KIND, int VPM>
+static void run(const char* name, int wps) {
+    const int blocks = 256, threads = 256 * wps, nw = blocks * threads / 64, iters = 20000;
+    unsigned long long* d;
+    float* src;
+    hipMalloc(&d, (size_t)nw * 16);
+    hipMalloc(&src, 1 << 20);
+    hipMemset(src, 0, 1 << 20);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int rep = 0; rep < 3; ++rep) k<KIND, VPM><<<blocks, threads>>>(d, src, iters, 1.0f);  // clock ramp (~100 ms of load)
+    hipEventRecord(e0);
+    k<KIND, VPM><<<blocks, threads>>>(d, src, iters, 1.0f);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned long long> h((size_t)nw * 2);
+    hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
+    double st = 0, sr = 0;
+    for (int w = 0; w < nw; ++w) { st += (double)h[2 * w]; sr += (double)h[2 * w + 1]; }
+    st /= nw; sr /= nw;
+    const double slots = 16.0 * iters * wps;  // MFMA16-equivalent slots per SIMD
+    const double flop = (KIND == 6) ? 0.0 : 2048.0 * 16 * iters * (double)nw;
+    printf("%-44s w%d  wall %7.3f ms %6.1f TF | memtime/slot %6.2f  memtime %.3e  realtime %.3e  clock %7.1f MHz (if memtime = shader clk) | wall cyc/slot @2.4GHz %5.1f\n",
+           name, wps, ms, flop / (ms * 1e-3) / 1e12, st / slots, st, sr, sr > 0 ? st / sr * 100.0 : 0.0, ms * 1e-3 * 2.4e9 / slots);
+    hipFree(d);
+    hipFree(src);
+}
+
+int main() {
+    for (int w = 1; w <= 3; ++w) {
+        run<0, 0>("mfma16x16x4 only", w);
+        run<1, 2>("mfma16x16x4 + 2 v_fma per MFMA", w);
+        run<1, 4>("mfma16x16x4 + 4 v_fma per MFMA", w);
+        run<2, 0>("mfma32x32x2 only (1 per 2 slots)", w);
+        run<3, 2>("mfma32x32x2 + 2 v_fma per slot", w);
+        run<4, 1>("mfma16x16x4 + 1 ds_read_b32 per MFMA", w);
+        run<5, 1>("mfma16x16x4 + 1 LDS-DMA per 16 MFMA", w);
+        run<5, 2>("mfma16x16x4 + 2 LDS-DMA per 16 MFMA", w);
+        run<6, 2>("v_fma only (2 per slot)", w);
+        run<10, 0>("AGPR acc: mfma16x16x4 only", w);
+        run<11, 2>("AGPR acc: mfma16x16x4 + 2 v_fma per MFMA", w);
+        run<11, 4>("AGPR acc: mfma16x16x4 + 4 v_fma per MFMA", w);
+        run<12, 2>("AGPR acc + AGPR B operand + 2 v_fma", w);
+        run<14, 1>("AGPR acc: mfma16x16x4 + 1 ds_read_b32", w);
+        run<15, 1>("AGPR acc: + 1 LDS-DMA per 16 MFMA", w);
+        run<15, 2>("AGPR acc: + 2 LDS-DMA per 16 MFMA", w);
+    }
+    return 0;
+}

@@ -154,3 +154,23 @@ def test_meta_concat_order_and_qp_last():
     fc_cats = [v for k, v in META.items() if v["op"] == "ConcatV2" and k != "concat" and len(v["inputs"]) == 3]
     assert len(fc_cats) == 6 and all(v["inputs"][1] == "mul_1" for v in fc_cats)   # [h, qp]: qp LAST
     assert META["mul_1"]["inputs"] == ["scalar_1", "Placeholder_2"]
+
+
+def test_blocked_fc1_is_bit_identical_to_the_per_ctu_chain(oracle):
+    """oracle_predict_frames / oracle_resi_vectors run FC1 for 8 CTUs at a time (W1 tiles reused, accumulators in
+    registers); the staged per-CTU functions are the plain restatement.  Same chains, same bits, both modes, ragged
+    block tails (n % 8 != 0)."""
+    import bench
+    w, h = 64 * 7, 64 * 3 - 9  # 21 CTUs: two full blocks + a tail of 5
+    luma = bench.synth_luma(w, h, 2, seed=12)
+    blob = oracle.synth_blob(7, 8.0)
+    for mode in (0, 1):
+        whole = oracle.predict_frames(blob, luma, w, h, 2, 27, 0.5, 0.5, mode=mode)
+        for f in range(2):
+            ctus = oracle.tile_frame(luma[f], w, h)
+            P, _ = oracle.heads(blob, oracle.fc1(blob, oracle.features(blob, ctus, mode=mode), mode), 27, mode)
+            want = oracle.gates(P, 0.5, 0.5)
+            assert np.array_equal(whole[f * 21:(f + 1) * 21].view(np.uint32), want.view(np.uint32))
+        ctus = oracle.tile_frame(luma[0], w, h)
+        V = oracle.resi_vectors(blob, luma[0], w, h, mode=mode)
+        assert np.array_equal(V.view(np.uint32), oracle.fc1(blob, oracle.features(blob, ctus, mode=mode, resi=1), mode).view(np.uint32))
