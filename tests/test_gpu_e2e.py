@@ -30,40 +30,89 @@ def _need(*exes):
     pytest.skip("oracle/_ref was never built (no /root/reference at build time)")
 
 
-def _encode(exe, cwd, w, h, frames, qp, env):
+def _encode(exe, cwd, w, h, frames, qp, env, extra=()):
     r = subprocess.run([exe, "-c", os.path.join(ROOT, "scripts", "hm_intra_test.cfg"), "-i", "seq.yuv", "-wdt", str(w), "-hgt", str(h),
-                        "-fr", "30", "-f", str(frames), "-q", str(qp), "-b", "str.bin", "-o", ""],
+                        "-fr", "30", "-f", str(frames), "-q", str(qp), "-b", "str.bin", "-o", ""] + list(extra),
                        cwd=str(cwd), env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     return hashlib.md5(open(os.path.join(str(cwd), "str.bin"), "rb").read()).hexdigest(), r.stdout
 
 
+def _yuv(luma):
+    w, h = luma.shape[2], luma.shape[1]
+    return np.concatenate([np.concatenate([luma[f].reshape(-1), np.full(w * h // 2, 128, np.uint8)]) for f in range(luma.shape[0])])
+
+
 def test_all_intra_drop_in_with_the_reference_encoder(oracle, tmp_path):
     """The whole drop-in: the reference's unchanged HM runs `python video_to_cu_depth.py <yuv> <w> <h> <qp>`
     (TAppEncCfg.cpp:2317-2321) in its cwd, where that name is a symlink to this repository's launcher;
-    cu_depth.dat is bit-exact vs the oracle, HM consumes it, and the in-process hook build (SURVEY 8f
-    row 3) produces the same file and the same bitstream."""
+    cu_depth.dat is bit-exact vs the oracle and HM consumes it.  The in-process build (SURVEY 8f row 3,
+    tools/hm_inprocess_patch.py) runs no predictor up front and writes no cu_depth.dat: TEncCu::compressCtu hands
+    every picture's own luma to libethcnn.so -- same probabilities (dumped for the check), same bitstream."""
     _need(HM_AI, HM_INPROC)
     sys.path.insert(0, ROOT)
     import bench
     w, h, frames, qp, seed, gain = 416, 240, 3, 32, 9, 8.0
     luma = bench.synth_luma(w, h, frames, 1)
-    yuv = np.concatenate([np.concatenate([luma[f].reshape(-1), np.full(w * h // 2, 128, np.uint8)]) for f in range(frames)])
+    yuv = _yuv(luma)
     env = dict(os.environ, ETHCNN_SYNTHETIC_SEED=str(seed), ETHCNN_HEAD_GAIN=str(gain), ETHCNN_HOME=ROOT)
+    want = oracle.predict_frames(oracle.synth_blob(seed, gain), yuv, w, h, frames, qp, 0.5, 0.5, frame_stride=w * h * 3 // 2)
     md5 = {}
     for tag, exe in (("unchanged", HM_AI), ("inprocess", HM_INPROC)):
         d = tmp_path / tag
         d.mkdir()
         yuv.tofile(str(d / "seq.yuv"))
         (d / "Thr_info.txt").write_text("0.5 0.5 0.5 0.5 0.5 0.5")
+        e = dict(env)
         if tag == "unchanged":
             os.symlink(os.path.join(ROOT, "video_to_cu_depth.py"), str(d / "video_to_cu_depth.py"))
-        md5[tag], out = _encode(exe, d, w, h, frames, qp, env)
-        got = np.fromfile(str(d / "cu_depth.dat"), dtype="<f4").reshape(-1, 21)
-        want = oracle.predict_frames(oracle.synth_blob(seed, gain), yuv, w, h, frames, qp, 0.5, 0.5, frame_stride=w * h * 3 // 2)
+        else:
+            e["ETHCNN_HM_DUMP"] = str(d / "probs_dump.dat")
+        md5[tag], out = _encode(exe, d, w, h, frames, qp, e)
+        got = np.fromfile(str(d / ("cu_depth.dat" if tag == "unchanged" else "probs_dump.dat")), dtype="<f4").reshape(-1, 21)
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), tag
-        assert ("Predicting Time" in out) if tag == "unchanged" else ("ethcnn (in-process)" in out)
+        if tag == "unchanged":
+            assert "Predicting Time" in out
+        else:
+            assert "in-process predictor" in out and "3 picture(s) predicted from the encoder's own luma buffers" in out
+            assert not (d / "cu_depth.dat").exists()  # no file round trip
     assert md5["unchanged"] == md5["inprocess"]
+
+
+def test_in_process_hook_honours_frame_skip(oracle, tmp_path):
+    """FrameSkip / FramesToBeEncoded (VERDICT r01 task 7): the file-based reference predicts every frame from 0 and
+    HM reads cu_depth.dat from its start whatever FrameSkip says (video_to_cu_depth.py:139-140).  The in-process
+    hook predicts exactly the pictures HM encodes: `-fs 2 -f 3` on a 6-frame file must give the bitstream the
+    UNCHANGED encoder gives on the pre-trimmed file (frames 2..4), and the dumped probabilities are those frames'."""
+    _need(HM_AI, HM_INPROC)
+    sys.path.insert(0, ROOT)
+    import bench
+    w, h, qp, seed, gain = 416, 240, 27, 4, 8.0
+    luma = bench.synth_luma(w, h, 6, 2)
+    env = dict(os.environ, ETHCNN_SYNTHETIC_SEED=str(seed), ETHCNN_HEAD_GAIN=str(gain), ETHCNN_HOME=ROOT)
+    a = tmp_path / "inprocess_skip"
+    a.mkdir()
+    _yuv(luma).tofile(str(a / "seq.yuv"))
+    (a / "Thr_info.txt").write_text("0.5 0.5 0.5 0.5 0.5 0.5")
+    md5_in, _ = _encode(HM_INPROC, a, w, h, 3, qp, dict(env, ETHCNN_HM_DUMP=str(a / "probs_dump.dat")), extra=("-fs", "2"))
+    b = tmp_path / "unchanged_trimmed"
+    b.mkdir()
+    _yuv(luma[2:5]).tofile(str(b / "seq.yuv"))
+    (b / "Thr_info.txt").write_text("0.5 0.5 0.5 0.5 0.5 0.5")
+    os.symlink(os.path.join(ROOT, "video_to_cu_depth.py"), str(b / "video_to_cu_depth.py"))
+    md5_ref, _ = _encode(HM_AI, b, w, h, 3, qp, env)
+    assert md5_in == md5_ref
+    got = np.fromfile(str(a / "probs_dump.dat"), dtype="<f4").reshape(-1, 21)
+    want = oracle.predict_frames(oracle.synth_blob(seed, gain), luma[2:5], w, h, 3, qp, 0.5, 0.5)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # for the record (not asserted): what the unchanged file-based flow does with FrameSkip on the full file
+    c = tmp_path / "unchanged_skip"
+    c.mkdir()
+    _yuv(luma).tofile(str(c / "seq.yuv"))
+    (c / "Thr_info.txt").write_text("0.5 0.5 0.5 0.5 0.5 0.5")
+    os.symlink(os.path.join(ROOT, "video_to_cu_depth.py"), str(c / "video_to_cu_depth.py"))
+    md5_quirk, _ = _encode(HM_AI, c, w, h, 3, qp, env, extra=("-fs", "2"))
+    print("file-based reference flow with FrameSkip=2: bitstream %s the correct one" % ("equals" if md5_quirk == md5_ref else "differs from"))
 
 
 def test_low_delay_p_with_the_reference_encoder(tmp_path):

@@ -11,19 +11,28 @@
  * Same files in the encoder's cwd (Thr_info.txt, model_2000000_qpXX~YY.dat.*), same output
  * (cu_depth.dat, read unchanged by TEncCu::compressCtu, TEncCu.cpp:237-261), 0 = success.
  * ETHCNN_SYNTHETIC_SEED / ETHCNN_HEAD_GAIN / ETHCNN_DEVICE as in the launchers.
+ *
+ * ethcnn_hm_predict_picture is the REAL in-process form (tools/hm_inprocess_patch.py applies it to a copy
+ * of the encoder source): no predictor run before encoding, no second read of the YUV file, no
+ * cu_depth.dat.  TEncCu::compressCtu, at the first CTU of every picture it encodes, hands over that
+ * picture's own luma plane (TComPicYuv, 16-bit Pel samples with a stride) and receives the nCtu*21
+ * probabilities it stores with TComPic::setCUDepth (TEncCu.cpp:256-259, TComPic.h:84-88).  Only the
+ * pictures HM actually encodes are predicted, so FrameSkip / FramesToBeEncoded are honoured -- the
+ * file-based reference predicts every frame from 0 and then reads cu_depth.dat from its start
+ * whatever FrameSkip says (video_to_cu_depth.py:139-140).
  */
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include "ethcnn.h"
 
-int ethcnn_hm_predict(const char* yuv, int width, int height, int qp) {
+/* context + thresholds + weights for sequence QP `qp`, as the launcher sets them up; NULL on failure */
+static ethcnn_ctx* open_predictor(int qp) {
     ethcnn_ctx* ctx = NULL;
     ethcnn_options opt;
     char model[64], data[96];
-    int64_t nframes = 0;
-    int rc = 1;
     const char* seed = getenv("ETHCNN_SYNTHETIC_SEED");
     const char* dev = getenv("ETHCNN_DEVICE");
     FILE* f;
@@ -31,8 +40,8 @@ int ethcnn_hm_predict(const char* yuv, int width, int height, int qp) {
     memset(&opt, 0, sizeof opt);
     opt.device = dev ? atoi(dev) : 0;
     if (ethcnn_create(&ctx, &opt) != ETHCNN_OK) {
-        fprintf(stderr, "ethcnn_hm_predict: %s\n", ethcnn_last_error(NULL));
-        return 1;
+        fprintf(stderr, "ethcnn (in-process): %s\n", ethcnn_last_error(NULL));
+        return NULL;
     }
     if (ethcnn_load_thresholds(ctx, "Thr_info.txt") != ETHCNN_OK) goto fail;
     if (ethcnn_model_name_for_qp(qp, model, sizeof model) != ETHCNN_OK) goto fail;
@@ -45,8 +54,88 @@ int ethcnn_hm_predict(const char* yuv, int width, int height, int qp) {
         const char* gain = getenv("ETHCNN_HEAD_GAIN");
         if (ethcnn_load_synthetic(ctx, (uint64_t)strtoull(seed, NULL, 10), gain ? atof(gain) : 1.0) != ETHCNN_OK) goto fail;
     }
+    return ctx;
+fail:
+    fprintf(stderr, "ethcnn (in-process): %s\n", ethcnn_last_error(ctx));
+    ethcnn_destroy(ctx);
+    return NULL;
+}
+
+/* ---- per-picture entry (the real in-process hook) ------------------------------------------- */
+static ethcnn_ctx* g_ctx = NULL;
+static int g_qp = -1;
+static unsigned char* g_luma8 = NULL;
+static size_t g_luma8_cap = 0;
+static long g_pictures = 0;
+
+static void close_predictor(void) {
+    if (g_ctx) {
+        printf("ethcnn (in-process): %ld picture(s) predicted from the encoder's own luma buffers\n", g_pictures);
+        ethcnn_destroy(g_ctx);
+    }
+    g_ctx = NULL;
+    free(g_luma8);
+    g_luma8 = NULL;
+}
+
+/* luma: `height` rows of `width` 16-bit samples, `stride` samples apart, `bit_depth` bits each (HM's
+ * Pel plane of the picture being encoded; the reference feeds 8-bit files, InternalBitDepth 8: deeper
+ * internal formats are shifted back to the 8 bits the network was trained on).  probs: nCtu*21 floats,
+ * the layout TEncCu::xCompressCU reads (TEncCu.cpp:419-463).  0 = success. */
+int ethcnn_hm_predict_picture(const short* luma, int stride, int width, int height, int bit_depth, int qp, float* probs) {
+    const int shift = bit_depth > 8 ? bit_depth - 8 : 0;
+    const size_t need = (size_t)width * (size_t)height;
+    int x, y;
+    if (!luma || !probs || width <= 0 || height <= 0 || stride < width) return 1;
+    if (!g_ctx || qp != g_qp) {
+        if (g_ctx) ethcnn_destroy(g_ctx);
+        else atexit(close_predictor);
+        g_ctx = open_predictor(qp);
+        g_qp = qp;
+        if (!g_ctx) return 1;
+    }
+    if (need > g_luma8_cap) {
+        free(g_luma8);
+        g_luma8 = (unsigned char*)malloc(need);
+        g_luma8_cap = g_luma8 ? need : 0;
+        if (!g_luma8) return 1;
+    }
+    for (y = 0; y < height; ++y) {
+        const short* src = luma + (size_t)y * stride;
+        unsigned char* dst = g_luma8 + (size_t)y * width;
+        for (x = 0; x < width; ++x) {
+            int v = src[x] >> shift;
+            dst[x] = (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        }
+    }
+    if (ethcnn_predict_luma(g_ctx, g_luma8, width, height, width, (ptrdiff_t)need, 1, qp, probs) != ETHCNN_OK) {
+        fprintf(stderr, "ethcnn (in-process): %s\n", ethcnn_last_error(g_ctx));
+        return 1;
+    }
+    {   /* verification aid: ETHCNN_HM_DUMP=<file> appends every picture's probabilities (tests compare them
+         * with the oracle); the encoder itself never reads it */
+        const char* dump = getenv("ETHCNN_HM_DUMP");
+        if (dump) {
+            const size_t n = (size_t)((width + 63) / 64) * (size_t)((height + 63) / 64) * 21;
+            FILE* f = fopen(dump, g_pictures ? "ab" : "wb");
+            if (f) {
+                fwrite(probs, sizeof(float), n, f);
+                fclose(f);
+            }
+        }
+    }
+    ++g_pictures;
+    return 0;
+}
+
+/* ---- whole-sequence entry (file-based, same contract as the reference's command line) -------- */
+int ethcnn_hm_predict(const char* yuv, int width, int height, int qp) {
+    ethcnn_ctx* ctx = open_predictor(qp);
+    int64_t nframes = 0;
+    int rc = 1;
+    if (!ctx) return 1;
     if (ethcnn_predict_yuv_file(ctx, yuv, width, height, qp, "cu_depth.dat", &nframes) != ETHCNN_OK) goto fail;
-    printf("ethcnn (in-process): %lld frames predicted on %s\n", (long long)nframes, "the GPU");
+    printf("ethcnn (in-process, file-based): %lld frames predicted on %s\n", (long long)nframes, "the GPU");
     rc = 0;
 fail:
     if (rc) fprintf(stderr, "ethcnn_hm_predict: %s\n", ethcnn_last_error(ctx));
