@@ -120,6 +120,8 @@ struct ethcnn_ctx {
     float* d_state[2] = {nullptr, nullptr};  // [lstm_cap][2][448] in / out
     float* d_lprobs = nullptr;    // [lstm_cap][21]
     int lstm_cap = 0;
+    int state_cur = -1;           // d_state[state_cur] = (c, h) left by the last ethcnn_ldp_step; -1 = none
+    int state_nctu = 0;
 
     Workspace ws;
     int max_ctus = 131072;
@@ -870,31 +872,69 @@ extern "C" int ethcnn_lstm_step_device(ethcnn_ctx* c, const float* d_vec, const 
     return ETHCNN_OK;
 }
 
-// predict_cu_depth() of resi_to_cu_depth_LDP.py:108-129 for one frame, host buffers
-extern "C" int ethcnn_ldp_predict_frame(ethcnn_ctx* c, const uint8_t* luma, int w, int h, ptrdiff_t pitch, int qp,
-                                        int i_frame, const float* state_in, float* state_out, float* probs) {
-    if (!c || !luma || !state_out || !probs) return c ? set_err(c, ETHCNN_ERR_ARG, "null pointer") : ETHCNN_ERR_ARG;
+// predict_cu_depth() of resi_to_cu_depth_LDP.py:108-129 for one frame; the new state stays in HBM.
+// state source: host `state_in` when given, else zeros (resident == false) or the previous step's state in HBM
+static int ldp_step_impl(ethcnn_ctx* c, const uint8_t* luma, int w, int h, ptrdiff_t pitch, int qp, int i_frame,
+                         const float* state_in, bool resident, float* probs) {
+    if (!c || !luma || !probs) return c ? set_err(c, ETHCNN_ERR_ARG, "null pointer") : ETHCNN_ERR_ARG;
     if (w <= 0 || h <= 0 || pitch < w) return set_err(c, ETHCNN_ERR_ARG, "bad geometry");
     if (!c->have_weights) return set_err(c, ETHCNN_ERR_NOWEIGHTS, "no CNN weights loaded");
     if (!c->have_lstm) return set_err(c, ETHCNN_ERR_NOWEIGHTS, "no LSTM weights loaded");
     const int nctu = ((w + 63) / 64) * ((h + 63) / 64);
-    const size_t lbytes = (size_t)(h - 1) * pitch + w;
+    const size_t lbytes = (size_t)(h - 1) * pitch + w;  // the meaningful bytes of a pitched plane
     int rc = ensure_staging(c, lbytes, (size_t)nctu * kNVec * 4);
     if (rc) return rc;
+    if (nctu > c->lstm_cap) c->state_cur = -1;  // the buffers are about to be reallocated
     rc = ensure_lstm_buffers(c, nctu);
     if (rc) return rc;
     const size_t sbytes = (size_t)nctu * 2 * kNVec * 4;
+    int in = -1;  // index of the input state buffer, -1 = zeros
+    if (state_in) {
+        in = 0;
+        HIPCHK(c, hipMemcpyAsync(c->d_state[in], state_in, sbytes, hipMemcpyHostToDevice, c->stream));
+    } else if (resident) {
+        if (c->state_cur < 0 || c->state_nctu != nctu)
+            return set_err(c, ETHCNN_ERR_ARG, "ethcnn_ldp_step: frame %d needs the previous frame's state, but none is resident for %d CTUs",
+                           i_frame, nctu);
+        in = c->state_cur;
+    }
+    const int out = (in == 0) ? 1 : 0;
     HIPCHK(c, hipMemcpyAsync(c->d_in[0], luma, lbytes, hipMemcpyHostToDevice, c->stream));
-    if (state_in) HIPCHK(c, hipMemcpyAsync(c->d_state[0], state_in, sbytes, hipMemcpyHostToDevice, c->stream));
     rc = ethcnn_resi_vectors_device(c, c->d_in[0], w, h, pitch, c->d_vec);
     if (rc) return rc;
-    rc = ethcnn_lstm_step_device(c, c->d_vec, state_in ? c->d_state[0] : nullptr, nctu, qp, i_frame, c->d_state[1],
-                                 c->d_lprobs);
+    rc = ethcnn_lstm_step_device(c, c->d_vec, in >= 0 ? c->d_state[in] : nullptr, nctu, qp, i_frame, c->d_state[out], c->d_lprobs);
     if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(state_out, c->d_state[1], sbytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(probs, c->d_lprobs, (size_t)nctu * kNOut * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->state_cur = out;
+    c->state_nctu = nctu;
     return ETHCNN_OK;
+}
+
+extern "C" int ethcnn_ldp_step(ethcnn_ctx* c, const uint8_t* luma, int w, int h, ptrdiff_t pitch, int qp, int i_frame,
+                               const float* state_in, float* probs) {
+    return ldp_step_impl(c, luma, w, h, pitch, qp, i_frame, state_in, /*resident=*/!state_in && i_frame > 1, probs);
+}
+
+extern "C" int ethcnn_ldp_get_state(ethcnn_ctx* c, float* state_out, size_t nfloats) {
+    if (!c || !state_out) return c ? set_err(c, ETHCNN_ERR_ARG, "null pointer") : ETHCNN_ERR_ARG;
+    if (c->state_cur < 0) return set_err(c, ETHCNN_ERR_ARG, "ethcnn_ldp_get_state: no resident state (call ethcnn_ldp_step first)");
+    if (nfloats != (size_t)c->state_nctu * 2 * kNVec)
+        return set_err(c, ETHCNN_ERR_ARG, "ethcnn_ldp_get_state: the resident state holds %zu floats, not %zu", (size_t)c->state_nctu * 2 * kNVec, nfloats);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(state_out, c->d_state[c->state_cur], nfloats * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ETHCNN_OK;
+}
+
+// the reference's per-frame call as one synchronous function: state in and out through host memory
+extern "C" int ethcnn_ldp_predict_frame(ethcnn_ctx* c, const uint8_t* luma, int w, int h, ptrdiff_t pitch, int qp,
+                                        int i_frame, const float* state_in, float* state_out, float* probs) {
+    if (!c || !luma || !state_out || !probs) return c ? set_err(c, ETHCNN_ERR_ARG, "null pointer") : ETHCNN_ERR_ARG;
+    int rc = ldp_step_impl(c, luma, w, h, pitch, qp, i_frame, state_in, /*resident=*/false, probs);  // NULL = zeros here
+    if (rc) return rc;
+    const int nctu = ((w + 63) / 64) * ((h + 63) / 64);
+    return ethcnn_ldp_get_state(c, state_out, (size_t)nctu * 2 * kNVec);
 }
 
 // ------------------------------------------------------------ device plumbing -------
@@ -907,6 +947,17 @@ extern "C" int ethcnn_device_alloc(ethcnn_ctx* c, size_t bytes, void** out) {
 extern "C" int ethcnn_device_free(ethcnn_ctx* c, void* p) {
     if (!c) return ETHCNN_ERR_ARG;
     if (p) HIPCHK(c, hipFree(p));
+    return ETHCNN_OK;
+}
+extern "C" int ethcnn_host_alloc(ethcnn_ctx* c, size_t bytes, void** out) {
+    if (!c || !out) return ETHCNN_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return ETHCNN_OK;
+}
+extern "C" int ethcnn_host_free(ethcnn_ctx* c, void* p) {
+    if (!c) return ETHCNN_ERR_ARG;
+    if (p) HIPCHK(c, hipHostFree(p));
     return ETHCNN_OK;
 }
 extern "C" int ethcnn_memcpy_h2d(ethcnn_ctx* c, void* dst, const void* src, size_t bytes) {

@@ -83,13 +83,25 @@ __global__ __launch_bounds__(64 * WM) void k_fc1_p3(const float* __restrict__ fe
         for (int j = 0; j < NS; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int ngroups = (M + 15) >> 4;
-    const float* a_src[MS];  // this lane's 16 B of the group's [k/4][16][4] image: linear in lane
+    // DMA addressing: every source is (wave-uniform 64-bit base in SGPRs) + (lane * 16 B in ONE VGPR), the
+    // `global_load_lds_dwordx4 vOffset, s[base:base+1]` form.  The per-chunk advance is scalar arithmetic (free beside
+    // MFMAs); the 64-bit per-lane addresses of the `vAddr, off` form cost two v_lshl_add_u64 per DMA and two VGPR
+    // address reads -- VALU / VGPR-port time that comes straight out of the matrix pipe on gfx950
+    // (profiles/r01_ubench_gfx950_issue_costs.txt).  LDS destinations are wave-uniform too (M0).
+    const unsigned wvu = __builtin_amdgcn_readfirstlane(wv);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const int mg0 = __builtin_amdgcn_readfirstlane(m0 >> 4);
+    const float* a_base[MS];  // this wave's group images [k/4][16][4]: 1 KiB per 16-k sub-chunk
 #pragma unroll
-    for (int i = 0; i < MS; ++i) a_src[i] = feat + (size_t)min((m0 >> 4) + i, ngroups - 1) * (kNFeat / 4) * 64 + lane * 4;
-    const float* b_src[B_PER];
+    for (int i = 0; i < MS; ++i) a_base[i] = feat + (size_t)min(mg0 + i, ngroups - 1) * (kNFeat / 4) * 64;
+    const float* b_base[B_PER];
+    unsigned b_dst[B_PER];
 #pragma unroll
-    for (int i = 0; i < B_PER; ++i)
-        b_src[i] = Wimg + (size_t)nb * NK * B_FLOATS + (size_t)min(wv + i * WM, B_INST - 1) * 256 + lane * 4;
+    for (int i = 0; i < B_PER; ++i) {
+        const unsigned piece = min(wvu + i * WM, (unsigned)(B_INST - 1));
+        b_base[i] = Wimg + (size_t)nb * NK * B_FLOATS + (size_t)piece * 256;
+        b_dst[i] = piece * 1024u;
+    }
     int bcol[NS];
 #pragma unroll
     for (int j = 0; j < NS; ++j) bcol[j] = (j * 16 + col) ^ (COLSWZ ? ((g & 1) << 4) : 0);
@@ -102,23 +114,22 @@ __global__ __launch_bounds__(64 * WM) void k_fc1_p3(const float* __restrict__ fe
     // (as it does for the builtin: a vmcnt(0) before the first ds_read) nor counts it -- the
     // counted waits below are the only ordering.  M0 = wave-uniform LDS byte address, written in
     // the same statement that uses it (guide 5.7).
-    const unsigned lds_base = (unsigned)(size_t)(lds_void*)smem;
-    const unsigned wvu = __builtin_amdgcn_readfirstlane(wv);
-#define P3_DMA(gsrc, lds_byte_off)                                                                     \
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void*)smem);
+    const unsigned a_dst0 = lds_base + 4u * (B_FLOATS + wvu * A_PER * 256);
+#define P3_DMA(sbase, lds_byte_addr)                                                                   \
     {                                                                                                  \
         unsigned keep_;                                                                                \
-        const unsigned dst_ = __builtin_amdgcn_readfirstlane(lds_base + (lds_byte_off));               \
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
-                     : "=&s"(keep_) : "v"(gsrc), "s"(dst_) : "memory");                                \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" \
+                     : "=&s"(keep_) : "v"(lane16), "s"(sbase), "s"(lds_byte_addr) : "memory");          \
     }
 #define P3_ISSUE(kc, st)                                                                               \
     {                                                                                                  \
         _Pragma("unroll") for (int i = 0; i < B_PER; ++i)                                              \
-            P3_DMA(b_src[i] + (size_t)(kc) * B_FLOATS, 4u * ((st) * STAGE + min(wvu + i * WM, (unsigned)(B_INST - 1)) * 256)); \
+            P3_DMA(b_base[i] + (size_t)(kc) * B_FLOATS, lds_base + 4u * (st) * STAGE + b_dst[i]);      \
         _Pragma("unroll") for (int u = 0; u < NSUB; ++u)                                               \
             _Pragma("unroll") for (int i = 0; i < MS; ++i)                                             \
-                P3_DMA(a_src[i] + ((size_t)(kc) * NSUB + u) * 256,                                     \
-                       4u * ((st) * STAGE + B_FLOATS + (wvu * A_PER + u * MS + i) * 256));             \
+                P3_DMA(a_base[i] + ((size_t)(kc) * NSUB + u) * 256,                                    \
+                       a_dst0 + 4u * ((st) * STAGE + (u * MS + i) * 256));                             \
     }
 #define P3_COMPUTE(st)                                                                                 \
     {                                                                                                  \

@@ -78,7 +78,7 @@ constexpr int kHeadsStages = 2;  // prefetch distance 1: 32 KB of LDS and 105 VG
 // of ethcnn_dense.hip at the heads' sizes; four blocks per CU cover the DMA latency for each other
 // (3 stages / 3 blocks per CU measured 7 % slower on 102,000 CTUs).
 template <int H>
-__device__ __forceinline__ void head_pass(float* smem, const float* __restrict__ h1row, const HeadsParams& hp, float qn,
+__device__ __forceinline__ void head_pass(float* smem, const float* __restrict__ H1, const HeadsParams& hp, float qn,
                                           int lane, unsigned wvu, bool valid, int ctu, float* __restrict__ h2row,
                                           float* __restrict__ logits, float* __restrict__ raw, float* __restrict__ probs,
                                           int* flag32, int* flag16, float thr1, float thr2) {
@@ -86,12 +86,15 @@ __device__ __forceinline__ void head_pass(float* smem, const float* __restrict__
     const int col = lane & 15, g = lane >> 4;
     const float* W2 = hp.w2[H];
     const float* W3 = hp.w3[H];
-    const unsigned lds_base = (unsigned)(size_t)(lds_void*)smem;
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void*)smem);
 
     // DMA sources.  W2 chunk: permuted LDS image (rows / column groups with odd (k>>2) swapped, as in
-    // ethcnn_dense.hip) applied to the per-lane source address.  h1 piece: lane (ctu, g) fetches
+    // ethcnn_dense.hip) applied to the per-lane source offset.  h1 piece: lane (ctu, g) fetches
     // its own float4 h1[ctu][O1 + 16 kc + 4 g ..], landing linearly at lane * 16 B.
-    const float* b_src[D::B_PER];
+    // every DMA source = wave-uniform base in SGPRs + a 32-bit per-lane byte offset in one VGPR (the saddr form of
+    // global_load_lds_dwordx4; scalar per-chunk advance -- see ethcnn_dense.hip).  h1 offsets stay < 2^32 bytes
+    // (<= 131072 CTUs per pass x 1792 B).
+    unsigned b_off[D::B_PER];
 #pragma unroll
     for (int i = 0; i < D::B_PER; ++i) {
         const int q = min((int)wvu + i * 4, D::B_INST - 1);
@@ -100,28 +103,28 @@ __device__ __forceinline__ void head_pass(float* smem, const float* __restrict__
         int c4 = e % (D::N2 / 4);
         if (D::COLSWZ) c4 ^= ((row >> 2) & 1) << 2;
         else row ^= (row >> 2) & 1;
-        b_src[i] = W2 + (size_t)row * D::N2 + c4 * 4;
+        b_off[i] = 4u * (unsigned)(row * D::N2 + c4 * 4);
     }
-    const float* a_src = h1row + D::O1 + 4 * g;
+    const unsigned a_off = 4u * (unsigned)(ctu * kNVec + D::O1 + 4 * g);
     int bcol[D::NT], brow[4];
 #pragma unroll
     for (int j = 0; j < D::NT; ++j) bcol[j] = (j * 16 + col) ^ (D::COLSWZ ? ((g & 1) << 4) : 0);
 #pragma unroll
     for (int e = 0; e < 4; ++e) brow[e] = (D::COLSWZ ? e : (e ^ (g & 1))) * D::N2;
 
-#define HP_DMA(gsrc, lds_byte_off)                                                                       \
+#define HP_DMA(voff, sbase, lds_byte_off)                                                                \
     {                                                                                                    \
         unsigned keep_;                                                                                  \
         const unsigned dst_ = __builtin_amdgcn_readfirstlane(lds_base + (lds_byte_off));                 \
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
-                     : "=&s"(keep_) : "v"(gsrc), "s"(dst_) : "memory");                                  \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" \
+                     : "=&s"(keep_) : "v"(voff), "s"(sbase), "s"(dst_) : "memory");                      \
     }
 #define HP_ISSUE(kc, st)                                                                                 \
     {                                                                                                    \
         _Pragma("unroll") for (int i = 0; i < D::B_PER; ++i)                                             \
-            HP_DMA(b_src[i] + (size_t)(kc) * 16 * D::N2,                                                 \
+            HP_DMA(b_off[i], W2 + (size_t)(kc) * 16 * D::N2,                                             \
                    4u * ((st) * kHeadsStage + min(wvu + i * 4, (unsigned)(D::B_INST - 1)) * 256));       \
-        HP_DMA(a_src + (kc) * 16, 4u * ((st) * kHeadsStage + 16 * 192 + wvu * 256));                     \
+        HP_DMA(a_off, H1 + (kc) * 16, 4u * ((st) * kHeadsStage + 16 * 192 + wvu * 256));                 \
     }
 #define HP_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
@@ -215,18 +218,17 @@ __global__ __launch_bounds__(256) void k_heads(const float* __restrict__ H1, Hea
     const int ctu_raw = (blockIdx.x * 4 + (int)wvu) * 16 + col;
     const bool valid = ctu_raw < N;
     const int ctu = min(ctu_raw, N - 1);  // clamped rows are loaded, never stored
-    const float* h1row = H1 + (size_t)ctu * kNVec;
     float* h2row = H2 ? H2 + (size_t)ctu * kNFc2 : nullptr;
     int* fl = flags + 2 * (gchunk(ctu0 + ctu, nctu, cpf) - gchunk(ctu0, nctu, cpf));
     // blockIdx.y selects the head: the three heads of a 64-CTU tile are independent (each reads its own
     // column slice of h1), so they run as separate blocks -- head 16 (16 K chunks) is dispatched first,
     // the short heads 32 / 64 fill in behind it.  A third of the per-block latency, three times the blocks.
     if (blockIdx.y == 0)
-        head_pass<2>(smem, h1row, hp, qn, lane, wvu, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
+        head_pass<2>(smem, H1, hp, qn, lane, wvu, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
     else if (blockIdx.y == 1)
-        head_pass<1>(smem, h1row, hp, qn, lane, wvu, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
+        head_pass<1>(smem, H1, hp, qn, lane, wvu, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
     else
-        head_pass<0>(smem, h1row, hp, qn, lane, wvu, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
+        head_pass<0>(smem, H1, hp, qn, lane, wvu, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
 }
 
 void launch_heads(const Workspace& ws, const DeviceWeights& w, int n, float qn, int nctu, long ctu0, float thr1,

@@ -61,6 +61,10 @@ SIGNATURES = {
     "ethcnn_set_thresholds": (_i, [_vp, ctypes.c_float, ctypes.c_float]),
     "ethcnn_get_thresholds": (_i, [_vp, _fp, _fp]),
     "ethcnn_predict_luma_device": (_i, [_vp, _vp, _i, _i, _pd, _pd, _i, _i, _vp]),
+    "ethcnn_ldp_step": (_i, [_vp, _vp, _i, _i, _pd, _i, _i, _vp, _fp]),
+    "ethcnn_ldp_get_state": (_i, [_vp, _fp, _sz]),
+    "ethcnn_host_alloc": (_i, [_vp, _sz, ctypes.POINTER(_vp)]),
+    "ethcnn_host_free": (_i, [_vp, _vp]),
     "ethcnn_predict_luma": (_i, [_vp, _vp, _i, _i, _pd, _pd, _i, _i, _fp]),
     "ethcnn_predict_yuv_file": (_i, [_vp, _cp, _i, _i, _i, _cp, ctypes.POINTER(ctypes.c_int64)]),
     "ethcnn_predict_yuv_shard": (_i, [_vp, _cp, _i, _i, _i, _cp, ctypes.c_int64, ctypes.c_int64]),
@@ -222,6 +226,7 @@ class EthCnn(object):
 
     def close(self):
         if getattr(self, "h", None):
+            self.free_host_buffers()
             self.lib.ethcnn_destroy(self.h)
             self.h = None
 
@@ -382,6 +387,44 @@ class EthCnn(object):
                                                     sin.ctypes.data if sin is not None else None,
                                                     state.ctypes.data_as(_fp), probs.ctypes.data_as(_fp)))
         return probs, state
+
+    def ldp_step(self, luma, width, height, qp, i_frame, state_in=None, pitch=None, probs_out=None):
+        """one frame with the recurrent state resident in HBM between calls (ethcnn_ldp_step): state_in None = the
+        previous call's state (zeros when i_frame <= 1) -> probs [nctu, 21]"""
+        luma = np.ascontiguousarray(luma, dtype=np.uint8)
+        pitch = width if pitch is None else pitch
+        need = (height - 1) * pitch + width if width > 0 and height > 0 else 0
+        if luma.size < need:
+            raise ValueError("luma buffer too small: %d < %d" % (luma.size, need))
+        n = ctus_per_frame(width, height)
+        probs = np.empty((n, NOUT), dtype=np.float32) if probs_out is None else probs_out
+        assert probs.dtype == np.float32 and probs.size == n * NOUT and probs.flags["C_CONTIGUOUS"]
+        sin = None
+        if state_in is not None:
+            sin = np.ascontiguousarray(state_in, dtype=np.float32).reshape(n, 2, NVEC)
+        self._chk(self.lib.ethcnn_ldp_step(self.h, luma.ctypes.data, width, height, pitch, int(qp), int(i_frame),
+                                           sin.ctypes.data if sin is not None else None, probs.ctypes.data_as(_fp)))
+        return probs.reshape(n, NOUT)
+
+    def ldp_get_state(self, width, height):
+        n = ctus_per_frame(width, height)
+        state = np.empty((n, 2, NVEC), dtype=np.float32)
+        self._chk(self.lib.ethcnn_ldp_get_state(self.h, state.ctypes.data_as(_fp), state.size))
+        return state
+
+    def host_buffer(self, nbytes):
+        """pinned host memory as a uint8 numpy array (freed with the context, or by free_host_buffer)"""
+        p = _vp()
+        self._chk(self.lib.ethcnn_host_alloc(self.h, int(nbytes), ctypes.byref(p)))
+        arr = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), shape=(max(1, int(nbytes)),))
+        self._pinned = getattr(self, "_pinned", [])
+        self._pinned.append(p.value)
+        return arr[:nbytes]
+
+    def free_host_buffers(self):
+        for ptr in getattr(self, "_pinned", []):
+            self.lib.ethcnn_host_free(self.h, ptr)
+        self._pinned = []
 
     # -- measurement / introspection
     def set_profiling(self, level=2):

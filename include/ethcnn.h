@@ -130,6 +130,22 @@ int ethcnn_lstm_step_device(ethcnn_ctx* ctx, const float* d_vec, const float* d_
 int ethcnn_ldp_predict_frame(ethcnn_ctx* ctx, const uint8_t* luma, int width, int height, ptrdiff_t pitch,
                              int qp, int i_frame, const float* state_in /* may be NULL */, float* state_out,
                              float* probs); /* host pointers; synchronous */
+/* The same per-frame call with the recurrent (c, h) state RESIDENT in HBM between frames (the daemon's fast path:
+ * state.dat is part of the reference's file protocol, but only the daemon itself ever reads it back --
+ * resi_to_cu_depth_LDP.py:103-106 -- so the 2 x nctu x 3.5 KB PCIe round trip per frame is not needed):
+ *   state_in != NULL          use (and upload) this state, as ethcnn_ldp_predict_frame does;
+ *   state_in == NULL, i_frame <= 1   zeros (:109-110);
+ *   state_in == NULL, i_frame > 1    the state the previous ethcnn_ldp_step left in HBM (error if there is none or the
+ *                                     CTU count changed).
+ * probs returns synchronously; ethcnn_ldp_get_state copies the new state out afterwards (off the encoder's critical
+ * path: the daemon signals pred_end.sig first, then refreshes state.dat). */
+int ethcnn_ldp_step(ethcnn_ctx* ctx, const uint8_t* luma, int width, int height, ptrdiff_t pitch, int qp, int i_frame,
+                    const float* state_in /* may be NULL */, float* probs);
+int ethcnn_ldp_get_state(ethcnn_ctx* ctx, float* state_out, size_t nfloats /* nctu * 896 */);
+/* Pinned (page-locked) host memory: buffers a caller fills itself (file reads) and hands to the host entry points are
+ * DMA-able directly, without the runtime's pageable staging copy. */
+int ethcnn_host_alloc(ethcnn_ctx* ctx, size_t bytes, void** out);
+int ethcnn_host_free(ethcnn_ctx* ctx, void* p);
 
 /* ---- device plumbing for callers without a HIP binding (ctypes, cgo, JNI ...) */
 int ethcnn_device_alloc(ethcnn_ctx* ctx, size_t bytes, void** out);

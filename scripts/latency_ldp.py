@@ -25,6 +25,21 @@ for name, w, h in (("416x240", 416, 240), ("832x480", 832, 480), ("1280x720", 12
     for i in range(reps):
         _, state = ctx.ldp_predict_frame(luma, w, h, 32, 6 + i, state)
     t_host = (time.perf_counter() - t0) / reps
+    # the daemon's fast path: state resident in HBM (ethcnn_ldp_step), luma and probabilities in pinned host memory
+    pin = ctx.host_buffer(w * h)
+    pin[:] = luma.reshape(-1)
+    pprobs = ctx.host_buffer(n * 84).view(np.float32).reshape(n, 21)
+    for i in range(1, 6):
+        ctx.ldp_step(pin.reshape(h, w), w, h, 32, i, probs_out=pprobs)
+    t0 = time.perf_counter()
+    for i in range(reps):
+        ctx.ldp_step(pin.reshape(h, w), w, h, 32, 6 + i, probs_out=pprobs)
+    t_res = (time.perf_counter() - t0) / reps
+    t0 = time.perf_counter()
+    for i in range(reps):
+        ctx.ldp_step(luma, w, h, 32, 6 + reps + i)
+    t_res_pageable = (time.perf_counter() - t0) / reps
+    ctx.free_host_buffers()
     # device-resident pieces
     d_in, d_vec = ctx.alloc(luma.nbytes), ctx.alloc(n * 448 * 4)
     d_s0, d_s1, d_p = ctx.alloc(n * 896 * 4), ctx.alloc(n * 896 * 4), ctx.alloc(n * 84)
@@ -41,7 +56,8 @@ for name, w, h in (("416x240", 416, 240), ("832x480", 832, 480), ("1280x720", 12
     for _ in range(20): dev()
     st = ctx.stage_times(); ctx.set_profiling(0)
     ms = {k: v / 20 * 1e3 for k, v in st["ms"].items()}
-    line = "%-10s %5d CTUs  host-call %8.1f us  device-resident %8.1f us" % (name, n, t_host * 1e6, t_dev * 1e6)
+    line = "%-10s %5d CTUs  host-call %8.1f us  resident-state call %8.1f us (pinned) %8.1f us (pageable)  device-resident %8.1f us" % (
+        name, n, t_host * 1e6, t_res * 1e6, t_res_pageable * 1e6, t_dev * 1e6)
     if ms: line += "  kernels(us): " + " ".join("%s=%.1f" % (k, v) for k, v in ms.items())
     if cpu:
         t0 = time.perf_counter(); r = 3

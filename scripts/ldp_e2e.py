@@ -85,9 +85,10 @@ def gpu_daemon(workdir, max_frames, log):
 
     def logging_save(depth_out, state_out, save_file, state_file, end_file, num_vectors):
         frame = len(log) + 1
-        log.append((frame, zlib.crc32(np.ascontiguousarray(depth_out, np.float32).tobytes()),
-                    zlib.crc32(np.ascontiguousarray(state_out, np.float32).tobytes())))
-        return orig(depth_out, state_out, save_file, state_file, end_file, num_vectors)
+        crc_p = zlib.crc32(np.ascontiguousarray(depth_out, np.float32).tobytes())  # before the signal: the buffer is reused
+        state = orig(depth_out, state_out, save_file, state_file, end_file, num_vectors)  # fetches the resident state after the signal
+        log.append((frame, crc_p, zlib.crc32(np.ascontiguousarray(state, np.float32).tobytes())))
+        return state
     d.save_cu_depth_and_state = logging_save
     d.serve(workdir, max_frames=max_frames, idle_timeout=600.0, verbose=False)
 

@@ -109,9 +109,11 @@ def test_lstm_errors(pkg, oracle):
 
 def test_ldp_daemon_handshake(pkg, oracle, lstm, tmp_path, monkeypatch):
     """The file handshake of TEncGOP.cpp:1463-1503 played from the test as "HM": resi.yuv +
-    command.dat + pred_start.sig -> wait pred_end.sig -> cu_depth.dat; 3 frames with the
+    command.dat + pred_start.sig -> wait pred_end.sig -> cu_depth.dat; 4 frames with the
     reference's trained LSTM weights (QP 32 band) and seeded CNN weights; every frame
-    bit-exact against the oracle chain; state.dat carries the recurrence."""
+    bit-exact against the oracle chain.  The recurrent state stays resident in HBM between frames
+    (state.dat is refreshed after pred_end.sig, for protocol compatibility); before frame 4 the test
+    REPLACES state.dat, which the daemon must notice and use, as the reference would."""
     import shutil
     import threading
     import time
@@ -122,7 +124,7 @@ def test_ldp_daemon_handshake(pkg, oracle, lstm, tmp_path, monkeypatch):
     (tmp_path / "Thr_info.txt").write_text("0.4 0.6 0.3 0.7 0.2 0.8")
     monkeypatch.setenv("ETHCNN_SYNTHETIC_SEED", "21")
     result = {}
-    th = threading.Thread(target=lambda: result.setdefault("n", d.serve(str(tmp_path), max_frames=3, idle_timeout=60.0,
+    th = threading.Thread(target=lambda: result.setdefault("n", d.serve(str(tmp_path), max_frames=4, idle_timeout=60.0,
                                                                        verbose=False)))
     th.start()
     cblob = oracle.synth_blob(21, 1.0)
@@ -131,7 +133,11 @@ def test_ldp_daemon_handshake(pkg, oracle, lstm, tmp_path, monkeypatch):
     n = ((w + 63) // 64) * ((h + 63) // 64)
     o_state = None
     try:
-        for poc in (1, 2, 3):
+        for poc in (1, 2, 3, 4):
+            if poc == 4:  # somebody else's state.dat: the resident state must not be used
+                o_state = (o_state * np.float32(0.5)).astype(np.float32)
+                time.sleep(0.01)
+                o_state.tofile(tmp_path / "state.dat")
             luma = rng.integers(96, 160, size=(h, w), dtype=np.uint8)  # residual + 128, roughly
             with open(tmp_path / "resi.yuv", "wb") as f:
                 f.write(luma.tobytes())
@@ -148,8 +154,56 @@ def test_ldp_daemon_handshake(pkg, oracle, lstm, tmp_path, monkeypatch):
             vec = oracle.resi_vectors(cblob, luma, w, h)
             want, o_state = lstm.lstm_step(lblob, vec, o_state, qp, poc, 0.6, 0.7, mode=0)
             assert np.array_equal(_bits(got), _bits(want)), poc
-            st = np.fromfile(tmp_path / "state.dat", dtype=np.float32).reshape(n, 2, 448)
-            assert np.array_equal(_bits(st), _bits(o_state)), poc
+            t0 = time.time()  # state.dat follows the ending signal (renamed into place, so never partial)
+            while True:
+                try:
+                    st = np.fromfile(tmp_path / "state.dat", dtype=np.float32)
+                except OSError:
+                    st = np.zeros(0, np.float32)
+                if st.size == n * 896 and np.array_equal(_bits(st.reshape(n, 2, 448)), _bits(o_state)):
+                    break
+                assert time.time() - t0 < 10, "state.dat was not refreshed with frame %d's state" % poc
+                time.sleep(0.001)
     finally:
         th.join(timeout=90)
-    assert result.get("n") == 3
+    assert result.get("n") == 4
+
+
+def test_ldp_step_keeps_the_state_resident(pkg, oracle, lstm):
+    """ethcnn_ldp_step: state_in None = the previous call's state in HBM.  The chain equals the host-state chain
+    (ethcnn_ldp_predict_frame) bit for bit; a host state overrides the resident one; a frame > 1 without a resident
+    state, or after a geometry change, is an error (never silent zeros)."""
+    e = pkg.ethcnn
+    rng = np.random.default_rng(77)
+    w, h = 832, 480
+    cblob, lblob = oracle.synth_blob(21, 1.0), lstm.synth_lstm_blob(22, 3.0)
+    a, b = pkg.EthCnn(device=0), pkg.EthCnn(device=0)
+    try:
+        for c in (a, b):
+            c.load_blob(cblob)
+            c.load_lstm_blob(lblob)
+            c.set_thresholds(0.5, 0.5)
+        with pytest.raises(e.EthCnnError):
+            a.ldp_step(np.zeros((h, w), np.uint8), w, h, 32, 2)  # nothing resident yet
+        host_state = None
+        for i_frame in (1, 2, 3, 4, 5):
+            luma = rng.integers(0, 256, size=(h, w), dtype=np.uint8)
+            pa = a.ldp_step(luma, w, h, 32, i_frame)
+            pb, host_state = b.ldp_predict_frame(luma, w, h, 32, i_frame, host_state)
+            assert np.array_equal(_bits(pa), _bits(pb)), i_frame
+            assert np.array_equal(_bits(a.ldp_get_state(w, h)), _bits(host_state)), i_frame
+        # host state given: it wins over the resident one
+        other = (host_state * np.float32(0.25)).astype(np.float32)
+        luma = rng.integers(0, 256, size=(h, w), dtype=np.uint8)
+        pa = a.ldp_step(luma, w, h, 32, 6, other)
+        pb, _ = b.ldp_predict_frame(luma, w, h, 32, 6, other)
+        assert np.array_equal(_bits(pa), _bits(pb))
+        with pytest.raises(e.EthCnnError):  # geometry changed: the resident state belongs to another frame size
+            a.ldp_step(np.zeros((240, 416), np.uint8), 416, 240, 32, 7)
+        # i_frame <= 1 restarts from zeros
+        pa = a.ldp_step(luma, w, h, 32, 1)
+        pb, _ = b.ldp_predict_frame(luma, w, h, 32, 1, None)
+        assert np.array_equal(_bits(pa), _bits(pb))
+    finally:
+        a.close()
+        b.close()
