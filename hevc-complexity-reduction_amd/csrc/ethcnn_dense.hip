@@ -173,17 +173,21 @@ __global__ __launch_bounds__(64 * WM) void k_fc1_p3(const float* __restrict__ fe
 #undef P3_WAIT
 #undef P3_STEP
 
+    // epilogue: bias + leaky-ReLU, one buffer_store per value: SGPR resource + uniform column offset (soffset) + one
+    // VGPR offset holding the ROW part.  The hardware range check covers voffset only (the SGPR offset is not part of
+    // it), and the resource ends at row M: rows of a ragged last tile are dropped by the check, no exec masking.
+    const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc(out, 0, M * kNVec * 4, 0x00020000);
+    const int lane_out = ((m0 + 4 * g) * kNVec + col) * 4;
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
-        const int n = n0 + j * 16 + col;
-        const float bv = bias[n];
+        const float bv = bias[n0 + j * 16 + col];
 #pragma unroll
         for (int i = 0; i < MS; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = m0 + i * 16 + 4 * g + r;
                 const float h = acc[i][j][r] + bv;
-                if (m < M) out[(size_t)m * kNVec + n] = fmaxf(0.2f * h, h);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(0.2f * h, h)), rO,
+                                                      lane_out + (i * 16 + r) * kNVec * 4, (n0 + j * 16) * 4, 0);
             }
     }
 }

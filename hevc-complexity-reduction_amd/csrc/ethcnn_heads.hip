@@ -18,6 +18,7 @@
 namespace ethcnn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
@@ -158,12 +159,16 @@ __device__ __forceinline__ void head_pass(float* smem, const float* __restrict__
 #undef HP_ISSUE
 #undef HP_WAIT
 
-    // FC2 epilogue in place: lane (ctu = col, g) holds h2[ctu][16 j + 4 g + r]
+    // FC2 epilogue in place: lane (ctu = col, g) holds h2[ctu][16 j + 4 g + r].  Small operand fetches below go through
+    // buffer instructions (SGPR resource + one VGPR offset): cheaper to issue beside MFMAs than 64-bit VGPR addresses
+    const __amdgpu_buffer_rsrc_t rW2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W2), 0, (D::N1 + 1) * D::N2 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hp.b2[H]), 0, D::N2 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rW3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W3), 0, (D::N2 + 1) * D::N3 * 4, 0x00020000);
 #pragma unroll
     for (int j = 0; j < D::NT; ++j) {
         const int n = 16 * j + 4 * g;
-        const float4 wq = *reinterpret_cast<const float4*>(W2 + (size_t)D::N1 * D::N2 + n);
-        const float4 bv = *reinterpret_cast<const float4*>(hp.b2[H] + n);
+        const f32x4 wq = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW2, 16 * g, (D::N1 * D::N2 + 16 * j) * 4, 0));
+        const f32x4 bv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rB2, 16 * g, 64 * j, 0));
         acc[j][0] = lrelu_h(fmaf(qn, wq.x, acc[j][0]) + bv.x);
         acc[j][1] = lrelu_h(fmaf(qn, wq.y, acc[j][1]) + bv.y);
         acc[j][2] = lrelu_h(fmaf(qn, wq.z, acc[j][2]) + bv.z);
@@ -172,15 +177,18 @@ __device__ __forceinline__ void head_pass(float* smem, const float* __restrict__
     }
     // FC3^T: rows = outputs (N3 of 16 used), columns = CTUs; step (j, r) consumes k = 16 j + 4 g + r
     f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
-    {   // W3 operands fetched one tile ahead of their use (8 VGPRs instead of 4 NT)
+    {   // W3 operands fetched one tile ahead of their use (8 VGPRs instead of 4 NT); columns >= N3 read as 0
         float wc[4], wn[4];
+        const int w3off = (4 * g * D::N3 + col) * 4;  // lane part of W3[(16 j + 4 g + r) * N3 + col]
 #pragma unroll
-        for (int r = 0; r < 4; ++r) wc[r] = (col < D::N3) ? W3[(4 * g + r) * D::N3 + col] : 0.0f;
+        for (int r = 0; r < 4; ++r)
+            wc[r] = (col < D::N3) ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rW3, w3off, r * D::N3 * 4, 0)) : 0.0f;
 #pragma unroll
         for (int j = 0; j < D::NT; ++j) {
             if (j + 1 < D::NT) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) wn[r] = (col < D::N3) ? W3[(16 * (j + 1) + 4 * g + r) * D::N3 + col] : 0.0f;
+                for (int r = 0; r < 4; ++r)
+                    wn[r] = (col < D::N3) ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rW3, w3off, (16 * (j + 1) + r) * D::N3 * 4, 0)) : 0.0f;
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) z = MFMA16(wc[r], acc[j][r], z);

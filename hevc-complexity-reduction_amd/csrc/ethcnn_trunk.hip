@@ -28,6 +28,13 @@
 namespace ethcnn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#ifndef TRUNK_BUF_LOADS
+#define TRUNK_BUF_LOADS 1
+#endif
+#ifndef TRUNK_BUF_STORES
+#define TRUNK_BUF_STORES 1
+#endif
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 // max(0.2h, h) as v_mul + ONE v_max per value: fmaxf() makes hipcc canonicalise the raw MFMA
@@ -135,9 +142,20 @@ struct Trunk {
                 }
         }
 
+        // buffer addressing: SGPR resource + SGPR task / slot offset + ONE VGPR lane offset per instruction.
+        // The 128-bit STORES keep their whole offset in the VGPR (one v_add each) and soffset = 0: with an SGPR soffset
+        // hipcc (ROCm 7.2) places the next VALU write of the store-data registers directly behind the store -- its
+        // hazard recognizer assumes a register soffset removes the ">64-bit store data" hazard -- and on gfx950 lanes
+        // 12..15 of every row then stored the overwritten value (profiles/r02_fc1_variants.txt, "buffer_store hazard").
+        const int lane16 = lane * 16;
+        const int lane_off = (col * 4 + g * 64) * 4;  // feature stores: [k/4][16 CTUs][4] -> g, col
+        const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(X), 0, -1, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rF = __builtin_amdgcn_make_buffer_rsrc(F, 0, -1, 0x00020000);
         uint4 raw[NJ];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) raw[j] = X[((size_t)wave * NJ + j) * 64 + lane];
+        for (int j = 0; j < NJ; ++j)
+            raw[j] = TRUNK_BUF_LOADS ? __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rX, lane16, (wave * NJ + j) * 1024, 0))
+                                     : X[((size_t)wave * NJ + j) * 64 + lane];
 
         for (int task = wave; task < ntasks; task += nwaves) {
             int T = raw_sum(raw);
@@ -153,8 +171,8 @@ struct Trunk {
             else if (BR == 1) { grp = task >> 2; by = (task >> 1) & 1; bx = task & 1; }
             else { grp = task; by = 0; bx = 0; }
             const bool valid = grp * 16 + col < N;
-            // feature k of this lane's CTU: Fg[(k/4) * 64 + (k%4)]  (k % 4 == 0 for every f32x4 below)
-            float* Fg = F + (size_t)grp * kNFeat * 16 + col * 4;
+            // feature k of this lane's CTU: group image [(k/4)][16 CTUs][4]; k = k0 + 4 g with a uniform k0 % 4 == 0
+            const int Fg = grp * (kNFeat * 16 * 4);  // uniform byte offset of the group image (< 2^31: <= 8192 groups)
 
             // conv1 of position q2: 4 patches (q1) x 4 k-steps (s = kx); lane supplies v[patch][ky=g][kx=s]
 #define CONV1(q2, c1)                                                                                  \
@@ -185,9 +203,15 @@ struct Trunk {
         a2[q2][1] = lrelu4(c2[1]);                                                                     \
         if (valid) {                                                                                   \
             const int slot = (2 * by + ((q2) >> 1)) * (2 * NB) + 2 * bx + ((q2) & 1);                  \
-            const int k0 = OFF2 + slot * 24 + 4 * g;                                                   \
-            *reinterpret_cast<f32x4*>(Fg + (k0 >> 2) * 64) = a2[q2][0];                                \
-            if (g < 2) *reinterpret_cast<f32x4*>(Fg + ((k0 + 16) >> 2) * 64) = a2[q2][1];              \
+            const int dst = Fg + ((OFF2 + slot * 24) >> 2) * 256;                                      \
+            if (TRUNK_BUF_STORES) {                                                                    \
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a2[q2][0]), rF, lane_off + dst, 0, 0);  \
+                if (g < 2) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a2[q2][1]), rF, lane_off + dst + 1024, 0, 0); \
+            } else {                                                                                   \
+                char* p_ = reinterpret_cast<char*>(F) + (size_t)dst + lane_off;                        \
+                *reinterpret_cast<f32x4*>(p_) = a2[q2][0];                                             \
+                if (g < 2) *reinterpret_cast<f32x4*>(p_ + 1024) = a2[q2][1];                           \
+            }                                                                                          \
         }                                                                                              \
     }
             f32x4 a2[4][2];
@@ -206,7 +230,9 @@ struct Trunk {
             // other waves' work) at no VGPR cost
             if (task + nwaves < ntasks) {
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) raw[j] = X[((size_t)(task + nwaves) * NJ + j) * 64 + lane];
+                for (int j = 0; j < NJ; ++j)
+                    raw[j] = TRUNK_BUF_LOADS ? __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rX, lane16, ((task + nwaves) * NJ + j) * 1024, 0))
+                                             : X[((size_t)(task + nwaves) * NJ + j) * 64 + lane];
             }
 #undef CONV1
 #undef CONV2
@@ -231,9 +257,15 @@ struct Trunk {
                     c3[1] = MFMA16(wA3[(24 + 16 + 4 * j + r) * 64], z, c3[1]);
                 }
             if (valid) {
-                const int k0 = OFF3 + (by * NB + bx) * 32 + 4 * g;
-                *reinterpret_cast<f32x4*>(Fg + (k0 >> 2) * 64) = lrelu4(c3[0]);
-                *reinterpret_cast<f32x4*>(Fg + ((k0 + 16) >> 2) * 64) = lrelu4(c3[1]);
+                const int dst = Fg + ((OFF3 + (by * NB + bx) * 32) >> 2) * 256;
+                if (TRUNK_BUF_STORES) {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, lrelu4(c3[0])), rF, lane_off + dst, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, lrelu4(c3[1])), rF, lane_off + dst + 1024, 0, 0);
+                } else {
+                    char* p_ = reinterpret_cast<char*>(F) + (size_t)dst + lane_off;
+                    *reinterpret_cast<f32x4*>(p_) = lrelu4(c3[0]);
+                    *reinterpret_cast<f32x4*>(p_ + 1024) = lrelu4(c3[1]);
+                }
             }
         }
     }
@@ -245,7 +277,10 @@ __global__ __launch_bounds__(256) void k1_trunk(const uint4* __restrict__ XS, co
                                                 const float* __restrict__ wfrag, const float* __restrict__ bfrag,
                                                 float* __restrict__ F) {
     __shared__ float wl[kTrunkWFrags * 64];  // this block's branch: 84 A-operand fragments, 21 KB
-    const int w = threadIdx.x >> 6;
+    // wave-uniform on purpose (readfirstlane): task, group and unit indices then live in SGPRs, and every load / store
+    // below is "SGPR base + one 32-bit VGPR lane offset" (saddr form) instead of a 64-bit per-lane address: a VMEM
+    // instruction with VGPR addresses costs several times more matrix-pipe time (profiles/r02_fc1_variants.txt)
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.x;
     const int groups = (N + 15) / 16;
     if (b < bS) Trunk<0, RESI>::run(XS, groups * 16, b * 4 + w, bS * 4, wfrag, bfrag, F, N, wl);
