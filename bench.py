@@ -370,7 +370,8 @@ def host_scopes(ctx, luma, W, H, NF, QP, yuv):
         best = min(best, time.perf_counter() - t0)
     out["s3_file_to_file_ctus_per_s"] = NF * nctu / best
     out["s3_luma_gbps"] = NF * W * H / best / 1e9
-    out["note"] = "best of 3; PCIe Gen5 x16 ceiling ~ 12 M CTU/s at 4096 B/CTU"
+    out["note"] = ("best of 3; measured H2D rate of this box's DMA engine from pinned memory: 57.5 GB/s = 14.0 M CTU/s at 4096 B/CTU "
+                   "(profiles/r02_host_copy.txt)")
     return out
 
 

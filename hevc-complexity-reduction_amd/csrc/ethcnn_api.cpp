@@ -97,6 +97,12 @@ private:
     bool stop_ = false;
 };
 
+// A 2-deep ring made the H2D of group i and the kernels of group i one serial stage of the pipeline (the host could not
+// start filling group i+1 before group i-1 had completely finished): 32-35 GB/s of luma where the DMA engine alone does
+// 57 (scripts/ubench/host_copy.cpp, profiles/r02_host_copy.txt).  Four buffers let fill, H2D and kernels of three
+// different groups run at the same time.
+constexpr int kStageBufs = 4;
+
 struct ethcnn_ctx {
     int device = 0;
     hipStream_t stream = nullptr;   // compute
@@ -135,11 +141,12 @@ struct ethcnn_ctx {
     std::vector<hipEvent_t> ev_pool;
     ethcnn_stage_times times{};
 
-    // staging for the host / file entry points (double buffered)
-    uint8_t* h_in[2] = {nullptr, nullptr};
-    float* h_out[2] = {nullptr, nullptr};
-    uint8_t* d_in[2] = {nullptr, nullptr};
-    float* d_out[2] = {nullptr, nullptr};
+    // staging ring for the host / file entry points: kStageBufs groups in flight (fill | H2D | kernels + D2H | drain)
+    uint8_t* h_in[kStageBufs] = {};
+    float* h_out[kStageBufs] = {};
+    uint8_t* d_in[kStageBufs] = {};
+    float* d_out[kStageBufs] = {};
+    hipEvent_t ev_in[kStageBufs] = {}, ev_comp[kStageBufs] = {}, ev_out[kStageBufs] = {};  // created with the ring, destroyed with it
     size_t in_cap = 0, out_cap = 0;
     HostPool* pool = nullptr;  // created on first use by the host / file entry points
 };
@@ -234,12 +241,17 @@ extern "C" int ethcnn_create(ethcnn_ctx** out, const ethcnn_options* opt) {
 }
 
 static void free_staging(ethcnn_ctx* c) {
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < kStageBufs; ++i) {
         if (c->h_in[i]) (void)hipHostFree(c->h_in[i]);
         if (c->h_out[i]) (void)hipHostFree(c->h_out[i]);
         if (c->d_in[i]) (void)hipFree(c->d_in[i]);
         if (c->d_out[i]) (void)hipFree(c->d_out[i]);
         c->h_in[i] = nullptr; c->h_out[i] = nullptr; c->d_in[i] = nullptr; c->d_out[i] = nullptr;
+        hipEvent_t* evs[3] = {&c->ev_in[i], &c->ev_comp[i], &c->ev_out[i]};
+        for (hipEvent_t* e : evs) {
+            if (*e) (void)hipEventDestroy(*e);
+            *e = nullptr;
+        }
     }
     c->in_cap = c->out_cap = 0;
 }
@@ -528,16 +540,25 @@ extern "C" int ethcnn_predict_luma_device(ethcnn_ctx* c, const uint8_t* d_luma, 
     return ETHCNN_OK;
 }
 
-static int ensure_staging(ethcnn_ctx* c, size_t in_bytes, size_t out_bytes) {
-    if (in_bytes > c->in_cap || out_bytes > c->out_cap) {
+// `nbufs` of the ring are needed by the caller (the single-frame LDP / resi entry points use one)
+static int ensure_staging(ethcnn_ctx* c, size_t in_bytes, size_t out_bytes, int nbufs = 1) {
+    bool have = in_bytes <= c->in_cap && out_bytes <= c->out_cap;
+    for (int i = 0; i < nbufs && have; ++i) have = c->h_in[i] != nullptr;
+    if (!have) {
         HIPCHK(c, hipDeviceSynchronize());
         const size_t ic = std::max(in_bytes, c->in_cap), oc = std::max(out_bytes, c->out_cap);
-        free_staging(c);
-        for (int i = 0; i < 2; ++i) {
+        int keep = nbufs;
+        for (int i = 0; i < kStageBufs; ++i)
+            if (c->h_in[i]) keep = std::max(keep, i + 1);
+        free_staging(c);  // on any failure below the partial ring is released by ethcnn_destroy / the next call
+        for (int i = 0; i < keep; ++i) {
             HIPCHK(c, hipHostMalloc((void**)&c->h_in[i], ic, hipHostMallocDefault));
             HIPCHK(c, hipHostMalloc((void**)&c->h_out[i], oc, hipHostMallocDefault));
             HIPCHK(c, hipMalloc((void**)&c->d_in[i], ic));
             HIPCHK(c, hipMalloc((void**)&c->d_out[i], oc));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_in[i], hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_comp[i], hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_out[i], hipEventDisableTiming));
         }
         c->in_cap = ic;
         c->out_cap = oc;
@@ -580,73 +601,57 @@ static int host_pipeline(ethcnn_ctx* c, int w, int h, int nframes, int qp, Fill 
     if (!c->have_weights) return set_err(c, ETHCNN_ERR_NOWEIGHTS, "no weights loaded");
     if (nframes == 0) return ETHCNN_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    // frames per group: whole frames up to max_ctus (a frame larger than the workspace is
-    // still one group; run_pass splits it)
-    // group size: ~8 groups per call so copies, kernels and the drain overlap, but no group smaller
-    // than ~4096 CTUs (kernel efficiency) or larger than the workspace
+    // Group size: whole frames, >= ~4096 CTUs (kernel efficiency), ~16 groups per call so that the pipeline's ramp (first
+    // fill, last kernels + D2H + drain) is a small part of it, never larger than the workspace.  A frame larger than the
+    // workspace is still one group; run_pass splits it.
     const int fpg = std::max(1, std::min(std::min(nframes, c->max_ctus / g.nctu),
-                                         std::max((4096 + g.nctu - 1) / g.nctu, (nframes + 7) / 8)));
+                                         std::max((4096 + g.nctu - 1) / g.nctu, (nframes + 15) / 16)));
     const size_t plane = (size_t)w * h;
-    rc = ensure_staging(c, plane * fpg, (size_t)fpg * g.nctu * kNOut * 4);
+    rc = ensure_staging(c, plane * fpg, (size_t)fpg * g.nctu * kNOut * 4, kStageBufs);
     if (rc) return rc;
-    hipEvent_t in_done[2], comp_done[2], out_done[2];
-    for (int i = 0; i < 2; ++i) {
-        HIPCHK(c, hipEventCreateWithFlags(&in_done[i], hipEventDisableTiming));
-        HIPCHK(c, hipEventCreateWithFlags(&comp_done[i], hipEventDisableTiming));
-        HIPCHK(c, hipEventCreateWithFlags(&out_done[i], hipEventDisableTiming));
-    }
     struct Group { int f0, nf; };
     std::vector<Group> groups;
     for (int f = 0; f < nframes; f += fpg) groups.push_back({f, std::min(fpg, nframes - f)});
-    int result = ETHCNN_OK;
+    const size_t ng = groups.size();
+    auto retire = [&](size_t gi) -> int {  // group gi's probabilities are in pinned memory: hand them to the caller
+        const int b = (int)(gi % kStageBufs);
+        HIPCHK(c, hipEventSynchronize(c->ev_out[b]));
+        return drain(c->h_out[b], groups[gi].f0, groups[gi].nf);
+    };
     auto body = [&]() -> int {
-        for (size_t gi = 0; gi <= groups.size(); ++gi) {
-            if (gi < groups.size()) {
-                const int b = (int)(gi & 1);
-                const Group& G = groups[gi];
-                if (gi >= 2) {  // buffer b was last used by group gi-2: its D2H must be done and drained
-                    HIPCHK(c, hipEventSynchronize(out_done[b]));
-                    int r = drain(c->h_out[b], groups[gi - 2].f0, groups[gi - 2].nf);
-                    if (r) return r;
-                }
-                int r = fill(c->h_in[b], G.f0, G.nf);
+        for (size_t gi = 0; gi < ng; ++gi) {
+            const int b = (int)(gi % kStageBufs);
+            const Group& G = groups[gi];
+            if (gi >= (size_t)kStageBufs) {  // ring slot b was last used by group gi - kStageBufs: retire it first
+                int r = retire(gi - kStageBufs);
                 if (r) return r;
-                HIPCHK(c, hipMemcpyAsync(c->d_in[b], c->h_in[b], plane * G.nf, hipMemcpyHostToDevice, c->copy_in));
-                HIPCHK(c, hipEventRecord(in_done[b], c->copy_in));
-                HIPCHK(c, hipStreamWaitEvent(c->stream, in_done[b], 0));
-                FrameGeom gg = g;
-                for (const Pass& p : plan_passes(g.nctu, G.nf, c->max_ctus)) {
-                    r = run_pass(c, c->d_in[b], gg, p.ctu0, p.n, qp, c->d_out[b] + (size_t)p.ctu0 * kNOut);
-                    if (r) return r;
-                }
-                HIPCHK(c, hipEventRecord(comp_done[b], c->stream));
-                HIPCHK(c, hipStreamWaitEvent(c->copy_out, comp_done[b], 0));
-                HIPCHK(c, hipMemcpyAsync(c->h_out[b], c->d_out[b], (size_t)G.nf * g.nctu * kNOut * 4, hipMemcpyDeviceToHost, c->copy_out));
-                HIPCHK(c, hipEventRecord(out_done[b], c->copy_out));
-                // buffer reuse is safe without further stream waits: before group gi+2 touches
-                // buffer b again the host has synchronised on out_done[b] (above), which orders
-                // after this group's H2D, kernels and D2H.
             }
+            int r = fill(c->h_in[b], G.f0, G.nf);
+            if (r) return r;
+            HIPCHK(c, hipMemcpyAsync(c->d_in[b], c->h_in[b], plane * G.nf, hipMemcpyHostToDevice, c->copy_in));
+            HIPCHK(c, hipEventRecord(c->ev_in[b], c->copy_in));
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_in[b], 0));
+            for (const Pass& p : plan_passes(g.nctu, G.nf, c->max_ctus)) {
+                r = run_pass(c, c->d_in[b], g, p.ctu0, p.n, qp, c->d_out[b] + (size_t)p.ctu0 * kNOut);
+                if (r) return r;
+            }
+            HIPCHK(c, hipEventRecord(c->ev_comp[b], c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->copy_out, c->ev_comp[b], 0));
+            HIPCHK(c, hipMemcpyAsync(c->h_out[b], c->d_out[b], (size_t)G.nf * g.nctu * kNOut * 4, hipMemcpyDeviceToHost, c->copy_out));
+            HIPCHK(c, hipEventRecord(c->ev_out[b], c->copy_out));
+            // slot reuse needs no further stream waits: before group gi + kStageBufs touches slot b the host has
+            // synchronised on ev_out[b] (retire), which orders after this group's H2D, kernels and D2H
         }
-        // drain the last (up to) two groups in order
-        const size_t ng = groups.size();
-        for (size_t gi = (ng >= 2 ? ng - 2 : 0); gi < ng; ++gi) {
-            const int b = (int)(gi & 1);
-            HIPCHK(c, hipEventSynchronize(out_done[b]));
-            int r = drain(c->h_out[b], groups[gi].f0, groups[gi].nf);
+        for (size_t gi = (ng >= (size_t)kStageBufs ? ng - kStageBufs : 0); gi < ng; ++gi) {  // the groups still in flight, in order
+            int r = retire(gi);
             if (r) return r;
         }
         return ETHCNN_OK;
     };
-    result = body();
-    (void)hipStreamSynchronize(c->copy_in);
+    const int result = body();
+    (void)hipStreamSynchronize(c->copy_in);  // on an error path nothing may still be reading / writing the ring
     (void)hipStreamSynchronize(c->stream);
     (void)hipStreamSynchronize(c->copy_out);
-    for (int i = 0; i < 2; ++i) {
-        (void)hipEventDestroy(in_done[i]);
-        (void)hipEventDestroy(comp_done[i]);
-        (void)hipEventDestroy(out_done[i]);
-    }
     return result;
 }
 
