@@ -4,6 +4,7 @@
 // Mirrors /root/reference/HM-16.5_Test_AI/bin/video_to_cu_depth.py (driver) around
 // net_CNN.py (network).  There is no CPU compute path in this library.
 #include <hip/hip_runtime.h>
+#include <sched.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -29,10 +30,35 @@ using namespace ethcnn;
 // Persistent host worker pool for the staging fill (file pread / memcpy into pinned memory):
 // one memcpy stream moves ~10 GB/s while PCIe Gen5 x16 takes ~50, and a fill lasts well under a
 // millisecond, so threads are created once per context, not once per group.
+// CPUs of the NUMA node the GPU hangs off.  On a two-socket host the staging path runs at 12 M CTU/s when the pinned
+// buffers and the fill threads live on that node and at 8 M when they live on the other one (profiles/r02_host_copy.txt):
+// the DMA engine then pulls every byte across the socket interconnect.
+struct NumaCpus {
+    bool valid = false;
+    cpu_set_t set;
+};
+// runs the enclosed allocations / thread start-ups on the GPU's node, then puts the caller's affinity back
+class AffinityScope {
+public:
+    explicit AffinityScope(const NumaCpus& n) {
+        if (n.valid && sched_getaffinity(0, sizeof saved_, &saved_) == 0 && sched_setaffinity(0, sizeof n.set, &n.set) == 0) on_ = true;
+    }
+    ~AffinityScope() {
+        if (on_) (void)sched_setaffinity(0, sizeof saved_, &saved_);
+    }
+private:
+    cpu_set_t saved_;
+    bool on_ = false;
+};
+
 class HostPool {
 public:
-    explicit HostPool(int nthreads) {
-        for (int t = 1; t < nthreads; ++t) workers_.emplace_back([this] { loop(); });
+    HostPool(int nthreads, const NumaCpus& numa) {
+        for (int t = 1; t < nthreads; ++t)
+            workers_.emplace_back([this, numa] {
+                if (numa.valid) (void)sched_setaffinity(0, sizeof numa.set, &numa.set);  // the worker, not the caller
+                loop();
+            });
     }
     ~HostPool() {
         {
@@ -130,6 +156,21 @@ struct ethcnn_ctx {
     int state_nctu = 0;
 
     Workspace ws;
+    // Cross-pass software pipeline ("pass pipeline"): the tile stage of pass i+1 (HBM-bound, no MFMA) and
+    // the heads + gate stages of pass i (latency-bound, little MFMA) run on side streams beside the MFMA-bound trunk / FC1 of
+    // the neighbouring passes.  What two passes in flight would share is double-buffered by pass parity: the tile outputs
+    // (xs/xm/xl), h1 and the gate flags.  feat is produced and consumed on the main stream only.
+    uint4 *xs1 = nullptr, *xm1 = nullptr, *xl1 = nullptr;
+    float* h1_1 = nullptr;
+    int* flags1 = nullptr;
+    hipStream_t s_tile = nullptr, s_heads = nullptr;
+    hipEvent_t e_tile[2] = {}, e_trunk[2] = {}, e_fc1[2] = {}, e_heads[2] = {}, e_main = nullptr;
+    int tile_blocks = 256;   // blocks of the side-stream tile stage: one per CU (ETHCNN_TILE_BLOCKS)
+    unsigned pass_idx = 0;   // parity selects the buffer set
+    int last_parity = 0;     // of the last pass (debug_fetch reads its h1)
+    int overlap = 1;         // ETHCNN_OVERLAP bits: 1 = tile stage on its own stream (under FC1 of the previous pass),
+                             // 2 = heads + gate on their own stream, 4 = (with 1) the tile stage may also start under the
+                             // previous pass's trunk; 0 = everything on the main stream (r01 behaviour)
     int max_ctus = 131072;
     int last_n = 0;  // CTUs of the last pass (debug_fetch)
     bool debug_capture = false;  // also store FC2 outputs, logits and ungated probabilities (1.7 KB/CTU of writes)
@@ -149,6 +190,7 @@ struct ethcnn_ctx {
     hipEvent_t ev_in[kStageBufs] = {}, ev_comp[kStageBufs] = {}, ev_out[kStageBufs] = {};  // created with the ring, destroyed with it
     size_t in_cap = 0, out_cap = 0;
     HostPool* pool = nullptr;  // created on first use by the host / file entry points
+    NumaCpus numa;             // the GPU's host NUMA node (staging buffers + fill threads are placed there)
 };
 
 static thread_local std::string g_create_err;
@@ -179,10 +221,26 @@ extern "C" const char* ethcnn_last_error(const ethcnn_ctx* ctx) {
 // ------------------------------------------------------------------ workspace -------
 static void free_workspace(ethcnn_ctx* c) {
     Workspace& w = c->ws;
-    void* ptrs[] = {w.xs, w.xm, w.xl, w.feat, w.h1, w.h2, w.logits, w.raw, w.flags};
+    void* ptrs[] = {w.xs, w.xm, w.xl, w.feat, w.h1, w.h2, w.logits, w.raw, w.flags, c->xs1, c->xm1, c->xl1, c->h1_1, c->flags1};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     w = Workspace();
+    c->xs1 = c->xm1 = c->xl1 = nullptr;
+    c->h1_1 = nullptr;
+    c->flags1 = nullptr;
+}
+
+// the buffer set of pass parity p
+static Workspace ws_view(const ethcnn_ctx* c, int p) {
+    Workspace v = c->ws;
+    if (p) {
+        v.xs = c->xs1;
+        v.xm = c->xm1;
+        v.xl = c->xl1;
+        v.h1 = c->h1_1;
+        v.flags = c->flags1;
+    }
+    return v;
 }
 
 static int ensure_workspace(ethcnn_ctx* c, int n, int chunks) {
@@ -198,12 +256,18 @@ static int ensure_workspace(ethcnn_ctx* c, int n, int chunks) {
         HIPCHK(c, hipMalloc((void**)&w.h2, (size_t)cap * kNFc2 * 4));
         HIPCHK(c, hipMalloc((void**)&w.logits, (size_t)cap * kNOut * 4));
         HIPCHK(c, hipMalloc((void**)&w.raw, (size_t)cap * kNOut * 4));
+        HIPCHK(c, hipMalloc((void**)&c->xs1, (size_t)cap * 4096));
+        HIPCHK(c, hipMalloc((void**)&c->xm1, (size_t)cap * 2048));
+        HIPCHK(c, hipMalloc((void**)&c->xl1, (size_t)cap * 512));
+        HIPCHK(c, hipMalloc((void**)&c->h1_1, (size_t)cap * kNVec * 4));
         w.cap = cap;
     }
     if (chunks > w.flags_cap) {
-        if (w.flags) (void)hipFree(w.flags);
-        w.flags = nullptr;
+        if (w.flags) (void)hipFree(w.flags);  // hipFree synchronises the device: no pass in flight still uses them
+        if (c->flags1) (void)hipFree(c->flags1);
+        w.flags = c->flags1 = nullptr;
         HIPCHK(c, hipMalloc((void**)&w.flags, (size_t)chunks * 2 * sizeof(int)));
+        HIPCHK(c, hipMalloc((void**)&c->flags1, (size_t)chunks * 2 * sizeof(int)));
         w.flags_cap = chunks;
     }
     return 0;
@@ -232,10 +296,65 @@ extern "C" int ethcnn_create(ethcnn_ctx** out, const ethcnn_options* opt) {
     if (opt && opt->max_ctus_per_pass > 0) c->max_ctus = std::max(1024, (opt->max_ctus_per_pass + 1023) / 1024 * 1024);
     if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->copy_in, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->copy_out, hipStreamNonBlocking) != hipSuccess) {
+        hipStreamCreateWithFlags(&c->copy_out, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->s_tile, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->s_heads, hipStreamNonBlocking) != hipSuccess) {
         ethcnn_destroy(c);  // releases whichever streams were created
         return set_err(nullptr, ETHCNN_ERR_DEVICE, "cannot create HIP streams on device %d", dev);
     }
+    {
+        hipEvent_t* evs[] = {&c->e_tile[0], &c->e_tile[1], &c->e_trunk[0], &c->e_trunk[1], &c->e_fc1[0], &c->e_fc1[1],
+                             &c->e_heads[0], &c->e_heads[1], &c->e_main};
+        for (hipEvent_t* e : evs)
+            if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) {
+                ethcnn_destroy(c);
+                return set_err(nullptr, ETHCNN_ERR_DEVICE, "cannot create HIP events on device %d", dev);
+            }
+    }
+    if (const char* e = std::getenv("ETHCNN_OVERLAP")) c->overlap = std::atoi(e) & 7;  // development knob (A/B runs)
+    c->tile_blocks = prop.multiProcessorCount;
+    {   // the GPU's NUMA node -> its CPU list (/sys/devices/system/node/nodeN/cpulist: "64-127,192-255"); ETHCNN_NUMA_BIND=0 opts out
+        int node = -1;
+        const char* off = std::getenv("ETHCNN_NUMA_BIND");
+        const bool asked = !(off && std::atoi(off) == 0);
+        hipError_t qe = hipErrorNotSupported;
+        if (asked) {  // the PCI device's own sysfs entry first (works inside containers that see one GPU of eight) ...
+            char pci[96];
+            std::snprintf(pci, sizeof pci, "/sys/bus/pci/devices/%04x:%02x:%02x.0/numa_node", prop.pciDomainID, prop.pciBusID, prop.pciDeviceID);
+            if (FILE* f = std::fopen(pci, "r")) {
+                if (std::fscanf(f, "%d", &node) == 1 && node >= 0) qe = hipSuccess;
+                std::fclose(f);
+            }
+            if (qe != hipSuccess) qe = hipDeviceGetAttribute(&node, hipDeviceAttributeHostNumaId, dev);  // ... then the runtime's view
+        }
+        (void)hipGetLastError();  // an optional query: its failure must not stay behind as the thread's sticky last error
+        if (qe == hipSuccess && node >= 0) {
+            char path[96], buf[1024];
+            std::snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+            if (FILE* f = std::fopen(path, "r")) {
+                if (std::fgets(buf, sizeof buf, f)) {
+                    CPU_ZERO(&c->numa.set);
+                    int n = 0;
+                    for (char* q = buf; *q && *q != '\n';) {
+                        char* end;
+                        const long a = std::strtol(q, &end, 10);
+                        long b = a;
+                        if (end == q) break;
+                        if (*end == '-') { q = end + 1; b = std::strtol(q, &end, 10); }
+                        for (long k = a; k <= b && k < CPU_SETSIZE; ++k) { CPU_SET((int)k, &c->numa.set); ++n; }
+                        q = (*end == ',') ? end + 1 : end;
+                    }
+                    c->numa.valid = n > 0;
+                    if (c->numa.valid) {
+                        const size_t L = std::strlen(c->devname);
+                        std::snprintf(c->devname + L, sizeof c->devname - L, ", host NUMA node %d", node);
+                    }
+                }
+                std::fclose(f);
+            }
+        }
+    }
+    if (const char* e = std::getenv("ETHCNN_TILE_BLOCKS")) c->tile_blocks = std::max(1, std::atoi(e));
     *out = c;
     return ETHCNN_OK;
 }
@@ -271,9 +390,15 @@ extern "C" void ethcnn_destroy(ethcnn_ctx* c) {
         for (void* p : lp)
             if (p) (void)hipFree(p);
     }
-    if (c->stream) (void)hipStreamDestroy(c->stream);
-    if (c->copy_in) (void)hipStreamDestroy(c->copy_in);
-    if (c->copy_out) (void)hipStreamDestroy(c->copy_out);
+    {
+        hipEvent_t evs[] = {c->e_tile[0], c->e_tile[1], c->e_trunk[0], c->e_trunk[1], c->e_fc1[0], c->e_fc1[1],
+                            c->e_heads[0], c->e_heads[1], c->e_main};
+        for (hipEvent_t e : evs)
+            if (e) (void)hipEventDestroy(e);
+    }
+    hipStream_t streams[] = {c->stream, c->copy_in, c->copy_out, c->s_tile, c->s_heads};
+    for (hipStream_t st : streams)
+        if (st) (void)hipStreamDestroy(st);
     delete c;
 }
 
@@ -316,7 +441,7 @@ static int upload_weights(ethcnn_ctx* c) {
         std::memcpy(host.data() + offs[11 + 2 * h], blob + kOffFc3B[h], sizes[11 + 2 * h] * 4);
     }
     if (!c->dw_arena) HIPCHK(c, hipMalloc((void**)&c->dw_arena, total * 4));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipDeviceSynchronize());  // no pass in flight (on any of the streams) may still read the old arena
     HIPCHK(c, hipMemcpy(c->dw_arena, host.data(), total * 4, hipMemcpyHostToDevice));
     DeviceWeights& d = c->dw;
     d.trunk_w = c->dw_arena + offs[0];
@@ -407,12 +532,13 @@ struct StageTimer {
     hipEvent_t a = nullptr, b = nullptr;
     bool on;
     long ctus;
-    StageTimer(ethcnn_ctx* c_, int st, long n = 0) : c(c_), stage(st), ctus(n) {
+    hipStream_t stream;  // the stream the stage is launched on (HIP events see only their own stream)
+    StageTimer(ethcnn_ctx* c_, int st, long n = 0, hipStream_t s = nullptr) : c(c_), stage(st), ctus(n), stream(s ? s : c_->stream) {
         on = c->profiling >= 2 || (c->profiling == 1 && st == ETHCNN_STAGE_FC1 && (c->fc1_sample++ % 3) == 0);
         if (on) {
             a = get_event(c);
             b = get_event(c);
-            if (!a || !b || hipEventRecord(a, c->stream) != hipSuccess) fail();
+            if (!a || !b || hipEventRecord(a, stream) != hipSuccess) fail();
         }
     }
     // a timing failure never fails the pass; it is counted (ethcnn_stage_times.timing_errors) so a
@@ -425,7 +551,7 @@ struct StageTimer {
         a = b = nullptr;
     }
     ~StageTimer() {
-        if (on && hipEventRecord(b, c->stream) != hipSuccess) fail();
+        if (on && hipEventRecord(b, stream) != hipSuccess) fail();
         if (on) {
             c->pending.push_back({a, b, stage, ctus});
             c->times.timed[stage]++;
@@ -484,25 +610,76 @@ static int make_geom(ethcnn_ctx* c, int w, int h, ptrdiff_t pitch, ptrdiff_t fst
     return 0;
 }
 
-// one pass over CTUs [ctu0, ctu0+n) of the sequence; ctu0 is sub-batch aligned
+// the main stream waits for everything the side streams still have in flight (heads + gate of the last two passes; a
+// tile stage is always followed by its trunk on the main stream)
+static int join_side(ethcnn_ctx* c) {
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->e_heads[0], 0));  // a never-recorded event is a no-op
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->e_heads[1], 0));
+    return 0;
+}
+// main-stream users of the workspace outside run_pass (LDP front-end, LSTM step) bracket themselves with these
+static int serial_begin(ethcnn_ctx* c) { return join_side(c); }
+static int serial_end(ethcnn_ctx* c) {
+    HIPCHK(c, hipEventRecord(c->e_main, c->stream));  // the next pipelined tile stage waits for it
+    return 0;
+}
+
+// one pass over CTUs [ctu0, ctu0+n) of the sequence; ctu0 is sub-batch aligned.  input_ready: event after which d_luma
+// may be read (nullptr: the caller ordered it before the call).  Asynchronous; with c->overlap the pass ends on s_heads.
 static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, int qp,
-                    float* d_probs_pass) {
+                    float* d_probs_pass, hipEvent_t input_ready = nullptr) {
     const int cpf = chunks_per_frame(g.nctu);
     const long nchunks = (ctu0 + n - 1) / g.nctu * cpf + ((ctu0 + n - 1) % g.nctu) / kSubBatch + 1 -
                          (ctu0 / g.nctu * cpf + (ctu0 % g.nctu) / kSubBatch);
     int rc = ensure_workspace(c, n, (int)nchunks);
     if (rc) return rc;
     const float qn = (float)qp * (1.0f / 51.0f);  // net_CNN.py:106
-    { StageTimer t(c, ETHCNN_STAGE_TILE, n); launch_tile(d_luma, g, ctu0, n, c->ws, (int)nchunks * 2, c->stream); }
-    { StageTimer t(c, ETHCNN_STAGE_TRUNK); launch_trunk(c->ws, c->dw, n, false, c->stream); }
-    { StageTimer t(c, ETHCNN_STAGE_FC1, n); launch_fc1(c->ws, c->dw, n, c->ws.h1, c->stream); }
-    Workspace wv = c->ws;
+    const int p = c->overlap ? (int)(c->pass_idx++ & 1) : 0;
+    const Workspace w = ws_view(c, p);
+    const bool side_tile = (c->overlap & 1) != 0, side_heads = (c->overlap & 2) != 0;
+    hipStream_t s_tile = side_tile ? c->s_tile : c->stream, s_heads = side_heads ? c->s_heads : c->stream;
+    if (input_ready) HIPCHK(c, hipStreamWaitEvent(s_tile, input_ready, 0));
+    if (side_tile) {
+        // tile(i) overwrites the tile outputs and gate flags of buffer set p: last read by trunk(i-2) / gate(i-2)
+        HIPCHK(c, hipStreamWaitEvent(s_tile, c->e_trunk[p], 0));
+        HIPCHK(c, hipStreamWaitEvent(s_tile, c->e_heads[p], 0));
+        HIPCHK(c, hipStreamWaitEvent(s_tile, c->e_main, 0));
+        // ... and it should run beside FC1(i-1), not beside trunk(i-1): with the trunk it competes for VALU issue and HBM
+        // (measured: trunk 556 -> 819 us, tile 180 -> 511 us, step period 2.60 -> 2.73 ms; profiles/r02_overlap_trace.txt)
+        if (!(c->overlap & 4)) HIPCHK(c, hipStreamWaitEvent(s_tile, c->e_trunk[p ^ 1], 0));
+    }
+    (void)hipGetLastError();  // launch errors below are reported per stage; drop anything stale first
+#define LAUNCH_OK(name)                                                                                            \
+    do {                                                                                                           \
+        const hipError_t le_ = hipGetLastError();                                                                  \
+        if (le_ != hipSuccess) return set_err(c, ETHCNN_ERR_DEVICE, "launch of the %s stage failed: %s", name, hipGetErrorString(le_)); \
+    } while (0)
+    { StageTimer t(c, ETHCNN_STAGE_TILE, n, s_tile); launch_tile(d_luma, g, ctu0, n, w, (int)nchunks * 2, s_tile, side_tile ? c->tile_blocks : 0); }
+    LAUNCH_OK("tile");
+    if (side_tile) {
+        HIPCHK(c, hipEventRecord(c->e_tile[p], s_tile));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->e_tile[p], 0));
+    }
+    { StageTimer t(c, ETHCNN_STAGE_TRUNK); launch_trunk(w, c->dw, n, false, c->stream); }
+    LAUNCH_OK("trunk");
+    if (side_tile) HIPCHK(c, hipEventRecord(c->e_trunk[p], c->stream));
+    if (side_heads) HIPCHK(c, hipStreamWaitEvent(c->stream, c->e_heads[p], 0));  // FC1(i) overwrites h1 of set p: last read by heads(i-2)
+    { StageTimer t(c, ETHCNN_STAGE_FC1, n); launch_fc1(w, c->dw, n, w.h1, c->stream); }
+    LAUNCH_OK("FC1");
+    if (side_heads) {
+        HIPCHK(c, hipEventRecord(c->e_fc1[p], c->stream));
+        HIPCHK(c, hipStreamWaitEvent(s_heads, c->e_fc1[p], 0));
+    }
+    Workspace wv = w;
     if (!c->debug_capture) wv.h2 = wv.logits = wv.raw = nullptr;
-    { StageTimer t(c, ETHCNN_STAGE_HEADS); launch_heads(wv, c->dw, n, qn, g.nctu, ctu0, c->thr1, c->thr2, d_probs_pass, c->stream); }
-    { StageTimer t(c, ETHCNN_STAGE_GATE); launch_gate(c->ws, n, g.nctu, ctu0, c->thr2, d_probs_pass, c->stream); }
-    HIPCHK(c, hipGetLastError());
+    { StageTimer t(c, ETHCNN_STAGE_HEADS, 0, s_heads); launch_heads(wv, c->dw, n, qn, g.nctu, ctu0, c->thr1, c->thr2, d_probs_pass, s_heads); }
+    { StageTimer t(c, ETHCNN_STAGE_GATE, 0, s_heads); launch_gate(w, n, g.nctu, ctu0, c->thr2, d_probs_pass, s_heads); }
+    LAUNCH_OK("heads / gate");
+#undef LAUNCH_OK
+    if (c->overlap) HIPCHK(c, hipEventRecord(c->e_heads[p], s_heads));  // gate(i) done: flags / h1 of set p are free again
     c->times.ctus += n;
     c->last_n = n;
+    c->last_parity = p;
     return 0;
 }
 
@@ -551,6 +728,7 @@ static int ensure_staging(ethcnn_ctx* c, size_t in_bytes, size_t out_bytes, int 
         for (int i = 0; i < kStageBufs; ++i)
             if (c->h_in[i]) keep = std::max(keep, i + 1);
         free_staging(c);  // on any failure below the partial ring is released by ethcnn_destroy / the next call
+        AffinityScope on_gpu_node(c->numa);  // page-locked memory is allocated where the calling thread runs
         for (int i = 0; i < keep; ++i) {
             HIPCHK(c, hipHostMalloc((void**)&c->h_in[i], ic, hipHostMallocDefault));
             HIPCHK(c, hipHostMalloc((void**)&c->h_out[i], oc, hipHostMallocDefault));
@@ -572,7 +750,7 @@ static HostPool* host_pool(ethcnn_ctx* c) {
     if (!c->pool) {
         int nt = std::min(16, std::max(1, (int)std::thread::hardware_concurrency() / 2));
         if (const char* e = std::getenv("ETHCNN_HOST_THREADS")) nt = std::max(1, std::min(32, std::atoi(e)));  // 64+ threads measured slower (scripts/s3_threads.py)
-        c->pool = new HostPool(nt);
+        c->pool = new HostPool(nt, c->numa);
     }
     return c->pool;
 }
@@ -630,12 +808,11 @@ static int host_pipeline(ethcnn_ctx* c, int w, int h, int nframes, int qp, Fill 
             if (r) return r;
             HIPCHK(c, hipMemcpyAsync(c->d_in[b], c->h_in[b], plane * G.nf, hipMemcpyHostToDevice, c->copy_in));
             HIPCHK(c, hipEventRecord(c->ev_in[b], c->copy_in));
-            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_in[b], 0));
             for (const Pass& p : plan_passes(g.nctu, G.nf, c->max_ctus)) {
-                r = run_pass(c, c->d_in[b], g, p.ctu0, p.n, qp, c->d_out[b] + (size_t)p.ctu0 * kNOut);
+                r = run_pass(c, c->d_in[b], g, p.ctu0, p.n, qp, c->d_out[b] + (size_t)p.ctu0 * kNOut, c->ev_in[b]);
                 if (r) return r;
             }
-            HIPCHK(c, hipEventRecord(c->ev_comp[b], c->stream));
+            HIPCHK(c, hipEventRecord(c->ev_comp[b], (c->overlap & 2) ? c->s_heads : c->stream));  // where the group's last pass ends
             HIPCHK(c, hipStreamWaitEvent(c->copy_out, c->ev_comp[b], 0));
             HIPCHK(c, hipMemcpyAsync(c->h_out[b], c->d_out[b], (size_t)G.nf * g.nctu * kNOut * 4, hipMemcpyDeviceToHost, c->copy_out));
             HIPCHK(c, hipEventRecord(c->ev_out[b], c->copy_out));
@@ -650,7 +827,9 @@ static int host_pipeline(ethcnn_ctx* c, int w, int h, int nframes, int qp, Fill 
     };
     const int result = body();
     (void)hipStreamSynchronize(c->copy_in);  // on an error path nothing may still be reading / writing the ring
+    (void)hipStreamSynchronize(c->s_tile);
     (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->s_heads);
     (void)hipStreamSynchronize(c->copy_out);
     return result;
 }
@@ -761,6 +940,8 @@ extern "C" int ethcnn_resi_vectors_device(ethcnn_ctx* c, const uint8_t* d_luma, 
     int rc = make_geom(c, w, h, pitch, (ptrdiff_t)pitch * h, &g);
     if (rc) return rc;
     HIPCHK(c, hipSetDevice(c->device));
+    rc = serial_begin(c);
+    if (rc) return rc;
     for (int o = 0; o < g.nctu; o += c->max_ctus) {
         const int n = std::min(c->max_ctus, g.nctu - o);
         rc = ensure_workspace(c, n, 1);
@@ -771,8 +952,9 @@ extern "C" int ethcnn_resi_vectors_device(ethcnn_ctx* c, const uint8_t* d_luma, 
         HIPCHK(c, hipGetLastError());
         c->times.ctus += n;
         c->last_n = n;
+        c->last_parity = 0;
     }
-    return ETHCNN_OK;
+    return serial_end(c);
 }
 
 extern "C" int ethcnn_resi_vectors(ethcnn_ctx* c, const uint8_t* luma, int w, int h, ptrdiff_t pitch, float* vec) {
@@ -794,6 +976,7 @@ extern "C" int ethcnn_resi_vectors(ethcnn_ctx* c, const uint8_t* luma, int w, in
 static int upload_lstm(ethcnn_ctx* c) {
     HIPCHK(c, hipSetDevice(c->device));
     if (!c->d_lstm) HIPCHK(c, hipMalloc((void**)&c->d_lstm, kLstmBlobFloats * sizeof(float)));
+    HIPCHK(c, hipDeviceSynchronize());
     HIPCHK(c, hipMemcpyAsync(c->d_lstm, c->lstm_blob.data(), kLstmBlobFloats * sizeof(float), hipMemcpyHostToDevice,
                              c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -861,6 +1044,8 @@ extern "C" int ethcnn_lstm_step_device(ethcnn_ctx* c, const float* d_vec, const 
     int rc = ensure_workspace(c, std::min(n, c->max_ctus), chunks);
     if (rc) return rc;
     if (n > c->ws.cap) return set_err(c, ETHCNN_ERR_ARG, "frame of %d CTUs exceeds max_ctus_per_pass", n);
+    rc = serial_begin(c);
+    if (rc) return rc;
     HIPCHK(c, hipMemsetAsync(c->ws.flags, 0, (size_t)chunks * 2 * sizeof(int), c->stream));
     {
         StageTimer t(c, ETHCNN_STAGE_HEADS);
@@ -874,7 +1059,7 @@ extern "C" int ethcnn_lstm_step_device(ethcnn_ctx* c, const float* d_vec, const 
     }
     HIPCHK(c, hipGetLastError());
     c->last_n = n;
-    return ETHCNN_OK;
+    return serial_end(c);
 }
 
 // predict_cu_depth() of resi_to_cu_depth_LDP.py:108-129 for one frame; the new state stays in HBM.
@@ -957,6 +1142,7 @@ extern "C" int ethcnn_device_free(ethcnn_ctx* c, void* p) {
 extern "C" int ethcnn_host_alloc(ethcnn_ctx* c, size_t bytes, void** out) {
     if (!c || !out) return ETHCNN_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
+    AffinityScope on_gpu_node(c->numa);
     HIPCHK(c, hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
     return ETHCNN_OK;
 }
@@ -967,18 +1153,22 @@ extern "C" int ethcnn_host_free(ethcnn_ctx* c, void* p) {
 }
 extern "C" int ethcnn_memcpy_h2d(ethcnn_ctx* c, void* dst, const void* src, size_t bytes) {
     if (!c || !dst || !src) return ETHCNN_ERR_ARG;
+    if (int rc = join_side(c)) return rc;  // "after everything enqueued so far", side streams included
     HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return ETHCNN_OK;
 }
 extern "C" int ethcnn_memcpy_d2h(ethcnn_ctx* c, void* dst, const void* src, size_t bytes) {
     if (!c || !dst || !src) return ETHCNN_ERR_ARG;
+    if (int rc = join_side(c)) return rc;
     HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return ETHCNN_OK;
 }
 extern "C" int ethcnn_synchronize(ethcnn_ctx* c) {
     if (!c) return ETHCNN_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = join_side(c)) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return ETHCNN_OK;
 }
@@ -997,7 +1187,7 @@ extern "C" int ethcnn_debug_fetch(ethcnn_ctx* c, int which, float* out, size_t n
     size_t per = 0;
     switch (which) {
         case ETHCNN_DBG_FEATURES: src = c->ws.feat; per = kNFeat; break;
-        case ETHCNN_DBG_FC1: src = c->ws.h1; per = kNVec; break;
+        case ETHCNN_DBG_FC1: src = ws_view(c, c->last_parity).h1; per = kNVec; break;
         case ETHCNN_DBG_FC2: src = c->ws.h2; per = kNFc2; break;
         case ETHCNN_DBG_LOGITS: src = c->ws.logits; per = kNOut; break;
         case ETHCNN_DBG_RAW_PROBS: src = c->ws.raw; per = kNOut; break;

@@ -29,8 +29,9 @@ struct FrameGeom {
 
 // k0: luma frames -> xs/xm/xl for CTUs [ctu0, ctu0 + n) of the frame sequence; also clears the first
 // n_flags ints of ws.flags (the pass's gate predicates; 0 = leave them alone)
+// max_blocks > 0: slab-staged persistent form with at most that many blocks (one per CU when it runs beside FC1)
 void launch_tile(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, const Workspace& ws, int n_flags,
-                 hipStream_t s);
+                 hipStream_t s, int max_blocks = 0);
 // k1: xs/xm/xl -> feat
 void launch_trunk(const Workspace& ws, const DeviceWeights& w, int n, bool resi, hipStream_t s);
 // k2: feat -> h1 (bias + leaky-ReLU fused); out may be ws.h1 or a caller buffer (resi vectors)

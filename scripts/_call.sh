@@ -1,11 +1,8 @@
 set -u
 mkdir -p gpurun_out
-python -m pytest tests -x -q -m gpu 2>&1 | tail -3
-python bench.py --no-cpu-baseline --steps 20 > gpurun_out/b_c3.json 2>gpurun_out/b.err || tail -3 gpurun_out/b.err
-python -c "
-import json; d=json.load(open('gpurun_out/b_c3.json')); print('c3', d['value'], d['host_scopes'])"
-python bench.py --workload c2 --no-cpu-baseline --steps 20 > gpurun_out/b_c2.json 2>gpurun_out/b.err || tail -3 gpurun_out/b.err
-python -c "
-import json; d=json.load(open('gpurun_out/b_c2.json')); print('c2', d['value'], d['host_scopes'])"
-for t in 8 16 32; do ETHCNN_HOST_THREADS=$t python bench.py --no-cpu-baseline --steps 5 > gpurun_out/b_t$t.json 2>/dev/null; python -c "
-import json; d=json.load(open('gpurun_out/b_t$t.json')); print('threads $t', d['host_scopes'])"; done
+python bench.py --no-cpu-baseline --steps 5 2>&1 | tail -3 | cut -c1-600
+for cpus in 0-63 64-127; do
+taskset -c $cpus python bench.py --no-cpu-baseline --steps 5 > gpurun_out/numa_$cpus.json 2>gpurun_out/numa.err || tail -3 gpurun_out/numa.err; python -c "
+import json; d=json.load(open('gpurun_out/numa_$cpus.json')); h=d['host_scopes']; print('cpus $cpus', d['value'], h['s2_host_to_host_ctus_per_s'], h['s3_file_to_file_ctus_per_s'])"
+done
+cat /sys/class/drm/card*/device/numa_node 2>/dev/null | tr '\n' ' '; echo
