@@ -582,6 +582,14 @@ extern "C" int ethcnn_set_profiling(ethcnn_ctx* c, int on) {
     c->fc1_sample = 0;  // the first pass after this call is a timed one
     return ETHCNN_OK;
 }
+extern "C" int ethcnn_set_pass_pipeline(ethcnn_ctx* c, int on) {
+    if (!c) return ETHCNN_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());  // nothing of the old mode is in flight when the mode changes
+    c->overlap = on ? 1 : 0;
+    return ETHCNN_OK;
+}
+
 extern "C" int ethcnn_get_stage_times(ethcnn_ctx* c, ethcnn_stage_times* out) {
     if (!c || !out) return ETHCNN_ERR_ARG;
     HIPCHK(c, hipStreamSynchronize(c->stream));

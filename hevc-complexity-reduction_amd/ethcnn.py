@@ -61,6 +61,7 @@ SIGNATURES = {
     "ethcnn_set_thresholds": (_i, [_vp, ctypes.c_float, ctypes.c_float]),
     "ethcnn_get_thresholds": (_i, [_vp, _fp, _fp]),
     "ethcnn_predict_luma_device": (_i, [_vp, _vp, _i, _i, _pd, _pd, _i, _i, _vp]),
+    "ethcnn_set_pass_pipeline": (_i, [_vp, _i]),
     "ethcnn_ldp_step": (_i, [_vp, _vp, _i, _i, _pd, _i, _i, _vp, _fp]),
     "ethcnn_ldp_get_state": (_i, [_vp, _fp, _sz]),
     "ethcnn_host_alloc": (_i, [_vp, _sz, ctypes.POINTER(_vp)]),
@@ -430,6 +431,10 @@ class EthCnn(object):
     def set_profiling(self, level=2):
         """0 off, 1 dominant kernel (FC1) only, 2 every stage."""
         self._chk(self.lib.ethcnn_set_profiling(self.h, int(level)))
+
+    def set_pass_pipeline(self, on=True):
+        """CTU-load stage of pass i+1 beside FC1 of pass i (default on); off = one stream, stage timings do not overlap"""
+        self._chk(self.lib.ethcnn_set_pass_pipeline(self.h, 1 if on else 0))
 
     def reset_stage_times(self):
         self._chk(self.lib.ethcnn_reset_stage_times(self.h))

@@ -177,6 +177,11 @@ typedef struct ethcnn_stage_times {
 int ethcnn_set_profiling(ethcnn_ctx* ctx, int level); /* 0 off; 1 events around the dominant kernel (FC1) on every 3rd
                                                           pass (an event pair costs ~12 us of stream time); 2 around every launch */
 int ethcnn_get_stage_times(ethcnn_ctx* ctx, ethcnn_stage_times* out); /* synchronizes */
+/* Pass pipeline (default on): the CTU-load stage of pass i+1 runs on a side stream beside FC1 of pass i (consecutive passes
+ * of one call, or consecutive asynchronous ethcnn_predict_luma_device calls).  Results do not depend on it.  Off = every
+ * stage of every pass in order on one stream: what per-stage timings (profiling level 2) should be read against, because
+ * with the pipeline on the stage intervals overlap.  Synchronizes.  Environment: ETHCNN_OVERLAP=0 starts contexts with it off. */
+int ethcnn_set_pass_pipeline(ethcnn_ctx* ctx, int on);
 int ethcnn_reset_stage_times(ethcnn_ctx* ctx);
 
 /* ---- parity-test introspection: intermediates of the LAST pass, copied to host. */
