@@ -310,12 +310,15 @@ def cpu_baseline_ldp(luma, W, H, QP, target_seconds):
     import ethcnn_lstm_np as ol
     cb, lb = oracle.synth_blob(1, 8.0), ol.synth_lstm_blob(2, 3.0)
     nctu = ((W + 63) // 64) * ((H + 63) // 64)
+    logical, cores, quota = usable_host_cpus()
+    oracle.set_threads(cores)
     st, n, t0 = None, 0, time.perf_counter()
     while time.perf_counter() - t0 < target_seconds or n < 2:
         _, st = ol.lstm_step(lb, oracle.resi_vectors(cb, luma[n % luma.shape[0]], W, H), st, QP, n + 1, 0.5, 0.5, mode=0)
         n += 1
     dt = time.perf_counter() - t0
-    return {"value": n * nctu / dt, "unit": "CTU/s", "cores": os.cpu_count() or 1, "kind": "port",
+    return {"value": n * nctu / dt, "unit": "CTU/s", "cores": cores, "kind": "port",
+            "host": "%d logical CPUs, cgroup CPU quota %s" % (logical, "none" if quota is None else "%.1f cores" % quota),
             "sample": "%d consecutive frames of %dx%d (%d CTUs each), oracle resi_vectors (OpenMP) + oracle_lstm_step, %.1f s"
                       % (n, W, H, nctu, dt)}
 
@@ -385,11 +388,33 @@ def host_scopes(ctx, luma, W, H, NF, QP, yuv):
     return out
 
 
+def usable_host_cpus():
+    """-> (logical cpus visible, cpus this process may actually burn).  The GPU boxes run the job in a cgroup with a CPU
+    quota (cpu.max 1600000/100000 = 16 cores of the 256 logical ones): more runnable threads than that get throttled by CFS
+    and the oracle collapses (measured: 16 threads 125 k CTU/s, 32: 136 k, 256: 27 k)."""
+    logical = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    usable = logical if quota is None else max(1, min(logical, int(quota + 0.5)))
+    return logical, usable, quota
+
+
 def cpu_baselines(luma, W, H, QP, target_seconds, yuv):
     """CPU baselines on the host cores of this box, each on a bounded sample of the same workload
     (BASELINE.md section 4).  [0] is also reported as `cpu_baseline`:
-      [0] B1/S1  oracle (C port of the reference's CPU path, OpenMP over CTUs), all cores, frames in
-                 memory -> probabilities in memory (the scope of the GPU step);
+      [0] B1/S1  oracle (C port of the reference's CPU path, OpenMP over CTUs), all USABLE cores (the cgroup CPU quota of
+                 the box, not its logical CPU count), frames in memory -> probabilities in memory (the scope of the GPU step);
       [1] B1/S1  the same on ONE thread;
       [2] B1/S3  the oracle at the reference's own timed scope: 4:2:0 file -> cu_depth.dat;
       [3] B2/S3  the TF-CPU proxy: per-CTU Python tiling loop + 1024-CTU feeds through torch-CPU ops
@@ -397,7 +422,8 @@ def cpu_baselines(luma, W, H, QP, target_seconds, yuv):
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ethcnn_np as oracle
-    cores = os.cpu_count() or 1
+    logical, cores, quota = usable_host_cpus()
+    host = "%d logical CPUs, cgroup CPU quota %s" % (logical, "none" if quota is None else "%.1f cores" % quota)
     blob = oracle.synth_blob(1, 8.0)
     NF = luma.shape[0]
     nctu = ((W + 63) // 64) * ((H + 63) // 64)
@@ -415,11 +441,11 @@ def cpu_baselines(luma, W, H, QP, target_seconds, yuv):
             oracle.predict_frames(blob, luma[:frames], W, H, frames, QP, 0.5, 0.5, mode=0)
         dt = time.perf_counter() - t0
         n = reps * frames * nctu
-        return {"value": n / dt, "unit": "CTU/s", "cores": threads, "kind": "port", "scope": "S1 memory -> memory", "name": label,
+        return {"value": n / dt, "unit": "CTU/s", "cores": threads, "kind": "port", "scope": "S1 memory -> memory", "name": label, "host": host,
                 "sample": "%d pass(es) over %d frame(s) of %dx%d (%d CTUs), oracle/ethcnn_oracle.c canonical mode, OpenMP over the "
                           "CTUs of a frame group, %.1f s" % (reps, frames, W, H, n, dt)}
 
-    out.append(timed_passes(NF, budget["all"], "B1 oracle, all host threads", cores))
+    out.append(timed_passes(NF, budget["all"], "B1 oracle, all usable host cores", cores))
     # one thread: ~0.5 k CTU/s -> one frame is seconds of work; never more than one frame, one pass
     one = timed_passes(1, 0.0, "B1 oracle, 1 thread", 1)
     out.append(one)
@@ -433,17 +459,16 @@ def cpu_baselines(luma, W, H, QP, target_seconds, yuv):
         P.tofile(dat)
         reps += 1
     dt = time.perf_counter() - t0
-    out.append({"value": reps * NF * nctu / dt, "unit": "CTU/s", "cores": cores, "kind": "port", "name": "B1 oracle, all host threads, file scope",
+    out.append({"value": reps * NF * nctu / dt, "unit": "CTU/s", "cores": cores, "kind": "port", "name": "B1 oracle, all usable host cores, file scope", "host": host,
                 "scope": "S3 4:2:0 file -> cu_depth.dat (video_to_cu_depth.py:142-145)",
                 "sample": "%d pass(es) over the %d-frame %dx%d file on tmpfs, %.1f s" % (reps, NF, W, H, dt)})
     try:
         import tf_cpu_proxy as proxy
         import torch
-        # 64 threads: more does not help ops this small (and 256 oversubscribe); the count used is reported
-        pt = min(cores, 64)
+        pt = min(cores, 64)  # more does not help ops this small; the count used is reported
         proxy.predict_file(blob, yuv.path, W, H, QP, dat, max_frames=1, threads=pt)  # warm
         frames, ctus, dt = proxy.predict_file(blob, yuv.path, W, H, QP, dat, max_seconds=budget["proxy"], threads=pt)
-        out.append({"value": ctus / dt, "unit": "CTU/s", "cores": pt, "kind": "port", "name": "B2 TF-CPU proxy (torch-CPU ops, reference-shaped driver)",
+        out.append({"value": ctus / dt, "unit": "CTU/s", "cores": pt, "kind": "port", "name": "B2 TF-CPU proxy (torch-CPU ops, reference-shaped driver)", "host": host,
                     "scope": "S3 4:2:0 file -> cu_depth.dat (video_to_cu_depth.py:142-145)",
                     "sample": "first %d frame(s) of the %dx%d file (%d CTUs): per-CTU Python tiling loop, <=1024-CTU feeds, torch %s CPU, "
                               "%d threads, %.1f s" % (frames, W, H, ctus, torch.__version__, pt, dt)})

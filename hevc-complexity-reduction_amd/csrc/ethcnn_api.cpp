@@ -754,9 +754,22 @@ static int ensure_staging(ethcnn_ctx* c, size_t in_bytes, size_t out_bytes, int 
 
 // A staging group is filled in units of (frame, band of rows) of ~512 KiB so that the units divide
 // evenly over the pool whatever the frame count of the group: fn(frame, row0, rows).
+// CPUs this process may actually use: the logical count capped by the cgroup CPU quota (cpu.max "1600000 100000" = 16)
+static int usable_cpus() {
+    int n = std::max(1, (int)std::thread::hardware_concurrency());
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32];
+        long per = 0;
+        if (std::fscanf(f, "%31s %ld", q, &per) == 2 && std::strcmp(q, "max") != 0 && per > 0)
+            n = std::max(1, std::min(n, (int)((std::atol(q) + per / 2) / per)));
+        std::fclose(f);
+    }
+    return n;
+}
+
 static HostPool* host_pool(ethcnn_ctx* c) {
     if (!c->pool) {
-        int nt = std::min(16, std::max(1, (int)std::thread::hardware_concurrency() / 2));
+        int nt = std::min(16, std::max(1, std::min(usable_cpus(), (int)std::thread::hardware_concurrency() / 2)));
         if (const char* e = std::getenv("ETHCNN_HOST_THREADS")) nt = std::max(1, std::min(32, std::atoi(e)));  // 64+ threads measured slower (scripts/s3_threads.py)
         c->pool = new HostPool(nt, c->numa);
     }

@@ -112,6 +112,24 @@ def build():
     subprocess.check_call(["make", "-s", "-C", _HERE])
 
 
+def _usable_cpus():
+    """logical CPUs of this process, capped by the cgroup CPU quota (the GPU boxes: 256 logical, quota 16 cores;
+    256 OpenMP threads under that quota run 5x SLOWER than 16)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(per) + 0.5)))
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            if q > 0:
+                n = max(1, min(n, int(q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()) + 0.5)))
+        except Exception:
+            pass
+    return n
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -131,6 +149,7 @@ def lib():
         L.oracle_resi_vectors.argtypes = [fp, up, ctypes.c_int, ctypes.c_int, ctypes.c_long,
                                           ctypes.c_int, fp]
         L.oracle_set_threads.argtypes = [ctypes.c_int]
+        L.oracle_set_threads(_usable_cpus())  # never more OpenMP threads than the cgroup lets run (CFS throttling otherwise)
         L.oracle_expf_export.argtypes = [ctypes.c_float]
         L.oracle_expf_export.restype = ctypes.c_float
         _lib = L
