@@ -41,7 +41,23 @@ typedef const __attribute__((address_space(1))) void glb_void;
 // iteration's own issue count: a COUNTED s_waitcnt, never vmcnt(0), and a raw s_barrier (a
 // __syncthreads() would drain the queue, ROCm 7.2).  WAR: stage (kc+3)%3 == kc%3 is refilled in
 // iteration kc+1, after every wave has passed the barrier that ends iteration kc.
-template <int MS, int NS, int WM, int NSUB, bool GROUP>
+template <int N>
+__device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// wait until at most `keep` (0..MAXK) groups of ISSUE DMA instructions are still in flight
+template <int ISSUE, int MAXK>
+__device__ __forceinline__ void vm_wait_groups(int keep) {
+    if constexpr (MAXK == 0) {
+        vm_wait<0>();
+    } else {
+        if (keep >= MAXK) vm_wait<MAXK * ISSUE>();
+        else vm_wait_groups<ISSUE, MAXK - 1>(keep);
+    }
+}
+
+// NST = LDS stages (prefetch distance NST - 1).  3 everywhere: deeper rings (4..6 stages, distance up to 5) were measured on
+// the short-range shapes, which run one block per CU or less, and change nothing (profiles/r02_fc1_variants.txt section 5):
+// those launches are bound by the per-chunk barrier + ds_read -> MFMA latency of a lone wave per SIMD, not by DMA latency.
+template <int MS, int NS, int WM, int NSUB, bool GROUP, int NST = 3>
 __global__ __launch_bounds__(64 * WM) void k_fc1_p3(const float* __restrict__ feat, const float* __restrict__ Wimg,
                                                     const float* __restrict__ bias, float* __restrict__ out, int M) {
     constexpr int BK = 16 * NSUB, BN = 16 * NS, NSPLIT = kNVec / BN, BM = 16 * MS * WM;
@@ -54,8 +70,10 @@ __global__ __launch_bounds__(64 * WM) void k_fc1_p3(const float* __restrict__ fe
     constexpr int ISSUE = B_PER + A_PER;            // VMEM ops per wave per iteration
     constexpr int A_FLOATS = WM * A_PER * 256;
     constexpr int STAGE = B_FLOATS + A_FLOATS;
-    static_assert(NK % 3 == 0 && NK >= 3, "K chunks must come in threes");
-    __shared__ __attribute__((aligned(16))) float smem[3 * STAGE];  // the ONLY LDS object
+    constexpr int DIST = NST - 1;
+    static_assert(NK % NST == 0 && NK >= NST, "K chunks must come in whole rounds of the stage ring");
+    static_assert(DIST * ISSUE <= 63, "vmcnt is a 6-bit counter");
+    __shared__ __attribute__((aligned(16))) float smem[NST * STAGE];  // the ONLY LDS object
 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int col = lane & 15, g = lane >> 4;
@@ -148,29 +166,28 @@ __global__ __launch_bounds__(64 * WM) void k_fc1_p3(const float* __restrict__ fe
             }                                                                                          \
         }                                                                                              \
     }
-#define P3_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
-#define P3_STEP(kc, st, st2)                                                                           \
+    // iteration kc: refill the stage consumed in iteration kc-1 with chunk kc+DIST, compute chunk kc, then make sure chunk
+    // kc+1 has landed: of the chunks issued so far only the newest min(DIST-1, NK-2-kc) may still be in flight
+#define P3_STEP(kc, st)                                                                                \
     {                                                                                                  \
-        if ((kc) + 2 < NK) { P3_ISSUE((kc) + 2, st2); }                                                \
+        if ((kc) + DIST < NK) { P3_ISSUE((kc) + DIST, ((st) + DIST) % NST); }                          \
         P3_COMPUTE(st);                                                                                \
-        if ((kc) + 2 < NK) { P3_WAIT(ISSUE); } else { P3_WAIT(0); }                                    \
+        vm_wait_groups<ISSUE, DIST - 1>(NK - 2 - (kc));                                                \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                             \
         __builtin_amdgcn_s_barrier();                                                                  \
     }
 
-    P3_ISSUE(0, 0);
-    P3_ISSUE(1, 1);
-    P3_WAIT(ISSUE);  // chunk 0 landed (chunk 1 may still be in flight)
+#pragma unroll
+    for (int c0 = 0; c0 < DIST; ++c0) { P3_ISSUE(c0, c0); }
+    vm_wait<(DIST - 1) * ISSUE>();  // chunk 0 landed (the younger ones may still be in flight)
     __builtin_amdgcn_s_barrier();
-    for (int kc = 0; kc < NK; kc += 3) {
-        P3_STEP(kc, 0, 2);
-        P3_STEP(kc + 1, 1, 0);
-        P3_STEP(kc + 2, 2, 1);
+    for (int kc = 0; kc < NK; kc += NST) {
+#pragma unroll
+        for (int st = 0; st < NST; ++st) { P3_STEP(kc + st, st); }
     }
 #undef P3_DMA
 #undef P3_ISSUE
 #undef P3_COMPUTE
-#undef P3_WAIT
 #undef P3_STEP
 
     // epilogue: bias + leaky-ReLU, one buffer_store per value: SGPR resource + uniform column offset (soffset) + one
@@ -192,12 +209,12 @@ __global__ __launch_bounds__(64 * WM) void k_fc1_p3(const float* __restrict__ fe
     }
 }
 
-template <int MS, int NS, int WM, int NSUB, bool GROUP = false>
+template <int MS, int NS, int WM, int NSUB, bool GROUP = false, int NST = 3>
 static void launch_fc1_p3(const float* feat, const float* wimg, const float* bias, float* out, int M, hipStream_t s) {
     constexpr int BM = 16 * MS * WM, NSPLIT = kNVec / (16 * NS);
     const int mtiles = (M + BM - 1) / BM;
     const int blocks = GROUP ? ((mtiles + 7) / 8) * 8 * NSPLIT : mtiles * NSPLIT;
-    hipLaunchKernelGGL((k_fc1_p3<MS, NS, WM, NSUB, GROUP>), dim3(blocks), dim3(64 * WM), 0, s, feat, wimg, bias, out, M);
+    hipLaunchKernelGGL((k_fc1_p3<MS, NS, WM, NSUB, GROUP, NST>), dim3(blocks), dim3(64 * WM), 0, s, feat, wimg, bias, out, M);
 }
 
 static int fc1_variant() {
