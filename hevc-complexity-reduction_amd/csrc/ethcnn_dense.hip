@@ -233,8 +233,9 @@ static int fc1_variant() {
 // (few MFMAs per K chunk per wave) but need more blocks.
 static int fc1_short_variant(int n) {
     struct Shape { int variant, bm, nsplit; double a, b; };
-    static const Shape shapes[] = {{0, 128, 4, 15.0, 150.0}, {1, 64, 4, 34.0, 74.0}, {2, 64, 7, 12.0, 48.0},
-                                   {3, 64, 14, 9.0, 27.0},   {4, 64, 28, 8.0, 17.0}, {5, 64, 14, 7.0, 27.5}};
+    // a, b refitted in round 2 (gpurun_out/fc1_rows.txt after the SGPR-base addressing; r01: profiles/r01_fc1_rows.txt)
+    static const Shape shapes[] = {{0, 128, 4, 15.0, 150.0}, {1, 64, 4, 30.0, 70.0},  {2, 64, 7, 9.0, 45.0},
+                                   {3, 64, 14, 10.0, 22.5},  {4, 64, 28, 8.0, 14.4}, {5, 64, 14, 9.5, 22.6}};
     int best = 2;
     double tbest = 1e30;
     for (const Shape& sh : shapes) {
