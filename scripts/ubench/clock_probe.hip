@@ -29,6 +29,9 @@ __device__ __forceinline__ unsigned long long memrealtime() {
 //       10 / 11 / 14 / 15 = 0 / 1 / 4 / 5 with the accumulators in AGPRs (inline asm, "a" constraint): do VALU / LDS / VMEM
 //       still cost matrix-pipe time when the MFMA's C/D traffic is on the AccVGPR side of the register file?
 //       12 = AGPR accumulators AND the B operand read from an AGPR (the trunk's layer chaining without leaving the AGPRs)
+//       7 = KIND 5 with the LDS-DMA in its saddr form (`global_load_lds_dwordx4 vOff, s[base:base+1]`: SGPR base + ONE VGPR)
+//       8 = mfma16 + VPM plain global_load_dwordx4 per 16 MFMAs with a 64-bit VGPR address, 9 = the same as buffer_load (SGPR
+//           resource + one VGPR offset): what the address form of a VMEM instruction costs the matrix pipe
 template <int KIND, int VPM>
 __global__ void k(unsigned long long* stamps, const float* src, int iters, float a0) {
     __shared__ float lds[8192];
@@ -47,8 +50,27 @@ __global__ void k(unsigned long long* stamps, const float* src, int iters, float
     const unsigned la = (threadIdx.x & 63) * 4;
     const float* gp = src + (threadIdx.x & 63) * 4;
     const unsigned ldsdst = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds + 16384 + (threadIdx.x >> 6) * 1024;
+    f32x4 ld4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, 1 << 20, 0x00020000);
     const unsigned long long t0 = memtime(), r0 = memrealtime();
     for (int it = 0; it < iters; ++it) {
+        if (KIND == 7) {
+#pragma unroll
+            for (int q = 0; q < VPM; ++q) {
+                unsigned keep;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(ldsdst);
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(la * 4u), "s"(src), "s"(dst) : "memory");
+            }
+        }
+        if (KIND == 8) {
+#pragma unroll
+            for (int q = 0; q < VPM; ++q) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ld4[q & 1]) : "v"(gp) : "memory");
+        }
+        if (KIND == 9) {
+#pragma unroll
+            for (int q = 0; q < VPM; ++q) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(ld4[q & 1]) : "v"(la * 4u), "s"(rsrc) : "memory");
+        }
         if (KIND == 5 || KIND == 15) {
 #pragma unroll
             for (int q = 0; q < VPM; ++q) {
@@ -60,7 +82,7 @@ __global__ void k(unsigned long long* stamps, const float* src, int iters, float
         }
 #pragma unroll
         for (int m = 0; m < 16; ++m) {
-            if (KIND == 0 || KIND == 1 || KIND == 4 || KIND == 5) acc[m & 3] = MFMA16(a, b, acc[m & 3]);
+            if (KIND == 0 || KIND == 1 || KIND == 4 || KIND == 5 || KIND == 7 || KIND == 8 || KIND == 9) acc[m & 3] = MFMA16(a, b, acc[m & 3]);
             if (KIND == 10 || KIND == 11 || KIND == 14 || KIND == 15)
                 asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[m & 3]) : "v"(a), "v"(b));
             if (KIND == 12) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[m & 3]) : "v"(a), "a"(bacc));
@@ -75,7 +97,7 @@ __global__ void k(unsigned long long* stamps, const float* src, int iters, float
             }
         }
         if (KIND == 4 || KIND == 14) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (KIND == 5 || KIND == 15) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (KIND == 5 || KIND == 15 || KIND == 7 || KIND == 8 || KIND == 9) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     const unsigned long long t1 = memtime(), r1 = memrealtime();
     float s = 0.f;
@@ -83,6 +105,7 @@ __global__ void k(unsigned long long* stamps, const float* src, int iters, float
     for (int i = 0; i < 2; ++i)
         for (int j = 0; j < 16; ++j) s += big[i][j];
     for (int i = 0; i < 8; ++i) s += v[i];
+    s += ld4[0][0] + ld4[1][3];
     if ((threadIdx.x & 63) == 0) {
         const size_t w = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
         stamps[2 * w] = t1 - t0;
@@ -133,6 +156,10 @@ int main() {
         run<5, 1>("mfma16x16x4 + 1 LDS-DMA per 16 MFMA", w);
         run<5, 2>("mfma16x16x4 + 2 LDS-DMA per 16 MFMA", w);
         run<6, 2>("v_fma only (2 per slot)", w);
+        run<7, 1>("mfma16x16x4 + 1 LDS-DMA (saddr form) per 16", w);
+        run<7, 2>("mfma16x16x4 + 2 LDS-DMA (saddr form) per 16", w);
+        run<8, 2>("mfma16x16x4 + 2 global_load x4 (vaddr64) /16", w);
+        run<9, 2>("mfma16x16x4 + 2 buffer_load x4 (offen) /16", w);
         run<10, 0>("AGPR acc: mfma16x16x4 only", w);
         run<11, 2>("AGPR acc: mfma16x16x4 + 2 v_fma per MFMA", w);
         run<11, 4>("AGPR acc: mfma16x16x4 + 4 v_fma per MFMA", w);
