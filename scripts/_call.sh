@@ -1,3 +1,4 @@
 set -u
-mkdir -p gpurun_out
-./scripts/ubench/clock_probe > gpurun_out/clock_probe.txt 2>&1; grep -E "w3" gpurun_out/clock_probe.txt | cut -c1-120
+python -m pytest tests/test_gpu_robustness.py -x -q -m gpu 2>&1 | tail -5
+python scripts/fuzz_many.py 2>&1 | tail -3
+python scripts/soak.py 2>&1 | tail -3

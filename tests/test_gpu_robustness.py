@@ -90,3 +90,62 @@ def test_lifecycle_churn(pkg, oracle):
         c.load_blob(blobs[1 - i % 2])
         assert np.array_equal(_bits(c.predict_luma(luma, 200, 136, 1, 30)), _bits(wants[1 - i % 2]))
         c.close()
+
+
+def test_pass_pipeline_back_to_back_async_calls(pkg, oracle):
+    """The pass pipeline (tile stage of pass i+1 beside FC1 of pass i, double-buffered tile outputs / h1 / gate flags):
+    six asynchronous device calls with six DIFFERENT inputs, geometries and QPs issued back to back without a
+    synchronisation in between, then one ethcnn_synchronize: every output bit-exact vs the oracle, pipeline on and off,
+    and with a workspace so small that every call is several passes."""
+    rng = np.random.default_rng(2024)
+    blob = oracle.synth_blob(9, 8.0)
+    cases = [(832, 480, 3, 32), (1920, 1080, 2, 22), (200, 136, 5, 37), (64 * 45, 64 * 30, 2, 27), (416, 240, 7, 32), (1280, 720, 3, 30)]
+    lumas = [rng.integers(0, 256, size=(f, h, w), dtype=np.uint8) for (w, h, f, _) in cases]
+    for lu in lumas:
+        lu[:, : lu.shape[1] // 2] = (lu[:, : lu.shape[1] // 2] // 16 + 60).astype(np.uint8)
+    wants = [oracle.predict_frames(blob, lu, w, h, f, qp, 0.5, 0.5, mode=0) for lu, (w, h, f, qp) in zip(lumas, cases)]
+    for pipeline, cap in ((True, 0), (False, 0), (True, 1024), (True, 4096)):
+        c = pkg.EthCnn(device=0, max_ctus_per_pass=cap)
+        c.load_blob(blob)
+        c.set_pass_pipeline(pipeline)
+        d_in = [c.alloc(lu.nbytes) for lu in lumas]
+        d_out = [c.alloc(wt.nbytes) for wt in wants]
+        for b, lu in zip(d_in, lumas):
+            b.upload(lu)
+        for _ in range(2):  # twice: the second round starts with buffers of the first still "two passes back"
+            for b_in, b_out, (w, h, f, qp) in zip(d_in, d_out, cases):
+                c.predict_luma_device(b_in, w, h, f, qp, b_out)  # no synchronisation between the calls
+        c.synchronize()
+        for k, (b_out, wt) in enumerate(zip(d_out, wants)):
+            got = b_out.download(np.float32, wt.size).reshape(wt.shape)
+            assert np.array_equal(got.view(np.uint32), wt.view(np.uint32)), "pipeline=%s cap=%d case %d" % (pipeline, cap, k)
+        for b in d_in + d_out:
+            b.free()
+        c.close()
+
+
+def test_ldp_calls_between_pipelined_passes(pkg, oracle):
+    """main-stream users of the workspace (LDP front-end) between pipelined All-Intra calls: the serial sections wait for
+    the side stream and the next tile stage waits for them"""
+    rng = np.random.default_rng(5)
+    blob = oracle.synth_blob(3, 1.0)
+    c = pkg.EthCnn(device=0)
+    c.load_blob(blob)
+    w, h = 1280, 720
+    luma = rng.integers(0, 256, size=(4, h, w), dtype=np.uint8)
+    resi = np.clip(np.rint(128 + rng.laplace(0, 6, size=(h, w))), 0, 255).astype(np.uint8)
+    want_ai = oracle.predict_frames(blob, luma, w, h, 4, 32, 0.5, 0.5, mode=0)
+    want_vec = oracle.resi_vectors(blob, resi, w, h, mode=0)
+    d_in, d_out = c.alloc(luma.nbytes), c.alloc(want_ai.nbytes)
+    d_in.upload(luma)
+    for _ in range(3):
+        c.predict_luma_device(d_in, w, h, 4, 32, d_out)
+        vec = c.resi_vectors(resi, w, h)                    # serial section right behind an unsynchronised pipelined pass
+        c.predict_luma_device(d_in, w, h, 4, 32, d_out)     # and a pipelined pass right behind it
+        assert np.array_equal(vec.view(np.uint32), want_vec.view(np.uint32))
+    c.synchronize()
+    got = d_out.download(np.float32, want_ai.size).reshape(want_ai.shape)
+    assert np.array_equal(got.view(np.uint32), want_ai.view(np.uint32))
+    d_in.free()
+    d_out.free()
+    c.close()
