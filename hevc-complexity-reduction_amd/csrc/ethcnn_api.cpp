@@ -156,21 +156,20 @@ struct ethcnn_ctx {
     int state_nctu = 0;
 
     Workspace ws;
-    // Cross-pass software pipeline ("pass pipeline"): the tile stage of pass i+1 (HBM-bound, no MFMA) and
-    // the heads + gate stages of pass i (latency-bound, little MFMA) run on side streams beside the MFMA-bound trunk / FC1 of
-    // the neighbouring passes.  What two passes in flight would share is double-buffered by pass parity: the tile outputs
-    // (xs/xm/xl), h1 and the gate flags.  feat is produced and consumed on the main stream only.
+    // Cross-pass software pipeline ("pass pipeline"): the tile stage of pass i+1 (HBM-bound, no MFMA) runs
+    // on a side stream beside the MFMA-bound FC1 of pass i.  What two passes in flight would share is double-buffered by pass
+    // parity: the tile outputs (xs/xm/xl), h1 and the gate flags.  feat is produced and consumed on the main stream only.
+    // (Heads + gate on a third stream were measured too: never co-resident with anything, profiles/r02_overlap_trace.txt.)
     uint4 *xs1 = nullptr, *xm1 = nullptr, *xl1 = nullptr;
     float* h1_1 = nullptr;
     int* flags1 = nullptr;
-    hipStream_t s_tile = nullptr, s_heads = nullptr;
-    hipEvent_t e_tile[2] = {}, e_trunk[2] = {}, e_fc1[2] = {}, e_heads[2] = {}, e_main = nullptr;
+    hipStream_t s_tile = nullptr;
+    hipEvent_t e_tile[2] = {}, e_trunk[2] = {}, e_heads[2] = {}, e_main = nullptr;
     int tile_blocks = 256;   // blocks of the side-stream tile stage: one per CU (ETHCNN_TILE_BLOCKS)
     unsigned pass_idx = 0;   // parity selects the buffer set
     int last_parity = 0;     // of the last pass (debug_fetch reads its h1)
-    int overlap = 1;         // ETHCNN_OVERLAP bits: 1 = tile stage on its own stream (under FC1 of the previous pass),
-                             // 2 = heads + gate on their own stream, 4 = (with 1) the tile stage may also start under the
-                             // previous pass's trunk; 0 = everything on the main stream (r01 behaviour)
+    int overlap = 1;         // 1 = pass pipeline on (tile stage on its own stream, beside FC1 of the previous pass);
+                             // 0 = every stage on the main stream (ethcnn_set_pass_pipeline, env ETHCNN_OVERLAP=0)
     int max_ctus = 131072;
     int last_n = 0;  // CTUs of the last pass (debug_fetch)
     bool debug_capture = false;  // also store FC2 outputs, logits and ungated probabilities (1.7 KB/CTU of writes)
@@ -297,21 +296,19 @@ extern "C" int ethcnn_create(ethcnn_ctx** out, const ethcnn_options* opt) {
     if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->copy_in, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->copy_out, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->s_tile, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->s_heads, hipStreamNonBlocking) != hipSuccess) {
+        hipStreamCreateWithFlags(&c->s_tile, hipStreamNonBlocking) != hipSuccess) {
         ethcnn_destroy(c);  // releases whichever streams were created
         return set_err(nullptr, ETHCNN_ERR_DEVICE, "cannot create HIP streams on device %d", dev);
     }
     {
-        hipEvent_t* evs[] = {&c->e_tile[0], &c->e_tile[1], &c->e_trunk[0], &c->e_trunk[1], &c->e_fc1[0], &c->e_fc1[1],
-                             &c->e_heads[0], &c->e_heads[1], &c->e_main};
+        hipEvent_t* evs[] = {&c->e_tile[0], &c->e_tile[1], &c->e_trunk[0], &c->e_trunk[1], &c->e_heads[0], &c->e_heads[1], &c->e_main};
         for (hipEvent_t* e : evs)
             if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) {
                 ethcnn_destroy(c);
                 return set_err(nullptr, ETHCNN_ERR_DEVICE, "cannot create HIP events on device %d", dev);
             }
     }
-    if (const char* e = std::getenv("ETHCNN_OVERLAP")) c->overlap = std::atoi(e) & 7;  // development knob (A/B runs)
+    if (const char* e = std::getenv("ETHCNN_OVERLAP")) c->overlap = std::atoi(e) != 0;  // development knob (A/B runs)
     c->tile_blocks = prop.multiProcessorCount;
     {   // the GPU's NUMA node -> its CPU list (/sys/devices/system/node/nodeN/cpulist: "64-127,192-255"); ETHCNN_NUMA_BIND=0 opts out
         int node = -1;
@@ -391,12 +388,11 @@ extern "C" void ethcnn_destroy(ethcnn_ctx* c) {
             if (p) (void)hipFree(p);
     }
     {
-        hipEvent_t evs[] = {c->e_tile[0], c->e_tile[1], c->e_trunk[0], c->e_trunk[1], c->e_fc1[0], c->e_fc1[1],
-                            c->e_heads[0], c->e_heads[1], c->e_main};
+        hipEvent_t evs[] = {c->e_tile[0], c->e_tile[1], c->e_trunk[0], c->e_trunk[1], c->e_heads[0], c->e_heads[1], c->e_main};
         for (hipEvent_t e : evs)
             if (e) (void)hipEventDestroy(e);
     }
-    hipStream_t streams[] = {c->stream, c->copy_in, c->copy_out, c->s_tile, c->s_heads};
+    hipStream_t streams[] = {c->stream, c->copy_in, c->copy_out, c->s_tile};
     for (hipStream_t st : streams)
         if (st) (void)hipStreamDestroy(st);
     delete c;
@@ -618,22 +614,16 @@ static int make_geom(ethcnn_ctx* c, int w, int h, ptrdiff_t pitch, ptrdiff_t fst
     return 0;
 }
 
-// the main stream waits for everything the side streams still have in flight (heads + gate of the last two passes; a
-// tile stage is always followed by its trunk on the main stream)
-static int join_side(ethcnn_ctx* c) {
-    HIPCHK(c, hipStreamWaitEvent(c->stream, c->e_heads[0], 0));  // a never-recorded event is a no-op
-    HIPCHK(c, hipStreamWaitEvent(c->stream, c->e_heads[1], 0));
-    return 0;
-}
-// main-stream users of the workspace outside run_pass (LDP front-end, LSTM step) bracket themselves with these
-static int serial_begin(ethcnn_ctx* c) { return join_side(c); }
+// Everything a pass leaves in flight ends on the main stream (its tile stage is always followed by its own trunk there), so
+// "after all passes enqueued so far" is simply main-stream order.  Main-stream users of the workspace outside run_pass (LDP
+// front-end, LSTM step) only have to tell the NEXT pipelined tile stage, which runs on the side stream, to wait for them:
 static int serial_end(ethcnn_ctx* c) {
     HIPCHK(c, hipEventRecord(c->e_main, c->stream));  // the next pipelined tile stage waits for it
     return 0;
 }
 
 // one pass over CTUs [ctu0, ctu0+n) of the sequence; ctu0 is sub-batch aligned.  input_ready: event after which d_luma
-// may be read (nullptr: the caller ordered it before the call).  Asynchronous; with c->overlap the pass ends on s_heads.
+// may be read (nullptr: the caller ordered it before the call).  Asynchronous; the pass ends on the main stream.
 static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, int qp,
                     float* d_probs_pass, hipEvent_t input_ready = nullptr) {
     const int cpf = chunks_per_frame(g.nctu);
@@ -644,17 +634,17 @@ static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, lo
     const float qn = (float)qp * (1.0f / 51.0f);  // net_CNN.py:106
     const int p = c->overlap ? (int)(c->pass_idx++ & 1) : 0;
     const Workspace w = ws_view(c, p);
-    const bool side_tile = (c->overlap & 1) != 0, side_heads = (c->overlap & 2) != 0;
-    hipStream_t s_tile = side_tile ? c->s_tile : c->stream, s_heads = side_heads ? c->s_heads : c->stream;
+    const bool side_tile = c->overlap != 0;
+    hipStream_t s_tile = side_tile ? c->s_tile : c->stream;
     if (input_ready) HIPCHK(c, hipStreamWaitEvent(s_tile, input_ready, 0));
     if (side_tile) {
         // tile(i) overwrites the tile outputs and gate flags of buffer set p: last read by trunk(i-2) / gate(i-2)
-        HIPCHK(c, hipStreamWaitEvent(s_tile, c->e_trunk[p], 0));
+        HIPCHK(c, hipStreamWaitEvent(s_tile, c->e_trunk[p], 0));  // a never-recorded event is a no-op
         HIPCHK(c, hipStreamWaitEvent(s_tile, c->e_heads[p], 0));
-        HIPCHK(c, hipStreamWaitEvent(s_tile, c->e_main, 0));
+        HIPCHK(c, hipStreamWaitEvent(s_tile, c->e_main, 0));      // main-stream users of the workspace outside run_pass (LDP)
         // ... and it should run beside FC1(i-1), not beside trunk(i-1): with the trunk it competes for VALU issue and HBM
         // (measured: trunk 556 -> 819 us, tile 180 -> 511 us, step period 2.60 -> 2.73 ms; profiles/r02_overlap_trace.txt)
-        if (!(c->overlap & 4)) HIPCHK(c, hipStreamWaitEvent(s_tile, c->e_trunk[p ^ 1], 0));
+        HIPCHK(c, hipStreamWaitEvent(s_tile, c->e_trunk[p ^ 1], 0));
     }
     (void)hipGetLastError();  // launch errors below are reported per stage; drop anything stale first
 #define LAUNCH_OK(name)                                                                                            \
@@ -671,20 +661,15 @@ static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, lo
     { StageTimer t(c, ETHCNN_STAGE_TRUNK); launch_trunk(w, c->dw, n, false, c->stream); }
     LAUNCH_OK("trunk");
     if (side_tile) HIPCHK(c, hipEventRecord(c->e_trunk[p], c->stream));
-    if (side_heads) HIPCHK(c, hipStreamWaitEvent(c->stream, c->e_heads[p], 0));  // FC1(i) overwrites h1 of set p: last read by heads(i-2)
     { StageTimer t(c, ETHCNN_STAGE_FC1, n); launch_fc1(w, c->dw, n, w.h1, c->stream); }
     LAUNCH_OK("FC1");
-    if (side_heads) {
-        HIPCHK(c, hipEventRecord(c->e_fc1[p], c->stream));
-        HIPCHK(c, hipStreamWaitEvent(s_heads, c->e_fc1[p], 0));
-    }
     Workspace wv = w;
     if (!c->debug_capture) wv.h2 = wv.logits = wv.raw = nullptr;
-    { StageTimer t(c, ETHCNN_STAGE_HEADS, 0, s_heads); launch_heads(wv, c->dw, n, qn, g.nctu, ctu0, c->thr1, c->thr2, d_probs_pass, s_heads); }
-    { StageTimer t(c, ETHCNN_STAGE_GATE, 0, s_heads); launch_gate(w, n, g.nctu, ctu0, c->thr2, d_probs_pass, s_heads); }
+    { StageTimer t(c, ETHCNN_STAGE_HEADS); launch_heads(wv, c->dw, n, qn, g.nctu, ctu0, c->thr1, c->thr2, d_probs_pass, c->stream); }
+    { StageTimer t(c, ETHCNN_STAGE_GATE); launch_gate(w, n, g.nctu, ctu0, c->thr2, d_probs_pass, c->stream); }
     LAUNCH_OK("heads / gate");
 #undef LAUNCH_OK
-    if (c->overlap) HIPCHK(c, hipEventRecord(c->e_heads[p], s_heads));  // gate(i) done: flags / h1 of set p are free again
+    if (side_tile) HIPCHK(c, hipEventRecord(c->e_heads[p], c->stream));  // gate(i) done: the flags of set p are free again
     c->times.ctus += n;
     c->last_n = n;
     c->last_parity = p;
@@ -833,7 +818,7 @@ static int host_pipeline(ethcnn_ctx* c, int w, int h, int nframes, int qp, Fill 
                 r = run_pass(c, c->d_in[b], g, p.ctu0, p.n, qp, c->d_out[b] + (size_t)p.ctu0 * kNOut, c->ev_in[b]);
                 if (r) return r;
             }
-            HIPCHK(c, hipEventRecord(c->ev_comp[b], (c->overlap & 2) ? c->s_heads : c->stream));  // where the group's last pass ends
+            HIPCHK(c, hipEventRecord(c->ev_comp[b], c->stream));
             HIPCHK(c, hipStreamWaitEvent(c->copy_out, c->ev_comp[b], 0));
             HIPCHK(c, hipMemcpyAsync(c->h_out[b], c->d_out[b], (size_t)G.nf * g.nctu * kNOut * 4, hipMemcpyDeviceToHost, c->copy_out));
             HIPCHK(c, hipEventRecord(c->ev_out[b], c->copy_out));
@@ -850,7 +835,6 @@ static int host_pipeline(ethcnn_ctx* c, int w, int h, int nframes, int qp, Fill 
     (void)hipStreamSynchronize(c->copy_in);  // on an error path nothing may still be reading / writing the ring
     (void)hipStreamSynchronize(c->s_tile);
     (void)hipStreamSynchronize(c->stream);
-    (void)hipStreamSynchronize(c->s_heads);
     (void)hipStreamSynchronize(c->copy_out);
     return result;
 }
@@ -961,8 +945,6 @@ extern "C" int ethcnn_resi_vectors_device(ethcnn_ctx* c, const uint8_t* d_luma, 
     int rc = make_geom(c, w, h, pitch, (ptrdiff_t)pitch * h, &g);
     if (rc) return rc;
     HIPCHK(c, hipSetDevice(c->device));
-    rc = serial_begin(c);
-    if (rc) return rc;
     for (int o = 0; o < g.nctu; o += c->max_ctus) {
         const int n = std::min(c->max_ctus, g.nctu - o);
         rc = ensure_workspace(c, n, 1);
@@ -1065,8 +1047,6 @@ extern "C" int ethcnn_lstm_step_device(ethcnn_ctx* c, const float* d_vec, const 
     int rc = ensure_workspace(c, std::min(n, c->max_ctus), chunks);
     if (rc) return rc;
     if (n > c->ws.cap) return set_err(c, ETHCNN_ERR_ARG, "frame of %d CTUs exceeds max_ctus_per_pass", n);
-    rc = serial_begin(c);
-    if (rc) return rc;
     HIPCHK(c, hipMemsetAsync(c->ws.flags, 0, (size_t)chunks * 2 * sizeof(int), c->stream));
     {
         StageTimer t(c, ETHCNN_STAGE_HEADS);
@@ -1174,14 +1154,12 @@ extern "C" int ethcnn_host_free(ethcnn_ctx* c, void* p) {
 }
 extern "C" int ethcnn_memcpy_h2d(ethcnn_ctx* c, void* dst, const void* src, size_t bytes) {
     if (!c || !dst || !src) return ETHCNN_ERR_ARG;
-    if (int rc = join_side(c)) return rc;  // "after everything enqueued so far", side streams included
     HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return ETHCNN_OK;
 }
 extern "C" int ethcnn_memcpy_d2h(ethcnn_ctx* c, void* dst, const void* src, size_t bytes) {
     if (!c || !dst || !src) return ETHCNN_ERR_ARG;
-    if (int rc = join_side(c)) return rc;
     HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return ETHCNN_OK;
@@ -1189,7 +1167,6 @@ extern "C" int ethcnn_memcpy_d2h(ethcnn_ctx* c, void* dst, const void* src, size
 extern "C" int ethcnn_synchronize(ethcnn_ctx* c) {
     if (!c) return ETHCNN_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    if (int rc = join_side(c)) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return ETHCNN_OK;
 }

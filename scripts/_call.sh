@@ -1,4 +1,8 @@
 set -u
-bash scripts/gpu_round.sh
-WL=c2 SKIP_TESTS=1 bash -c 'cd /tmp; export TMPDIR=/tmp; rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/prof_c2 -o c2 -- python /root/repo/bench.py --workload c2 --no-cpu-baseline --no-host-scopes > /root/repo/gpurun_out/prof_c2.log 2>&1'
-head -8 gpurun_out/prof_c2/c2_kernel_stats.csv | cut -c1-160
+mkdir -p gpurun_out
+python -m pytest tests -x -q -m gpu 2>&1 | tail -2
+python bench.py --no-cpu-baseline --no-host-scopes --steps 30 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('c3', d['value'], d['roofline']['frac'])"
+ETHCNN_OVERLAP=0 python bench.py --no-cpu-baseline --no-host-scopes --steps 30 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('c3 serial', d['value'], d['roofline']['frac'])"
+python scripts/fuzz_many.py 2>&1 | tail -1
