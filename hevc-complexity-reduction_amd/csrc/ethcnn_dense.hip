@@ -57,9 +57,17 @@ __device__ __forceinline__ void vm_wait_groups(int keep) {
 // NST = LDS stages (prefetch distance NST - 1).  3 everywhere: deeper rings (4..6 stages, distance up to 5) were measured on
 // the short-range shapes, which run one block per CU or less, and change nothing (profiles/r02_fc1_variants.txt section 5):
 // those launches are bound by the per-chunk barrier + ds_read -> MFMA latency of a lone wave per SIMD, not by DMA latency.
-template <int MS, int NS, int WM, int NSUB, bool GROUP, int NST = 3>
-__global__ __launch_bounds__(64 * WM) void k_fc1_p3(const float* __restrict__ feat, const float* __restrict__ Wimg,
-                                                    const float* __restrict__ bias, float* __restrict__ out, int M) {
+template <int MS, int NS, int WM, int NSUB, int NST>
+struct Fc1Shape {
+    static constexpr int B_FLOATS = 16 * NSUB * 16 * NS;
+    static constexpr int STAGE = B_FLOATS + WM * NSUB * MS * 256;
+    static constexpr int LDS_FLOATS = NST * STAGE;
+};
+
+// one output tile (block `bid` of a grid of this shape over M rows); smem: >= Fc1Shape<...>::LDS_FLOATS floats
+template <int MS, int NS, int WM, int NSUB, bool GROUP, int NST>
+__device__ __forceinline__ void fc1_tile(float* __restrict__ smem, const float* __restrict__ feat, const float* __restrict__ Wimg,
+                                         const float* __restrict__ bias, float* __restrict__ out, int M, const unsigned bid) {
     constexpr int BK = 16 * NSUB, BN = 16 * NS, NSPLIT = kNVec / BN, BM = 16 * MS * WM;
     constexpr int NK = kNFeat / BK;
     constexpr int B_FLOATS = BK * BN;
@@ -73,7 +81,7 @@ __global__ __launch_bounds__(64 * WM) void k_fc1_p3(const float* __restrict__ fe
     constexpr int DIST = NST - 1;
     static_assert(NK % NST == 0 && NK >= NST, "K chunks must come in whole rounds of the stage ring");
     static_assert(DIST * ISSUE <= 63, "vmcnt is a 6-bit counter");
-    __shared__ __attribute__((aligned(16))) float smem[NST * STAGE];  // the ONLY LDS object
+    static_assert(STAGE == Fc1Shape<MS, NS, WM, NSUB, NST>::STAGE, "LDS budget of the shape");
 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int col = lane & 15, g = lane >> 4;
@@ -83,13 +91,13 @@ __global__ __launch_bounds__(64 * WM) void k_fc1_p3(const float* __restrict__ fe
     // from HBM once and are shared through that XCD's L2 (W1 is then swept whole per XCD).
     int nb, mt;
     if (GROUP) {
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int xcd = bid & 7, slot = bid >> 3;
         nb = slot % NSPLIT;
         mt = (slot / NSPLIT) * 8 + xcd;
         if (mt * BM >= M) return;  // whole block leaves before any barrier
     } else {
-        nb = (int)(blockIdx.x % NSPLIT);
-        mt = (int)(blockIdx.x / NSPLIT);
+        nb = (int)(bid % NSPLIT);
+        mt = (int)(bid / NSPLIT);
     }
     const int m0 = mt * BM + wv * 16 * MS;
     const int n0 = nb * BN;
@@ -209,6 +217,30 @@ __global__ __launch_bounds__(64 * WM) void k_fc1_p3(const float* __restrict__ fe
     }
 }
 
+template <int MS, int NS, int WM, int NSUB, bool GROUP, int NST = 3>
+__global__ __launch_bounds__(64 * WM) void k_fc1_p3(const float* __restrict__ feat, const float* __restrict__ Wimg,
+                                                    const float* __restrict__ bias, float* __restrict__ out, int M) {
+    __shared__ __attribute__((aligned(16))) float smem[Fc1Shape<MS, NS, WM, NSUB, NST>::LDS_FLOATS];  // the ONLY LDS object
+    fc1_tile<MS, NS, WM, NSUB, GROUP, NST>(smem, feat, Wimg, bias, out, M, blockIdx.x);
+}
+
+// The bulk launch of a big pass: rows [0, m_main) as 128 x 112 tiles (a whole number of blocks per CU) AND the remaining rows
+// [m_main, m_total) as 64 x 112 tiles, in ONE grid.  The remainder's blocks come FIRST (rem_blocks of them, a multiple of 8 so
+// that the XCD grouping of both parts holds), so they run beside two bulk blocks per CU from the start: their short
+// per-chunk MFMA chains, latency-bound when such a launch has the GPU to itself (107 us for 3696 rows), are absorbed at the
+// bulk rate instead (the matrix pipe just sees 4 % more MFMAs).  Same chains per accumulator: results are identical.
+template <int NS, int WM, int NSUB>
+__global__ __launch_bounds__(64 * WM) void k_fc1_bulk(const float* __restrict__ feat, const float* __restrict__ Wimg,
+                                                      const float* __restrict__ bias, float* __restrict__ out, int m_main,
+                                                      int m_total, unsigned rem_blocks) {
+    __shared__ __attribute__((aligned(16))) float smem[Fc1Shape<2, NS, WM, NSUB, 3>::LDS_FLOATS];  // the ONLY LDS object
+    if (blockIdx.x < rem_blocks)
+        fc1_tile<1, NS, WM, NSUB, true, 3>(smem, feat + (size_t)(m_main / 16) * kNFeat * 16, Wimg, bias, out + (size_t)m_main * kNVec,
+                                           m_total - m_main, blockIdx.x);
+    else
+        fc1_tile<2, NS, WM, NSUB, true, 3>(smem, feat, Wimg, bias, out, m_main, blockIdx.x - rem_blocks);
+}
+
 template <int MS, int NS, int WM, int NSUB, bool GROUP = false, int NST = 3>
 static void launch_fc1_p3(const float* feat, const float* wimg, const float* bias, float* out, int M, hipStream_t s) {
     constexpr int BM = 16 * MS * WM, NSPLIT = kNVec / (16 * NS);
@@ -287,7 +319,7 @@ void launch_fc1(const Workspace& ws, const DeviceWeights& w, int n, float* out, 
         if (n > bt * 128) launch_fc1_rows(variant - 100, ws, w, bt * 128, n - bt * 128, out, s);
         return;
     }
-    if (variant >= 0 && variant != 20) {  // A/B knob: one fixed shape (20 = the best single shape for n)
+    if (variant >= 0 && variant != 20 && variant != 30) {  // A/B knob: one fixed shape (20 = the best single shape for n)
         launch_fc1_rows(variant, ws, w, 0, n, out, s);
         return;
     }
@@ -299,6 +331,17 @@ void launch_fc1(const Workspace& ws, const DeviceWeights& w, int n, float* out, 
     // blocks per CU (a multiple of 256 blocks), the remaining rows (< 8192) with the lowest-latency shape.
     const int big_tiles = ((n / 128) * 4 / 256) * 256 / 4;
     const int row0 = big_tiles * 128;
+    // bulk + remainder in one grid -- only when the bulk part runs for several rounds of resident blocks: the remainder's
+    // blocks take a slot on some CUs for a third of the launch, and with a one-round bulk part (c2: 24,576 + 924 rows) that
+    // pushes bulk blocks into a second round (measured: c3 +1.1 %, c4 +0.4 %, c2 -5 %; profiles/r02_fc1_variants.txt section 7)
+    if (big_tiles >= 3 * 64 && n > row0 && fc1_variant() != 30) {  // 64 tiles of 128 x 4 column blocks = one round (30: A/B knob)
+        const int rem_tiles = (n - row0 + 63) / 64;
+        const unsigned rem_blocks = (unsigned)((rem_tiles + 7) / 8) * 8 * 4;   // GROUP mapping: tiles in eights, 4 column blocks
+        const unsigned main_blocks = (unsigned)((big_tiles + 7) / 8) * 8 * 4;
+        hipLaunchKernelGGL((k_fc1_bulk<7, 4, 1>), dim3(rem_blocks + main_blocks), dim3(256), 0, s, ws.feat, w.fc1_img112, w.fc1_b, out,
+                           row0, n, rem_blocks);
+        return;
+    }
     if (big_tiles > 0) launch_fc1_rows(0, ws, w, 0, row0, out, s);
     if (n > row0) launch_fc1_rows(fc1_short_variant(n - row0), ws, w, row0, n - row0, out, s);
 }
