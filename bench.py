@@ -200,7 +200,7 @@ def main():
             "config": {"workload": wl["name"], "width": W, "height": H, "frames_per_gpu": NF, "qp": QP,
                        "ctus_per_step_per_gpu": ctus_per_step, "sharding": "frame ranges, no collective",
                        "device": ctx.device_name},
-            "roofline": {"kernel": "k_fc1_p3 (FC1 [N,2688]x[2688,448], v_mfma_f32_16x16x4_f32)",
+            "roofline": {"kernel": "FC1 stage = k_fc1_bulk / k_fc1_p3 (FC1 [N,2688]x[2688,448], v_mfma_f32_16x16x4_f32)",
                          "bound": "mfma", "achieved": fc1_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": fc1_tflops / PEAK_F32_MFMA_TFLOPS, **pmc_traffic(args.workload),
                          "avg_launch_ms": fc1_ms, "launches_timed": st["timed"]["fc1"], "ctus_per_launch": ctus_per_launch,

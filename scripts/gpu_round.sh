@@ -44,7 +44,7 @@ def per_step(tag, counter):
         for r in csv.DictReader(open(f)):
             if "k_fc1" in r["Kernel_Name"] and r["Counter_Name"] == counter:
                 tot += float(r["Counter_Value"])
-                steps += 1 if "<2, 7, 4, 1" in r["Kernel_Name"] else 0
+                steps += 1 if ("k_fc1_bulk" in r["Kernel_Name"] or "<2, 7, 4, 1" in r["Kernel_Name"]) else 0
     return (tot / steps, steps) if steps else (None, 0)
 (fe, n1), (wr, n2) = per_step("FETCH_SIZE","FETCH_SIZE"), per_step("WRITE_SIZE","WRITE_SIZE")
 if fe is not None and wr is not None:
