@@ -338,7 +338,7 @@ void launch_fc1(const Workspace& ws, const DeviceWeights& w, int n, float* out, 
     // bulk + remainder in one grid -- only when the bulk part runs for several rounds of resident blocks: the remainder's
     // blocks take a slot on some CUs for a third of the launch, and with a one-round bulk part (c2: 24,576 + 924 rows) that
     // pushes bulk blocks into a second round (measured: c3 +1.1 %, c4 +0.4 %, c2 -5 %; profiles/r02_fc1_variants.txt section 7)
-    if (big_tiles >= 3 * 64 && n > row0 && fc1_variant() != 30) {  // 64 tiles of 128 x 4 column blocks = one round (30: A/B knob)
+    if (big_tiles >= 3 * 192 && n > row0 && fc1_variant() != 30) {  // 192 tiles of 128 x 4 column blocks = one round (30: A/B knob)
         const int rem_tiles = (n - row0 + 63) / 64;
         const unsigned rem_blocks = (unsigned)((rem_tiles + 7) / 8) * 8 * 4;   // GROUP mapping: tiles in eights, 4 column blocks
         const unsigned main_blocks = (unsigned)((big_tiles + 7) / 8) * 8 * 4;
