@@ -118,6 +118,7 @@ def main():
     ctus_per_step = nctu * NF
 
     ctx = pkg.EthCnn(device=local_rank)
+    numa = pin_to_gpu_numa_node(ctx.device_name)  # before any input buffer is first touched
     ctx.load_synthetic(seed=1, head_gain=8.0)
     ctx.set_thresholds(0.5, 0.5)  # shipped Thr_info.txt
     luma = synth_luma(W, H, NF, seed=0xE7C00000 + 2 + 1000 * rank)
@@ -199,7 +200,7 @@ def main():
             "data": "synthetic (seeded luma frames resident in HBM; seeded synthetic weights -- trained blobs absent from the reference)",
             "config": {"workload": wl["name"], "width": W, "height": H, "frames_per_gpu": NF, "qp": QP,
                        "ctus_per_step_per_gpu": ctus_per_step, "sharding": "frame ranges, no collective",
-                       "device": ctx.device_name},
+                       "device": ctx.device_name, "host_affinity": numa},
             "roofline": {"kernel": "FC1 stage = k_fc1_bulk / k_fc1_p3 (FC1 [N,2688]x[2688,448], v_mfma_f32_16x16x4_f32)",
                          "bound": "mfma", "achieved": fc1_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": fc1_tflops / PEAK_F32_MFMA_TFLOPS, **pmc_traffic(args.workload),
@@ -247,6 +248,28 @@ def main():
         barrier()
         dist.destroy_process_group()
     return 0
+
+
+def pin_to_gpu_numa_node(device_name):
+    """Run this process on the CPUs of the GPU's host NUMA node (the library reports it in its device string), as one
+    would deploy it: on the two-socket boxes the host scopes (S2 / S3) lose a third of their rate when the caller's luma or
+    the page cache of the YUV file sits on the other socket.  The HBM-resident `value` does not depend on it."""
+    import re
+    m = re.search(r"host NUMA node (\d+)", device_name or "")
+    if not m or not hasattr(os, "sched_setaffinity"):
+        return "not pinned"
+    try:
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%s/cpulist" % m.group(1)).read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+            return "NUMA node %s (%d CPUs)" % (m.group(1), len(cpus))
+    except Exception:
+        pass
+    return "not pinned"
 
 
 def first_frame_parity(ctx, d_out, luma, W, H, QP, nctu):
