@@ -188,6 +188,7 @@ struct ethcnn_ctx {
     float* d_out[kStageBufs] = {};
     hipEvent_t ev_in[kStageBufs] = {}, ev_comp[kStageBufs] = {}, ev_out[kStageBufs] = {};  // created with the ring, destroyed with it
     size_t in_cap = 0, out_cap = 0;
+    std::vector<std::pair<const char*, size_t>> pinned;  // ethcnn_host_alloc'ed ranges: device-addressable as they are
     HostPool* pool = nullptr;  // created on first use by the host / file entry points
     NumaCpus numa;             // the GPU's host NUMA node (staging buffers + fill threads are placed there)
 };
@@ -380,6 +381,7 @@ extern "C" void ethcnn_destroy(ethcnn_ctx* c) {
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     free_workspace(c);
     free_staging(c);
+    for (const auto& r : c->pinned) (void)hipHostFree(const_cast<char*>(r.first));  // ethcnn_host_alloc buffers die with the context
     delete c->pool;
     if (c->dw_arena) (void)hipFree(c->dw_arena);
     {
@@ -1063,6 +1065,14 @@ extern "C" int ethcnn_lstm_step_device(ethcnn_ctx* c, const float* d_vec, const 
     return serial_end(c);
 }
 
+// [p, p + bytes) inside a buffer from ethcnn_host_alloc: page-locked and mapped at the same address on the device (unified
+// addressing), so kernels can read / write it in place -- one PCIe crossing, no staging copy, no copy launch
+static bool in_pinned(const ethcnn_ctx* c, const void* p, size_t bytes) {
+    for (const auto& r : c->pinned)
+        if ((const char*)p >= r.first && (const char*)p + bytes <= r.first + r.second) return true;
+    return false;
+}
+
 // predict_cu_depth() of resi_to_cu_depth_LDP.py:108-129 for one frame; the new state stays in HBM.
 // state source: host `state_in` when given, else zeros (resident == false) or the previous step's state in HBM
 static int ldp_step_impl(ethcnn_ctx* c, const uint8_t* luma, int w, int h, ptrdiff_t pitch, int qp, int i_frame,
@@ -1090,12 +1100,19 @@ static int ldp_step_impl(ethcnn_ctx* c, const uint8_t* luma, int w, int h, ptrdi
         in = c->state_cur;
     }
     const int out = (in == 0) ? 1 : 0;
-    HIPCHK(c, hipMemcpyAsync(c->d_in[0], luma, lbytes, hipMemcpyHostToDevice, c->stream));
-    rc = ethcnn_resi_vectors_device(c, c->d_in[0], w, h, pitch, c->d_vec);
+    // Latency path (one frame, lock-step with the encoder): buffers from ethcnn_host_alloc are used IN PLACE -- the tile stage
+    // reads the luma over PCIe while it runs, the heads / gate stages write the 84 B per CTU straight into the caller's
+    // memory -- instead of two copy launches around the kernels
+    const uint8_t* d_luma = c->d_in[0];
+    if (in_pinned(c, luma, lbytes)) d_luma = luma;
+    else HIPCHK(c, hipMemcpyAsync(c->d_in[0], luma, lbytes, hipMemcpyHostToDevice, c->stream));
+    const size_t pbytes = (size_t)nctu * kNOut * 4;
+    float* d_probs = in_pinned(c, probs, pbytes) ? probs : c->d_lprobs;
+    rc = ethcnn_resi_vectors_device(c, d_luma, w, h, pitch, c->d_vec);
     if (rc) return rc;
-    rc = ethcnn_lstm_step_device(c, c->d_vec, in >= 0 ? c->d_state[in] : nullptr, nctu, qp, i_frame, c->d_state[out], c->d_lprobs);
+    rc = ethcnn_lstm_step_device(c, c->d_vec, in >= 0 ? c->d_state[in] : nullptr, nctu, qp, i_frame, c->d_state[out], d_probs);
     if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(probs, c->d_lprobs, (size_t)nctu * kNOut * 4, hipMemcpyDeviceToHost, c->stream));
+    if (d_probs != probs) HIPCHK(c, hipMemcpyAsync(probs, c->d_lprobs, pbytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->state_cur = out;
     c->state_nctu = nctu;
@@ -1145,11 +1162,17 @@ extern "C" int ethcnn_host_alloc(ethcnn_ctx* c, size_t bytes, void** out) {
     HIPCHK(c, hipSetDevice(c->device));
     AffinityScope on_gpu_node(c->numa);
     HIPCHK(c, hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    c->pinned.emplace_back((const char*)*out, bytes ? bytes : 1);
     return ETHCNN_OK;
 }
 extern "C" int ethcnn_host_free(ethcnn_ctx* c, void* p) {
     if (!c) return ETHCNN_ERR_ARG;
-    if (p) HIPCHK(c, hipHostFree(p));
+    if (p) {
+        HIPCHK(c, hipDeviceSynchronize());  // a kernel may still be reading / writing it directly
+        for (size_t i = 0; i < c->pinned.size(); ++i)
+            if (c->pinned[i].first == (const char*)p) { c->pinned.erase(c->pinned.begin() + (long)i); break; }
+        HIPCHK(c, hipHostFree(p));
+    }
     return ETHCNN_OK;
 }
 extern "C" int ethcnn_memcpy_h2d(ethcnn_ctx* c, void* dst, const void* src, size_t bytes) {

@@ -143,7 +143,9 @@ int ethcnn_ldp_step(ethcnn_ctx* ctx, const uint8_t* luma, int width, int height,
                     const float* state_in /* may be NULL */, float* probs);
 int ethcnn_ldp_get_state(ethcnn_ctx* ctx, float* state_out, size_t nfloats /* nctu * 896 */);
 /* Pinned (page-locked) host memory: buffers a caller fills itself (file reads) and hands to the host entry points are
- * DMA-able directly, without the runtime's pageable staging copy. */
+ * DMA-able directly, without the runtime's pageable staging copy.  ethcnn_ldp_step goes further: a luma / probs pointer that
+ * lies inside such a buffer is read / written by the kernels IN PLACE (no copy launch at all).  Buffers still allocated when
+ * the context is destroyed are freed with it. */
 int ethcnn_host_alloc(ethcnn_ctx* ctx, size_t bytes, void** out);
 int ethcnn_host_free(ethcnn_ctx* ctx, void* p);
 

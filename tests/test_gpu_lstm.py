@@ -200,6 +200,18 @@ def test_ldp_step_keeps_the_state_resident(pkg, oracle, lstm):
         assert np.array_equal(_bits(pa), _bits(pb))
         with pytest.raises(e.EthCnnError):  # geometry changed: the resident state belongs to another frame size
             a.ldp_step(np.zeros((240, 416), np.uint8), 416, 240, 32, 7)
+        # buffers from ethcnn_host_alloc are used in place by the kernels (no copy launches): same bits
+        pin = a.host_buffer(w * h)
+        pprobs = a.host_buffer(pa.nbytes).view(np.float32).reshape(pa.shape)
+        st = None
+        for i_frame in (1, 2, 3):
+            luma = rng.integers(0, 256, size=(h, w), dtype=np.uint8)
+            pin[:] = luma.reshape(-1)
+            got = a.ldp_step(pin.reshape(h, w), w, h, 32, i_frame, probs_out=pprobs)
+            pb, st = b.ldp_predict_frame(luma, w, h, 32, i_frame, st)
+            assert got.ctypes.data == pprobs.ctypes.data  # written straight into the pinned buffer
+            assert np.array_equal(_bits(got), _bits(pb)), i_frame
+        a.free_host_buffers()
         # i_frame <= 1 restarts from zeros
         pa = a.ldp_step(luma, w, h, 32, 1)
         pb, _ = b.ldp_predict_frame(luma, w, h, 32, 1, None)
