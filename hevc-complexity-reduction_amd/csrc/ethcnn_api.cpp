@@ -128,6 +128,7 @@ private:
 // 57 (scripts/ubench/host_copy.cpp, profiles/r02_host_copy.txt).  Four buffers let fill, H2D and kernels of three
 // different groups run at the same time.
 constexpr int kStageBufs = 4;
+constexpr int kPipelineMinCtus = 8192;  // passes below this run all their stages on the main stream (run_pass)
 
 struct ethcnn_ctx {
     int device = 0;
@@ -634,9 +635,11 @@ static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, lo
     int rc = ensure_workspace(c, n, (int)nchunks);
     if (rc) return rc;
     const float qn = (float)qp * (1.0f / 51.0f);  // net_CNN.py:106
-    const int p = c->overlap ? (int)(c->pass_idx++ & 1) : 0;
+    // Small passes (a frame or a few: the in-process encoder hook, the LDP-sized calls) stay on one stream: there is no FC1 of
+    // a previous pass long enough to hide anything under, and the cross-stream event costs ~10 us of a 75 us call
+    const bool side_tile = c->overlap != 0 && n >= kPipelineMinCtus;
+    const int p = side_tile ? (int)(c->pass_idx++ & 1) : 0;
     const Workspace w = ws_view(c, p);
-    const bool side_tile = c->overlap != 0;
     hipStream_t s_tile = side_tile ? c->s_tile : c->stream;
     if (input_ready) HIPCHK(c, hipStreamWaitEvent(s_tile, input_ready, 0));
     if (side_tile) {
@@ -672,6 +675,7 @@ static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, lo
     LAUNCH_OK("heads / gate");
 #undef LAUNCH_OK
     if (side_tile) HIPCHK(c, hipEventRecord(c->e_heads[p], c->stream));  // gate(i) done: the flags of set p are free again
+    else if (c->overlap) HIPCHK(c, hipEventRecord(c->e_main, c->stream));  // a later pipelined tile stage must wait for this pass
     c->times.ctus += n;
     c->last_n = n;
     c->last_parity = p;

@@ -94,12 +94,15 @@ def test_lifecycle_churn(pkg, oracle):
 
 def test_pass_pipeline_back_to_back_async_calls(pkg, oracle):
     """The pass pipeline (tile stage of pass i+1 beside FC1 of pass i, double-buffered tile outputs / h1 / gate flags):
-    six asynchronous device calls with six DIFFERENT inputs, geometries and QPs issued back to back without a
+    eight asynchronous device calls with eight DIFFERENT inputs, geometries and QPs issued back to back without a
     synchronisation in between, then one ethcnn_synchronize: every output bit-exact vs the oracle, pipeline on and off,
     and with a workspace so small that every call is several passes."""
     rng = np.random.default_rng(2024)
     blob = oracle.synth_blob(9, 8.0)
-    cases = [(832, 480, 3, 32), (1920, 1080, 2, 22), (200, 136, 5, 37), (64 * 45, 64 * 30, 2, 27), (416, 240, 7, 32), (1280, 720, 3, 30)]
+    # passes of >= 8192 CTUs take the pipelined path (tile stage on the side stream), smaller ones stay on the main stream:
+    # both kinds, interleaved
+    cases = [(832, 480, 3, 32), (1920, 1080, 20, 22), (200, 136, 5, 37), (3840, 2160, 5, 27), (64 * 45, 64 * 30, 2, 27),
+             (1920, 1080, 17, 32), (416, 240, 7, 32), (1280, 720, 3, 30)]
     lumas = [rng.integers(0, 256, size=(f, h, w), dtype=np.uint8) for (w, h, f, _) in cases]
     for lu in lumas:
         lu[:, : lu.shape[1] // 2] = (lu[:, : lu.shape[1] // 2] // 16 + 60).astype(np.uint8)
