@@ -42,6 +42,24 @@ __device__ __forceinline__ float expf_canonical_h(float x) {
     return __int_as_float(__float_as_int(p) + (((int)n) << 23));
 }
 
+#ifdef HEADS_STAMPS
+// development probe (scripts/ubench/heads_probe.hip): stamps of wave 0 of every block -- s_memtime (shader clock, per
+// XCC) at the phase boundaries, s_memrealtime (100 MHz, device-wide) at entry and exit
+__device__ unsigned long long g_heads_stamps[1 << 16][8];
+__device__ __forceinline__ void heads_stamp(int slot) {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    if (threadIdx.x == 0) g_heads_stamps[(blockIdx.y * gridDim.x + blockIdx.x) & 0xffff][slot] = t;
+    if (slot == 0 || slot == 4) {
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        if (threadIdx.x == 0) g_heads_stamps[(blockIdx.y * gridDim.x + blockIdx.x) & 0xffff][slot == 0 ? 6 : 7] = t;
+    }
+}
+#define HEADS_STAMP(i) heads_stamp(i)
+#else
+#define HEADS_STAMP(i)
+#endif
+
 struct HeadsParams {
     const float* w2[3];
     const float* b2[3];
@@ -134,9 +152,11 @@ __device__ __forceinline__ void head_pass(float* smem, const float* __restrict__
     for (int j = 0; j < D::NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     __builtin_amdgcn_s_barrier();  // the previous head's last stage has been consumed by every wave
+    HEADS_STAMP(1);
     HP_ISSUE(0, 0);
     HP_WAIT(0);
     __builtin_amdgcn_s_barrier();
+    HEADS_STAMP(2);
     int st = 0;
 #pragma unroll 1
     for (int kc = 0; kc < D::NK; ++kc) {
@@ -158,6 +178,7 @@ __device__ __forceinline__ void head_pass(float* smem, const float* __restrict__
 #undef HP_DMA
 #undef HP_ISSUE
 #undef HP_WAIT
+    HEADS_STAMP(3);
 
     // FC2 epilogue in place: lane (ctu = col, g) holds h2[ctu][16 j + 4 g + r].  Small operand fetches below go through
     // buffer instructions (SGPR resource + one VGPR offset): cheaper to issue beside MFMAs than 64-bit VGPR addresses
@@ -220,6 +241,7 @@ __global__ __launch_bounds__(256) void k_heads(const float* __restrict__ H1, Hea
                                                float* __restrict__ logits, float* __restrict__ raw,
                                                float* __restrict__ probs, int* __restrict__ flags) {
     __shared__ __attribute__((aligned(16))) float smem[kHeadsStages * kHeadsStage];  // the ONLY LDS object (32 KB)
+    HEADS_STAMP(0);
     const int lane = threadIdx.x & 63;
     const unsigned wvu = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int col = lane & 15;
@@ -237,6 +259,7 @@ __global__ __launch_bounds__(256) void k_heads(const float* __restrict__ H1, Hea
         head_pass<1>(smem, H1, hp, qn, lane, wvu, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
     else
         head_pass<0>(smem, H1, hp, qn, lane, wvu, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
+    HEADS_STAMP(4);
 }
 
 void launch_heads(const Workspace& ws, const DeviceWeights& w, int n, float qn, int nctu, long ctu0, float thr1,
