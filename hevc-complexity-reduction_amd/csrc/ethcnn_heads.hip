@@ -11,6 +11,8 @@
 //   The FC2^T accumulator of lane (ctu, g) holds h2[ctu][16t + 4g + r]: exactly the B operand
 //   FC3^T needs for step (t, r) -- so FC2 -> FC3 chains in registers (same k order), no LDS,
 //   no HBM round trip.  FC3^T's A operand (W3, 3525 floats in all) comes straight from L1/L2.
+// Where the stage's time goes (phase stamps, device timeline, the rebuilt "wide" variant that was measured and dropped):
+// profiles/r02_heads_timeline.txt, scripts/ubench/heads_probe.hip.
 #include <hip/hip_runtime.h>
 
 #include "ethcnn_kernels.h"
