@@ -166,7 +166,7 @@ struct ethcnn_ctx {
     float* h1_1 = nullptr;
     int* flags1 = nullptr;
     hipStream_t s_tile = nullptr;
-    hipEvent_t e_tile[2] = {}, e_trunk[2] = {}, e_heads[2] = {}, e_main = nullptr;
+    hipEvent_t e_tile[2] = {}, e_trunk[2] = {}, e_main = nullptr;
     int tile_blocks = 256;   // blocks of the side-stream tile stage: one per CU (ETHCNN_TILE_BLOCKS)
     unsigned pass_idx = 0;   // parity selects the buffer set
     int last_parity = 0;     // of the last pass (debug_fetch reads its h1)
@@ -304,7 +304,7 @@ extern "C" int ethcnn_create(ethcnn_ctx** out, const ethcnn_options* opt) {
         return set_err(nullptr, ETHCNN_ERR_DEVICE, "cannot create HIP streams on device %d", dev);
     }
     {
-        hipEvent_t* evs[] = {&c->e_tile[0], &c->e_tile[1], &c->e_trunk[0], &c->e_trunk[1], &c->e_heads[0], &c->e_heads[1], &c->e_main};
+        hipEvent_t* evs[] = {&c->e_tile[0], &c->e_tile[1], &c->e_trunk[0], &c->e_trunk[1], &c->e_main};
         for (hipEvent_t* e : evs)
             if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) {
                 ethcnn_destroy(c);
@@ -392,7 +392,7 @@ extern "C" void ethcnn_destroy(ethcnn_ctx* c) {
             if (p) (void)hipFree(p);
     }
     {
-        hipEvent_t evs[] = {c->e_tile[0], c->e_tile[1], c->e_trunk[0], c->e_trunk[1], c->e_heads[0], c->e_heads[1], c->e_main};
+        hipEvent_t evs[] = {c->e_tile[0], c->e_tile[1], c->e_trunk[0], c->e_trunk[1], c->e_main};
         for (hipEvent_t e : evs)
             if (e) (void)hipEventDestroy(e);
     }
@@ -644,9 +644,12 @@ static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, lo
     hipStream_t s_tile = side_tile ? c->s_tile : c->stream;
     if (input_ready) HIPCHK(c, hipStreamWaitEvent(s_tile, input_ready, 0));
     if (side_tile) {
-        // tile(i) overwrites the tile outputs and gate flags of buffer set p: last read by trunk(i-2) / gate(i-2)
-        HIPCHK(c, hipStreamWaitEvent(s_tile, c->e_trunk[p], 0));  // a never-recorded event is a no-op
-        HIPCHK(c, hipStreamWaitEvent(s_tile, c->e_heads[p], 0));
+        // tile(i) overwrites the tile outputs and gate flags of buffer set p: last read by trunk(i-2) / gate(i-2).  Both are
+        // ordered before trunk(i-1) on the main stream, so the wait for e_trunk[p ^ 1] below covers them; a main-stream
+        // pass in between (small pass, LDP call) records e_main behind its last kernel instead.  Every event RECORD on the
+        // main stream is a barrier packet between two kernels (~7 us of idle GPU, rocprofv3 kernel trace): there is exactly
+        // one per pipelined pass (e_trunk).  A never-recorded event is a no-op.
+        HIPCHK(c, hipStreamWaitEvent(s_tile, c->e_trunk[p], 0));
         HIPCHK(c, hipStreamWaitEvent(s_tile, c->e_main, 0));      // main-stream users of the workspace outside run_pass (LDP)
         // ... and it should run beside FC1(i-1), not beside trunk(i-1): with the trunk it competes for VALU issue and HBM
         // (measured: trunk 556 -> 819 us, tile 180 -> 511 us, step period 2.60 -> 2.73 ms; profiles/r02_overlap_trace.txt)
@@ -675,8 +678,7 @@ static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, lo
     { StageTimer t(c, ETHCNN_STAGE_GATE); launch_gate(w, n, g.nctu, ctu0, c->thr2, d_probs_pass, c->stream); }
     LAUNCH_OK("heads / gate");
 #undef LAUNCH_OK
-    if (side_tile) HIPCHK(c, hipEventRecord(c->e_heads[p], c->stream));  // gate(i) done: the flags of set p are free again
-    else if (c->overlap) HIPCHK(c, hipEventRecord(c->e_main, c->stream));  // a later pipelined tile stage must wait for this pass
+    if (!side_tile && c->overlap) HIPCHK(c, hipEventRecord(c->e_main, c->stream));  // a later pipelined tile stage must wait for this pass
     c->times.ctus += n;
     c->last_n = n;
     c->last_parity = p;
