@@ -167,6 +167,10 @@ struct ethcnn_ctx {
     int* flags1 = nullptr;
     hipStream_t s_tile = nullptr;
     hipEvent_t e_tile[2] = {}, e_trunk[2] = {}, e_main = nullptr;
+    int* d_lgate = nullptr;  // LSTM heads launch: ticket counter + gate predicates [2 * chunks]
+    int lgate_chunks = 0;
+    unsigned lgate_tickets = 0;
+    bool lgate_clean = false;
     int tile_blocks = 256;   // blocks of the side-stream tile stage: one per CU (ETHCNN_TILE_BLOCKS)
     unsigned pass_idx = 0;   // parity selects the buffer set
     int last_parity = 0;     // of the last pass (debug_fetch reads its h1)
@@ -387,7 +391,7 @@ extern "C" void ethcnn_destroy(ethcnn_ctx* c) {
     delete c->pool;
     if (c->dw_arena) (void)hipFree(c->dw_arena);
     {
-        void* lp[] = {c->d_lstm, c->d_vec, c->d_state[0], c->d_state[1], c->d_lprobs};
+        void* lp[] = {c->d_lstm, c->d_vec, c->d_state[0], c->d_state[1], c->d_lprobs, c->d_lgate};
         for (void* p : lp)
             if (p) (void)hipFree(p);
     }
@@ -1093,18 +1097,29 @@ extern "C" int ethcnn_lstm_step_device(ethcnn_ctx* c, const float* d_vec, const 
     int rc = ensure_workspace(c, std::min(n, c->max_ctus), chunks);
     if (rc) return rc;
     if (n > c->ws.cap) return set_err(c, ETHCNN_ERR_ARG, "frame of %d CTUs exceeds max_ctus_per_pass", n);
-    HIPCHK(c, hipMemsetAsync(c->ws.flags, 0, (size_t)chunks * 2 * sizeof(int), c->stream));
+    // gate predicates + ticket counter of the LSTM heads launch: zero between launches by construction (the launch's last
+    // block clears what it used); (re)established here after an allocation or after any failure on this path
+    if (chunks > c->lgate_chunks || !c->lgate_clean) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (chunks > c->lgate_chunks) {
+            if (c->d_lgate) (void)hipFree(c->d_lgate);
+            c->d_lgate = nullptr;
+            c->lgate_chunks = 0;
+            HIPCHK(c, hipMalloc((void**)&c->d_lgate, ((size_t)chunks * 2 + 1) * sizeof(int)));
+            c->lgate_chunks = chunks;
+        }
+        HIPCHK(c, hipMemsetAsync(c->d_lgate, 0, ((size_t)c->lgate_chunks * 2 + 1) * sizeof(int), c->stream));  // stream-ordered
+        c->lgate_tickets = 0;
+    }
+    c->lgate_clean = false;  // until this launch has been enqueued without an error
+    c->lgate_tickets += lstm_heads_blocks(n);
     {
         StageTimer t(c, ETHCNN_STAGE_HEADS);
-        Workspace wv = c->ws;
-        if (!c->debug_capture) wv.raw = nullptr;
-        launch_lstm(d_vec, d_state_in, d_state_out, c->d_lstm, n, qp, i_frame, c->thr1, c->thr2, wv, d_probs, c->stream);
-    }
-    {
-        StageTimer t(c, ETHCNN_STAGE_GATE);
-        launch_gate(c->ws, n, n, 0, c->thr2, d_probs, c->stream);
+        launch_lstm(d_vec, d_state_in, d_state_out, c->d_lstm, n, qp, i_frame, c->thr1, c->thr2, c->debug_capture ? c->ws.raw : nullptr,
+                    d_probs, c->d_lgate, c->lgate_tickets, c->stream);
     }
     HIPCHK(c, hipGetLastError());
+    c->lgate_clean = true;
     c->last_n = n;
     return serial_end(c);
 }

@@ -212,7 +212,9 @@ __device__ __forceinline__ void lstm_heads(const LstmParams& lp, const float* __
                 const float p = sigmoid_l(zz + b3[o]);
                 const size_t idx = (size_t)ctu * kNOut + O3 + o;
                 if (raw) raw[idx] = p;
-                probs[idx] = p;
+                // agent-scope store (written through the XCD's L2): the block that applies the gates may run on another XCD
+                // and overwrite this word; with plain stores every block would need an L2 write-back before its ticket
+                __hip_atomic_store(&probs[idx], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (LV == 0 && p > thr1 && __hip_atomic_load(flag32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
                     __hip_atomic_store(flag32, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (LV == 1 && p > thr2 && __hip_atomic_load(flag16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
@@ -222,25 +224,61 @@ __device__ __forceinline__ void lstm_heads(const LstmParams& lp, const float* __
     }
 }
 
-// grid = (groups of 16 CTUs, level); 12 waves per block (levels 64 / 32 use 3 / 6 of them)
+// grid = (groups of 16 CTUs, level); 12 waves per block (levels 64 / 32 use 3 / 6 of them).
+// The tf.cond gates (net():305,317 -- the AI path's k5_gate) are applied by the LAST block to finish: every block publishes
+// its probabilities and predicates (agent-scope stores), takes a ticket, and the block that draws the launch's last ticket
+// zero-fills the closed sub-batches (usually none) and hands the predicate words back as zeros for the next frame.  One
+// launch instead of three (memset of the predicates, heads, gate) in a latency-bound chain.
 __global__ __launch_bounds__(768) void k_lstm_heads(const float* __restrict__ state_out, LstmParams lp, int N, float thr1,
                                                     float thr2, float* __restrict__ raw, float* __restrict__ probs,
-                                                    int* __restrict__ flags) {
+                                                    int* __restrict__ gate, unsigned ticket_target) {
     __shared__ f32x4 h2T[12 * 64];
+    __shared__ int s_last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ctu_raw = blockIdx.x * 16 + (lane & 15);
     const bool valid = ctu_raw < N;
     const int ctu = min(ctu_raw, N - 1);
     const float* hrow = state_out + (size_t)ctu * 2 * kNVec + kNVec;
-    int* fl = flags + 2 * (ctu / kSubBatch);  // one frame: mini-batches of 1024 in raster order
+    int* const pred = gate + 1;               // gate[0] = ticket counter, then two predicate words per mini-batch
+    int* fl = pred + 2 * (ctu / kSubBatch);  // one frame: mini-batches of 1024 in raster order
     const int lv = 2 - (int)blockIdx.y;
     if (lv == 0) lstm_heads<0>(lp, hrow, valid, ctu, lane, wave, h2T, raw, probs, fl, fl + 1, thr1, thr2);
     else if (lv == 1) lstm_heads<1>(lp, hrow, valid, ctu, lane, wave, h2T, raw, probs, fl, fl + 1, thr1, thr2);
     else lstm_heads<2>(lp, hrow, valid, ctu, lane, wave, h2T, raw, probs, fl, fl + 1, thr1, thr2);
+
+    const int chunks = (N + kSubBatch - 1) / kSubBatch;
+    unsigned* tickets = reinterpret_cast<unsigned*>(gate);
+    // This block's probabilities and predicates are agent-scope atomic stores: once they have completed (vmcnt 0) they are
+    // visible to every XCD, so the ticket needs no release fence (on the 8-XCD part that is a write-back of the whole L2:
+    // measured 36 -> 58 us for a 1080p frame).  The gate block only reads predicates (atomic loads) and overwrites
+    // probabilities, so it needs no acquire either.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0)  // tickets run on across launches (mod 2^32)
+        s_last = (__hip_atomic_fetch_add(tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == ticket_target);
+    __syncthreads();
+    if (!s_last) return;
+    for (int ch = 0; ch < chunks; ++ch) {
+        const bool open32 = __hip_atomic_load(pred + 2 * ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        // y16 is gated on the GATED y32: a closed L1 gate leaves zeros, and any(0 > thr2) decides (the 0 > thr2 corner)
+        const bool open16 = open32 ? (__hip_atomic_load(pred + 2 * ch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) : (0.0f > thr2);
+        if (open32 && open16) continue;
+        const int c0 = ch * kSubBatch, cnt = min(N - c0, kSubBatch) * kNOut;
+        for (int idx = threadIdx.x; idx < cnt; idx += 768) {
+            const int j = idx % kNOut;
+            if (j != 0 && (j < 5 ? !open32 : !open16))
+                __hip_atomic_store(&probs[(size_t)c0 * kNOut + idx], 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();  // every thread has read the predicates
+    for (int i = threadIdx.x; i < 2 * chunks; i += 768) __hip_atomic_store(pred + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+unsigned lstm_heads_blocks(int n) { return (unsigned)((n + 15) / 16) * 3u; }
+
 void launch_lstm(const float* d_vec, const float* d_state_in, float* d_state_out, const float* d_lstm_blob, int n, int qp,
-                 int i_frame, float thr1, float thr2, const Workspace& ws, float* d_probs, hipStream_t s) {
+                 int i_frame, float thr1, float thr2, float* d_raw, float* d_probs, int* d_gate, unsigned ticket_target,
+                 hipStream_t s) {
     LstmParams lp;
     lp.blob = d_lstm_blob;
     lp.efs[0] = ((float)qp / 51.0f) * 0.18f;  // net():283  qp / 51.0 * 0.18
@@ -248,8 +286,8 @@ void launch_lstm(const float* d_vec, const float* d_state_in, float* d_state_out
     for (int e = 0; e < 4; ++e) lp.efs[1 + e] = (e == phase) ? 1.0f : 0.0f;
     const unsigned groups = (unsigned)((n + 15) / 16);
     hipLaunchKernelGGL(k_lstm_cell, dim3(groups, 28), dim3(64), 0, s, d_vec, d_state_in, d_state_out, lp, n);
-    hipLaunchKernelGGL(k_lstm_heads, dim3(groups, 3), dim3(768), 0, s, d_state_out, lp, n, thr1, thr2, ws.raw, d_probs,
-                       ws.flags);
+    hipLaunchKernelGGL(k_lstm_heads, dim3(groups, 3), dim3(768), 0, s, d_state_out, lp, n, thr1, thr2, d_raw, d_probs, d_gate,
+                       ticket_target);
 }
 
 }  // namespace ethcnn

@@ -50,6 +50,32 @@ def test_lstm_step_bit_exact(ctx, lstm, n, gain, qp, i_frame, with_state):
     ctx.set_thresholds(0.5, 0.5)
 
 
+def test_lstm_gates_are_applied_inside_the_heads_launch(ctx, lstm):
+    """The tf.cond zero-fill (net():305,317) is done by the last block of the LSTM heads launch, whose predicate words
+    and ticket counter persist between launches: frame sizes with 1, 2 and 4 sub-batches in a mixed order, thresholds
+    that close the L1 gate, only the L2 gate, neither, and the `0 > thr2` corner -- every call bit-exact vs the oracle,
+    and every call repeated (the words a launch leaves behind must be clean)."""
+    blob = lstm.synth_lstm_blob(5, 3.0)
+    ctx.load_lstm_blob(blob)
+    cases = [(700, 0.5, 0.5), (2040, 0.99, 0.5), (3927, 0.5, 0.999), (64, 1.5, -0.5), (2040, 0.2, 0.2), (1025, 1.5, 0.5),
+             (3927, 0.7, 0.6), (16, 0.5, 1.5), (1024, 0.999, 0.999)]
+    closed = 0
+    for k, (n, t1, t2) in enumerate(cases):
+        rng = np.random.default_rng(100 + k)
+        vec, state = _inputs(rng, n)
+        # make the sub-batches differ: a quiet first half raises fewer predicates
+        vec[: n // 2] *= 0.25
+        ctx.set_thresholds(t1, t2)
+        want_p, want_s = lstm.lstm_step(blob, vec, state, 32, k + 2, t1, t2, mode=0)
+        closed += int((want_p[:, 1:] == 0).all(axis=0).any() or (want_p[:, 1:5] == 0).any())
+        for rep in range(2):
+            got_p, got_s = ctx.lstm_step(vec, state, 32, k + 2)
+            assert np.array_equal(_bits(got_p), _bits(want_p)), "case %d rep %d: %d CTUs thr %.3f / %.3f" % (k, rep, n, t1, t2)
+            assert np.array_equal(_bits(got_s), _bits(want_s))
+    assert closed >= 3, "the cases must actually close gates"
+    ctx.set_thresholds(0.5, 0.5)
+
+
 def test_lstm_synthetic_generator_matches(ctx, lstm):
     ctx.load_lstm_synthetic(17, 3.0)
     assert np.array_equal(_bits(ctx.get_lstm_blob()), _bits(lstm.synth_lstm_blob(17, 3.0)))
