@@ -6,8 +6,10 @@
 // One wave = 16 CTUs, "transposed": MFMA rows = output features, columns = CTUs.
 //   FC2^T: A operand = W2 (16-k chunks by LDS-DMA, shared by the block's 4 waves, 2 stages),
 //          B operand = this wave's h1 rows, one float4 per lane per chunk (element e feeds MFMA
-//          step e -> k order 16c + 4g + e, the canonical FC order).  One block = one head of a
-//          64-CTU tile (blockIdx.y = head, 16 first): short per-block latency, three times the blocks.
+//          step e -> k order 16c + 4g + e, the canonical FC order; head 16 fetches it straight into
+//          registers a chunk ahead, heads 32 / 64 through the stage).  One block = one head of a
+//          64-CTU tile (blockIdx.y = head, 16 first): short per-block latency, three times the blocks;
+//          24 KB of LDS and 77 VGPRs: six blocks per CU cover each other's DMA latency.
 //   The FC2^T accumulator of lane (ctu, g) holds h2[ctu][16t + 4g + r]: exactly the B operand
 //   FC3^T needs for step (t, r) -- so FC2 -> FC3 chains in registers (same k order), no LDS,
 //   no HBM round trip.  FC3^T's A operand (W3, 3525 floats in all) comes straight from L1/L2.
@@ -69,9 +71,19 @@ struct HeadsParams {
     const float* b3[3];
 };
 
-__device__ __forceinline__ long gchunk(long gn, int nctu, int cpf) {
-    const long f = gn / nctu;
-    return f * cpf + (gn - f * nctu) / kSubBatch;
+// where the gate predicates of a pass live: chunk(c) = 1024-CTU sub-batch of the frame holding pass CTU c, counted from
+// the chunk of the pass's first CTU (video_to_cu_depth.py:61-73).  32-bit arithmetic with a float reciprocal (+-1 fix-up)
+// instead of two 64-bit divisions per wave.
+struct GateIndex {
+    int nctu, cpf, r0, c0;  // CTUs per frame, chunks per frame, ctu0 % nctu, chunk of ctu0 within its frame
+    float inv_nctu;
+};
+__device__ __forceinline__ int gate_chunk(const GateIndex& gi, int ctu) {
+    const int u = gi.r0 + ctu;  // < 2^24: exact in float
+    int f = (int)((float)u * gi.inv_nctu);
+    if (f * gi.nctu > u) --f;
+    if ((f + 1) * gi.nctu <= u) ++f;
+    return f * gi.cpf + (u - f * gi.nctu) / kSubBatch - gi.c0;
 }
 
 // compile-time description of head H: 0/1/2 -> (n1, n2, n3) = (64,48,1) / (128,96,4) / (256,192,16)
@@ -90,14 +102,18 @@ struct Hd {
     static constexpr int B_PER = (B_INST + 3) / 4; // per wave (the tail duplicates the last piece)
     static constexpr int ISSUE = B_PER + 1;        // VMEM ops per wave per iteration (+ its h1 piece)
     static constexpr bool COLSWZ = (N2 % 32 == 0);
+    // head 16's W2 chunk fills a whole 12 KB stage, so its h1 quads go straight into registers (buffer_load, a chunk
+    // ahead); heads 32 / 64 (6 / 3 KB chunks) keep theirs in the stage behind the chunk, by LDS-DMA
+    static constexpr bool H1REG = (H == 2);
+    static constexpr int H1_AT = 16 * N2;          // float offset of the 4 waves' h1 pieces inside a stage (not H1REG)
 };
-constexpr int kHeadsStage = 16 * 192 + 4 * 256;  // floats per LDS stage: widest W2 chunk + 4 waves' h1 pieces
-constexpr int kHeadsStages = 2;  // prefetch distance 1: 32 KB of LDS and 105 VGPRs per block -> 4 blocks per CU
+constexpr int kHeadsStage = 16 * 192;  // floats per LDS stage: the widest W2 chunk (12 KB) = chunk + h1 pieces of the others
+constexpr int kHeadsStages = 2;  // prefetch distance 1: 24 KB of LDS, < 80 VGPRs per block -> 6 blocks per CU
 
-// One head for this wave's 16 CTUs.  2 LDS stages, prefetch distance 1, every operand by LDS-DMA
-// (inline asm: hipcc neither drains nor counts it), explicit vmcnt + raw barrier -- the FC1 pipeline
-// of ethcnn_dense.hip at the heads' sizes; four blocks per CU cover the DMA latency for each other
-// (3 stages / 3 blocks per CU measured 7 % slower on 102,000 CTUs).
+// One head for this wave's 16 CTUs.  2 LDS stages, prefetch distance 1, W2 by LDS-DMA (inline asm: hipcc neither
+// drains nor counts it), explicit vmcnt + raw barrier -- the FC1 pipeline of ethcnn_dense.hip at the heads' sizes;
+// occupancy, not depth, covers the DMA latency (3 stages / 3 blocks per CU measured 7 % slower on 102,000 CTUs;
+// 6 blocks per CU instead of 4: stage alone 143.6 -> 131.2 us, in the pipeline 0.157 -> 0.148 ms).
 template <int H>
 __device__ __forceinline__ void head_pass(float* smem, const float* __restrict__ H1, const HeadsParams& hp, float qn,
                                           int lane, unsigned wvu, bool valid, int ctu, float* __restrict__ h2row,
@@ -127,11 +143,12 @@ __device__ __forceinline__ void head_pass(float* smem, const float* __restrict__
         b_off[i] = 4u * (unsigned)(row * D::N2 + c4 * 4);
     }
     const unsigned a_off = 4u * (unsigned)(ctu * kNVec + D::O1 + 4 * g);
-    int bcol[D::NT], brow[4];
-#pragma unroll
-    for (int j = 0; j < D::NT; ++j) bcol[j] = (j * 16 + col) ^ (D::COLSWZ ? ((g & 1) << 4) : 0);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) brow[e] = (D::COLSWZ ? e : (e ^ (g & 1))) * D::N2;
+    // A-operand reads: W2[k = 4 g + e][n = 16 j + col] of the chunk sits at  a_base[sel] + e N2 + 16 j  with two per-lane bases
+    // (the permutation above moves odd-g lanes by +-16 columns, sel = j & 1, or by +-1 row, sel = e & 1): everything else
+    // is an immediate offset of the ds_read -- no address VALU in the K loop
+    int a_base[2];
+    if (D::COLSWZ) { a_base[0] = 4 * g * D::N2 + col + 16 * (g & 1); a_base[1] = 4 * g * D::N2 + col - 16 * (g & 1); }
+    else { a_base[0] = 4 * g * D::N2 + col + D::N2 * (g & 1); a_base[1] = 4 * g * D::N2 + col - D::N2 * (g & 1); }
 
 #define HP_DMA(voff, sbase, lds_byte_off)                                                                \
     {                                                                                                    \
@@ -145,7 +162,7 @@ __device__ __forceinline__ void head_pass(float* smem, const float* __restrict__
         _Pragma("unroll") for (int i = 0; i < D::B_PER; ++i)                                             \
             HP_DMA(b_off[i], W2 + (size_t)(kc) * 16 * D::N2,                                             \
                    4u * ((st) * kHeadsStage + min(wvu + i * 4, (unsigned)(D::B_INST - 1)) * 256));       \
-        HP_DMA(a_off, H1 + (kc) * 16, 4u * ((st) * kHeadsStage + 16 * 192 + wvu * 256));                 \
+        if (!D::H1REG) HP_DMA(a_off, H1 + (kc) * 16, 4u * ((st) * kHeadsStage + D::H1_AT + wvu * 256));  \
     }
 #define HP_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
@@ -153,6 +170,9 @@ __device__ __forceinline__ void head_pass(float* smem, const float* __restrict__
 #pragma unroll
     for (int j = 0; j < D::NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    const __amdgpu_buffer_rsrc_t rH1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(H1), 0, -1, 0x00020000);
+    f32x4 avr = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (D::H1REG) avr = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rH1, a_off, 0, 0));
     __builtin_amdgcn_s_barrier();  // the previous head's last stage has been consumed by every wave
     HEADS_STAMP(1);
     HP_ISSUE(0, 0);
@@ -164,18 +184,28 @@ __device__ __forceinline__ void head_pass(float* smem, const float* __restrict__
     for (int kc = 0; kc < D::NK; ++kc) {
         const int st2 = st ^ 1;
         if (kc + 1 < D::NK) { HP_ISSUE(kc + 1, st2); }
-        const float4 av = *reinterpret_cast<const float4*>(smem + st * kHeadsStage + 16 * 192 + wvu * 256 + lane * 4);
-        const float* bs = smem + st * kHeadsStage + 4 * g * D::N2;
+        f32x4 av, avn = avr;
+        if (D::H1REG) {
+            av = avr;
+            if (kc + 1 < D::NK) avn = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rH1, a_off, (kc + 1) * 64, 0));
+            asm volatile("" ::: "memory");  // the prefetch stays ahead of this chunk's MFMAs
+        } else {
+            av = *reinterpret_cast<const f32x4*>(smem + st * kHeadsStage + D::H1_AT + wvu * 256 + lane * 4);
+        }
+        const float* bsE = smem + st * kHeadsStage + a_base[0];
+        const float* bsO = smem + st * kHeadsStage + a_base[1];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float hv = (e == 0) ? av.x : (e == 1) ? av.y : (e == 2) ? av.z : av.w;
+            const float hv = av[e];
 #pragma unroll
-            for (int j = 0; j < D::NT; ++j) acc[j] = MFMA16(bs[brow[e] + bcol[j]], hv, acc[j]);  // rows = W2 columns
+            for (int j = 0; j < D::NT; ++j)
+                acc[j] = MFMA16((((D::COLSWZ ? j : e) & 1) ? bsO : bsE)[e * D::N2 + 16 * j], hv, acc[j]);  // rows = W2 columns
         }
         HP_WAIT(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         st = st2;
+        avr = avn;
     }
 #undef HP_DMA
 #undef HP_ISSUE
@@ -238,26 +268,29 @@ __device__ __forceinline__ void head_pass(float* smem, const float* __restrict__
     }
 }
 
-__global__ __launch_bounds__(256) void k_heads(const float* __restrict__ H1, HeadsParams hp, float qn, int N, int nctu,
-                                               int cpf, long ctu0, float thr1, float thr2, float* __restrict__ H2,
+__global__ __launch_bounds__(256) void k_heads(const float* __restrict__ H1, HeadsParams hp, float qn, int N, GateIndex gi,
+                                               float thr1, float thr2, float* __restrict__ H2,
                                                float* __restrict__ logits, float* __restrict__ raw,
                                                float* __restrict__ probs, int* __restrict__ flags) {
-    __shared__ __attribute__((aligned(16))) float smem[kHeadsStages * kHeadsStage];  // the ONLY LDS object (32 KB)
+    __shared__ __attribute__((aligned(16))) float smem[kHeadsStages * kHeadsStage];  // the ONLY LDS object (24 KB)
     HEADS_STAMP(0);
     const int lane = threadIdx.x & 63;
     const unsigned wvu = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int col = lane & 15;
-    const int ctu_raw = (blockIdx.x * 4 + (int)wvu) * 16 + col;
+    const int tile_ = blockIdx.x, head_ = blockIdx.y;
+    const int ctu_raw = (tile_ * 4 + (int)wvu) * 16 + col;
     const bool valid = ctu_raw < N;
     const int ctu = min(ctu_raw, N - 1);  // clamped rows are loaded, never stored
     float* h2row = H2 ? H2 + (size_t)ctu * kNFc2 : nullptr;
-    int* fl = flags + 2 * (gchunk(ctu0 + ctu, nctu, cpf) - gchunk(ctu0, nctu, cpf));
+    // only heads 64 / 32 raise predicates (blockIdx.y = 2 / 1); head 16 (most of the blocks) skips the index arithmetic
+    int* fl = flags;
+    if (head_ != 0) fl += 2 * gate_chunk(gi, ctu);
     // blockIdx.y selects the head: the three heads of a 64-CTU tile are independent (each reads its own
     // column slice of h1), so they run as separate blocks -- head 16 (16 K chunks) is dispatched first,
     // the short heads 32 / 64 fill in behind it.  A third of the per-block latency, three times the blocks.
-    if (blockIdx.y == 0)
+    if (head_ == 0)
         head_pass<2>(smem, H1, hp, qn, lane, wvu, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
-    else if (blockIdx.y == 1)
+    else if (head_ == 1)
         head_pass<1>(smem, H1, hp, qn, lane, wvu, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
     else
         head_pass<0>(smem, H1, hp, qn, lane, wvu, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
@@ -273,8 +306,15 @@ void launch_heads(const Workspace& ws, const DeviceWeights& w, int n, float qn, 
         hp.w3[h] = w.fc3_w[h];
         hp.b3[h] = w.fc3_b[h];
     }
-    hipLaunchKernelGGL(k_heads, dim3((n + 63) / 64, 3), dim3(256), 0, s, ws.h1, hp, qn, n, nctu, chunks_per_frame(nctu),
-                       ctu0, thr1, thr2, ws.h2, ws.logits, ws.raw, d_probs, ws.flags);
+    GateIndex gi;
+    gi.nctu = nctu;
+    gi.cpf = chunks_per_frame(nctu);
+    gi.r0 = (int)(ctu0 % nctu);
+    gi.c0 = gi.r0 / kSubBatch;
+    gi.inv_nctu = 1.0f / (float)nctu;
+    const dim3 grid((n + 63) / 64, 3);
+    hipLaunchKernelGGL(k_heads, grid, dim3(256), 0, s, ws.h1, hp, qn, n, gi, thr1, thr2, ws.h2, ws.logits, ws.raw, d_probs,
+                       ws.flags);
 }
 
 }  // namespace ethcnn
