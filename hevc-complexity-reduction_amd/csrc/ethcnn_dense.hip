@@ -233,16 +233,31 @@ __global__ __launch_bounds__(64 * WM) void k_fc1_p3(const float* __restrict__ fe
 // that the XCD grouping of both parts holds), so they run beside two bulk blocks per CU from the start: their short
 // per-chunk MFMA chains, latency-bound when such a launch has the GPU to itself (107 us for 3696 rows), are absorbed at the
 // bulk rate instead (the matrix pipe just sees 4 % more MFMAs).  Same chains per accumulator: results are identical.
+#ifdef FC1_STAMPS
+// development probe (scripts/ubench/fc1_probe.hip): device-wide 100 MHz stamps at entry / exit of every block
+__device__ unsigned long long g_fc1_stamps[1 << 14][2];
+__device__ __forceinline__ void fc1_stamp(int slot) {
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    if (threadIdx.x == 0) g_fc1_stamps[blockIdx.x & 0x3fff][slot] = t;
+}
+#define FC1_STAMP(i) fc1_stamp(i)
+#else
+#define FC1_STAMP(i)
+#endif
+
 template <int NS, int WM, int NSUB>
 __global__ __launch_bounds__(64 * WM) void k_fc1_bulk(const float* __restrict__ feat, const float* __restrict__ Wimg,
                                                       const float* __restrict__ bias, float* __restrict__ out, int m_main,
                                                       int m_total, unsigned rem_blocks) {
     __shared__ __attribute__((aligned(16))) float smem[Fc1Shape<2, NS, WM, NSUB, 3>::LDS_FLOATS];  // the ONLY LDS object
+    FC1_STAMP(0);
     if (blockIdx.x < rem_blocks)
         fc1_tile<1, NS, WM, NSUB, true, 3>(smem, feat + (size_t)(m_main / 16) * kNFeat * 16, Wimg, bias, out + (size_t)m_main * kNVec,
                                            m_total - m_main, blockIdx.x);
     else
         fc1_tile<2, NS, WM, NSUB, true, 3>(smem, feat, Wimg, bias, out, m_main, blockIdx.x - rem_blocks);
+    FC1_STAMP(1);
 }
 
 template <int MS, int NS, int WM, int NSUB, bool GROUP = false, int NST = 3>
