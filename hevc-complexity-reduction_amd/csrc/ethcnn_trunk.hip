@@ -288,14 +288,21 @@ __global__ __launch_bounds__(256) void k1_trunk(const uint4* __restrict__ XS, co
     else Trunk<2, RESI>::run(XL, groups, (b - bS - bM) * 4 + w, (int)(gridDim.x - bS - bM) * 4, wfrag, bfrag, F, N, wl);
 }
 
+// blocks per 256 of the S / M / L branches: tasks 16 : 4 : 1, weighted by their instruction-mix cost per task (M / L tasks
+// carry ~80 more VALU for the 16-bit unpack: ~9700 vs ~9400 clocks) -> 193 : 50 : 13 (195 : 49 : 12 measured 0.6 % slower)
+#ifndef TRUNK_SH_S
+#define TRUNK_SH_S 193
+#define TRUNK_SH_M 50
+#define TRUNK_SH_L 13
+#endif
+
 void launch_trunk(const Workspace& ws, const DeviceWeights& w, int n, bool resi, hipStream_t s) {
-    // tasks per group: 16 S, 4 M, 1 L -- all 240 MFMAs.  768 blocks = 3 per CU (161 VGPRs, 21 KB LDS),
-    // shares 16:4:1.
+    // tasks per group: 16 S, 4 M, 1 L -- all 240 MFMAs.  768 blocks = 3 per CU (156 VGPRs, 21 KB LDS).
     const int groups = (n + 15) / 16, tS = groups * 16, tM = groups * 4, tL = groups;
     auto blocks = [](int tasks, int budget) { int b = (tasks + 3) / 4; return b < budget ? b : budget; };
     static int per_cu = 0;
     if (!per_cu) { const char* e = getenv("ETHCNN_TRUNK_BLOCKS_PER_CU"); per_cu = e ? atoi(e) : 3; }  // development knob
-    const int bS = blocks(tS, 195 * per_cu), bM = blocks(tM, 49 * per_cu), bL = blocks(tL, 12 * per_cu);
+    const int bS = blocks(tS, TRUNK_SH_S * per_cu), bM = blocks(tM, TRUNK_SH_M * per_cu), bL = blocks(tL, TRUNK_SH_L * per_cu);
     if (resi)
         hipLaunchKernelGGL(k1_trunk<true>, dim3(bS + bM + bL), dim3(256), 0, s, ws.xs, ws.xm, ws.xl, n, bS, bM,
                            w.trunk_w, w.trunk_b, ws.feat);
