@@ -1028,9 +1028,13 @@ extern "C" int ethcnn_resi_vectors(ethcnn_ctx* c, const uint8_t* luma, int w, in
 // ------------------------------------------------ config #5: ETH-LSTM one step -------
 static int upload_lstm(ethcnn_ctx* c) {
     HIPCHK(c, hipSetDevice(c->device));
-    if (!c->d_lstm) HIPCHK(c, hipMalloc((void**)&c->d_lstm, kLstmBlobFloats * sizeof(float)));
+    if (!c->d_lstm) HIPCHK(c, hipMalloc((void**)&c->d_lstm, (kLstmBlobFloats + kLstmPackFloats) * sizeof(float)));
+    std::vector<float> pack(kLstmPackFloats);  // the LSTMCell kernels in the cell kernel's load order, behind the blob
+    pack_lstm_kernels(c->lstm_blob.data(), pack.data());
     HIPCHK(c, hipDeviceSynchronize());
     HIPCHK(c, hipMemcpyAsync(c->d_lstm, c->lstm_blob.data(), kLstmBlobFloats * sizeof(float), hipMemcpyHostToDevice,
+                             c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_lstm + kLstmBlobFloats, pack.data(), kLstmPackFloats * sizeof(float), hipMemcpyHostToDevice,
                              c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->have_lstm = true;

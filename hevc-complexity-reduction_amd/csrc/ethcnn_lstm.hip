@@ -14,7 +14,7 @@
 // k = 16c + 4g + e order, then the 5 efs columns, then the bias (oracle: oracle_lstm_step).
 // LDP calls this once per frame on a few hundred CTUs (lock-step with the encoder): the design
 // goal is latency.  Weight operands come straight from L2 (each is used once per block), the
-// dependent MFMA chain per wave is kept short by spreading hidden tiles over 16 waves.
+// dependent MFMA chain per wave is kept short: one wave per (hidden tile, gate) in the cell, one per fc2 tile in the heads.
 #include <hip/hip_runtime.h>
 
 #include "ethcnn_kernels.h"
@@ -58,10 +58,10 @@ __device__ __constant__ int kLstmOff[3][6] = {{723640, 723688, 727000, 727001, 7
                                               {0, 192, 50304, 50320, 53472, 54496}};
 
 // Two launches per frame, both latency-oriented (few hundred CTUs, lock-step with the encoder):
-//   k_lstm_cell : one wave per (16 CTUs, hidden tile of 16 units): the four gate accumulators of
-//                 the tile, a dependent chain of 2 N / 4 MFMA steps fed by a 4-chunk-deep register
-//                 prefetch of the kernel rows (each weight is used once per wave: no LDS), then the
-//                 lane-local cell update; writes (c, h) to state_out.
+//   k_lstm_cell : one block per (16 CTUs, hidden tile of 16 units), one wave per gate: its accumulator is a
+//                 dependent chain of 2 N / 4 MFMA steps fed by an 8-chunk-deep register prefetch of the kernel
+//                 rows (each weight is used once per wave: no LDS); the four gates of a unit meet through
+//                 1 KB of LDS and wave q updates unit r = q of every lane; writes (c, h) to state_out.
 //   k_lstm_heads: one block per (16 CTUs, level): wave j owns fc2 tile j with h_new read back from
 //                 state_out (L2) as the B operand; h2 crosses waves through LDS in [tile][g][ctu][r]
 //                 order (the writer's C-layout quad and the reader's B-operand quad of lane (ctu, g)
@@ -76,84 +76,100 @@ struct LstmDims {
     static constexpr int NT = N / 16, NT2 = N2 / 16;
 };
 
-template <int LV>
-__device__ __forceinline__ void lstm_cell(const LstmParams& lp, const float* __restrict__ vrow,
-                                          const float* __restrict__ sin_row, float* __restrict__ sout_row, bool valid,
-                                          int lane, int t) {
+// One gate (wave q) of hidden tile t for CG column groups of 16 CTUs: the kernel rows fetched once feed CG MFMAs (the
+// weights are streamed from L2 by every block: at one column group per block a 1080p frame moves 85 MB at ~4 TB/s).
+template <int LV, int CG>
+__device__ __forceinline__ void lstm_cell(const LstmParams& lp, const float* __restrict__ vec, const float* __restrict__ state_in,
+                                          float* __restrict__ state_out, int N_ctus, int group0, int lane, int q, int t,
+                                          f32x4* xch) {
     using D = LstmDims<LV>;
-    constexpr int N = D::N, O1 = D::O1, NC = 2 * N / 16, PF = 4;
+    constexpr int N = D::N, O1 = D::O1, NC = 2 * N / 16, PF = (CG == 4) ? 4 : 8;
     const int col = lane & 15, g = lane >> 4;
     const float* bk = lp.blob + kLstmOff[LV][4];
-    const float* kcol = lp.blob + kLstmOff[LV][5] + 16 * t + col + (size_t)(4 * g) * (4 * N);
-    const float* xsrc = vrow + O1 + 4 * g;
-    const float* hsrc = sin_row ? sin_row + kNVec + O1 + 4 * g : xsrc;  // null state: any valid address, zeroed below
+    // wave q owns gate q (i, j, f, o) of the tile: ONE accumulator per column group, the same chain as ever (k = 16 c + 4 g + e);
+    // its A operands come from the packed copy of the kernel (ethcnn_spec.h): one dwordx4 per lane per chunk, 1 KB runs
+    const float* kpk = lp.blob + kLstmBlobFloats + kLstmPackOff[LV] + (size_t)((t * 4 + q) * NC) * 256 + lane * 4;
+    const float* xsrc[CG];
+    const float* hsrc[CG];
+    bool valid[CG];
+    size_t row[CG];
+#pragma unroll
+    for (int c = 0; c < CG; ++c) {
+        const int ctu_raw = (group0 + c) * 16 + col;
+        valid[c] = ctu_raw < N_ctus;
+        row[c] = (size_t)min(ctu_raw, N_ctus - 1);
+        xsrc[c] = vec + row[c] * kNVec + O1 + 4 * g;
+        hsrc[c] = state_in ? state_in + row[c] * 2 * kNVec + kNVec + O1 + 4 * g : xsrc[c];  // null state: any valid address, zeroed below
+    }
 
-    float a[PF][16];
-    float4 bv[PF];
+    float4 a[PF];
+    float4 bv[PF][CG];
     auto load = [&](int kc, int p) {  // [x, h_prev]: x first (array_ops.concat([inputs, m_prev], 1))
         const bool in_x = kc < N / 16;
-        const float* src = in_x ? xsrc + 16 * kc : hsrc + 16 * (kc - N / 16);
-        float4 v = *reinterpret_cast<const float4*>(src);
-        if (!in_x && !sin_row) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        bv[p] = v;
-        const float* krow = kcol + (size_t)(16 * kc) * (4 * N);
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) a[p][4 * e + q] = krow[(size_t)e * (4 * N) + q * N];
+        for (int c = 0; c < CG; ++c) {
+            const float* src = in_x ? xsrc[c] + 16 * kc : hsrc[c] + 16 * (kc - N / 16);
+            float4 v = *reinterpret_cast<const float4*>(src);
+            if (!in_x && !state_in) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            bv[p][c] = v;
+        }
+        a[p] = *reinterpret_cast<const float4*>(kpk + (size_t)kc * 256);
     };
-    f32x4 acc[4];
+    f32x4 acc[CG];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < CG; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int p = 0; p < PF; ++p) load(p, p);
 #pragma unroll 1
     for (int kc = 0; kc < NC; kc += PF) {
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
-            const float hv[4] = {bv[p].x, bv[p].y, bv[p].z, bv[p].w};
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = MFMA16(a[p][4 * e + q], hv[e], acc[q]);
+                for (int c = 0; c < CG; ++c) {
+                    const float hv = (e == 0) ? bv[p][c].x : (e == 1) ? bv[p][c].y : (e == 2) ? bv[p][c].z : bv[p][c].w;
+                    const float av = (e == 0) ? a[p].x : (e == 1) ? a[p].y : (e == 2) ? a[p].z : a[p].w;
+                    acc[c] = MFMA16(av, hv, acc[c]);
+                }
             load(min(kc + PF + p, NC - 1), p);  // the tail re-reads the last chunk (unused)
         }
     }
-    // cell update, lane-local: units u = 16 t + 4 g + r
-    const int u0 = 16 * t + 4 * g;
-    const float4 cp = sin_row ? *reinterpret_cast<const float4*>(sin_row + O1 + u0) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float cpv[4] = {cp.x, cp.y, cp.z, cp.w};
-    f32x4 cn, hn;
+    // the four gates of lane (ctu, g) meet in LDS; wave q then updates unit r = q of every lane: u = 16 t + 4 g + q
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int u = u0 + r;
-        const float gi = acc[0][r] + bk[u], gj = acc[1][r] + bk[N + u];
-        const float gf = acc[2][r] + bk[2 * N + u], go = acc[3][r] + bk[3 * N + u];
-        float cc = sigmoid_l(gf + 1.0f) * cpv[r] + sigmoid_l(gi) * tanh_l(gj);
+    for (int c = 0; c < CG; ++c) xch[(c * 4 + q) * 64 + lane] = acc[c];
+    __syncthreads();
+    const int u = 16 * t + 4 * g + q;
+    const float b_i = bk[u], b_j = bk[N + u], b_f = bk[2 * N + u], b_o = bk[3 * N + u];
+#pragma unroll
+    for (int c = 0; c < CG; ++c) {
+        const float* xf = reinterpret_cast<const float*>(xch + c * 256) + lane * 4 + q;
+        const float gi = xf[0] + b_i, gj = xf[256] + b_j, gf = xf[512] + b_f, go = xf[768] + b_o;
+        const float cp = state_in ? state_in[row[c] * 2 * kNVec + O1 + u] : 0.0f;
+        float cc = sigmoid_l(gf + 1.0f) * cp + sigmoid_l(gi) * tanh_l(gj);
         cc = fminf(fmaxf(cc, -5.0f), 5.0f);
-        cn[r] = cc;
-        hn[r] = sigmoid_l(go) * tanh_l(cc);
-    }
-    if (valid) {
-        *reinterpret_cast<f32x4*>(sout_row + O1 + u0) = cn;
-        *reinterpret_cast<f32x4*>(sout_row + kNVec + O1 + u0) = hn;
+        const float hn = sigmoid_l(go) * tanh_l(cc);
+        if (valid[c]) {
+            float* so = state_out + row[c] * 2 * kNVec;
+            so[O1 + u] = cc;
+            so[kNVec + O1 + u] = hn;
+        }
     }
 }
 
-// grid = (groups of 16 CTUs, 28 hidden tiles: 16 of level 16 first, then 8 of level 32, 4 of level 64)
-__global__ __launch_bounds__(64) void k_lstm_cell(const float* __restrict__ vec, const float* __restrict__ state_in,
-                                                  float* __restrict__ state_out, LstmParams lp, int N) {
-    const int lane = threadIdx.x;
-    const int ctu_raw = blockIdx.x * 16 + (lane & 15);
-    const bool valid = ctu_raw < N;
-    const int ctu = min(ctu_raw, N - 1);
-    const float* vrow = vec + (size_t)ctu * kNVec;
-    const float* sin_row = state_in ? state_in + (size_t)ctu * 2 * kNVec : nullptr;
-    float* sout_row = state_out + (size_t)ctu * 2 * kNVec;
+// grid = (groups of 16 CG CTUs, 28 hidden tiles: 16 of level 16 first, then 8 of level 32, 4 of level 64); four waves per
+// block, one per gate: the dependent MFMA chain of a wave is a quarter of the tile's (128 steps at level 16) and four times
+// as many waves hide the weight-load latency.  CG = 1 for small frames (parallelism), 2 / 4 from 720p / 4K up (weight reuse).
+template <int CG>
+__global__ __launch_bounds__(256) void k_lstm_cell(const float* __restrict__ vec, const float* __restrict__ state_in,
+                                                   float* __restrict__ state_out, LstmParams lp, int N) {
+    __shared__ f32x4 xch[CG * 4 * 64];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int group0 = blockIdx.x * CG;
     const int ti = blockIdx.y;
-    if (ti < 16) lstm_cell<2>(lp, vrow, sin_row, sout_row, valid, lane, ti);
-    else if (ti < 24) lstm_cell<1>(lp, vrow, sin_row, sout_row, valid, lane, ti - 16);
-    else lstm_cell<0>(lp, vrow, sin_row, sout_row, valid, lane, ti - 24);
+    if (ti < 16) lstm_cell<2, CG>(lp, vec, state_in, state_out, N, group0, lane, q, ti, xch);
+    else if (ti < 24) lstm_cell<1, CG>(lp, vec, state_in, state_out, N, group0, lane, q, ti - 16, xch);
+    else lstm_cell<0, CG>(lp, vec, state_in, state_out, N, group0, lane, q, ti - 24, xch);
 }
 
 template <int LV>
@@ -274,6 +290,10 @@ __global__ __launch_bounds__(768) void k_lstm_heads(const float* __restrict__ st
     for (int i = threadIdx.x; i < 2 * chunks; i += 768) __hip_atomic_store(pred + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+#ifndef LSTM_CG4_MIN
+#define LSTM_CG4_MIN 96
+#endif
+
 unsigned lstm_heads_blocks(int n) { return (unsigned)((n + 15) / 16) * 3u; }
 
 void launch_lstm(const float* d_vec, const float* d_state_in, float* d_state_out, const float* d_lstm_blob, int n, int qp,
@@ -285,7 +305,9 @@ void launch_lstm(const float* d_vec, const float* d_state_in, float* d_state_out
     const int phase = ((i_frame % 4) + 4) % 4;
     for (int e = 0; e < 4; ++e) lp.efs[1 + e] = (e == phase) ? 1.0f : 0.0f;
     const unsigned groups = (unsigned)((n + 15) / 16);
-    hipLaunchKernelGGL(k_lstm_cell, dim3(groups, 28), dim3(64), 0, s, d_vec, d_state_in, d_state_out, lp, n);
+    if (groups >= LSTM_CG4_MIN) hipLaunchKernelGGL(k_lstm_cell<4>, dim3((groups + 3) / 4, 28), dim3(256), 0, s, d_vec, d_state_in, d_state_out, lp, n);
+    else if (groups >= 12) hipLaunchKernelGGL(k_lstm_cell<2>, dim3((groups + 1) / 2, 28), dim3(256), 0, s, d_vec, d_state_in, d_state_out, lp, n);
+    else hipLaunchKernelGGL(k_lstm_cell<1>, dim3(groups, 28), dim3(256), 0, s, d_vec, d_state_in, d_state_out, lp, n);
     hipLaunchKernelGGL(k_lstm_heads, dim3(groups, 3), dim3(768), 0, s, d_state_out, lp, n, thr1, thr2, d_raw, d_probs, d_gate,
                        ticket_target);
 }

@@ -39,6 +39,12 @@ extern const TensorDesc kTensors[kNumTensors];  // bundle (sorted-key) order
 constexpr int kNumLstmTensors = 18;
 extern const TensorDesc kLstmTensors[kNumLstmTensors];
 constexpr size_t kLstmBlobFloats = 760078;  // 3,040,312-byte .data payload
+// LSTMCell kernels [2N][4N] re-laid for the gate-per-wave cell kernel (ethcnn_lstm.hip), appended to the blob on the device:
+// level LV (N = 64 / 128 / 256): [tile N/16][gate 4][chunk 2N/16][lane 64][e 4] = K[16 chunk + 4 g + e][gate N + 16 tile + col],
+// lane = col + 16 g -- one contiguous 1 KB run per (tile, gate, chunk), a dwordx4 per lane
+constexpr int kLstmKernelOff[3] = {727310, 592568, 54496};    // float offsets of the three kernels inside the blob
+constexpr int kLstmPackOff[3] = {0, 32768, 163840};           // float offsets inside the packed area
+constexpr size_t kLstmPackFloats = 688128;
 
 // float offsets into the blob ------------------------------------------------------------
 // conv variables are unnamed: L = Variable.._5, M = _6.._11, S = _12.._17 (creation order,
@@ -96,6 +102,7 @@ void pack_fc1(const float* blob, float* w_out /*[2688][448]*/, float* b_out /*[4
 void pack_fc1_image(const float* w_cat /*[2688][448]*/, int bn, int bk, float* img_out /*[2688*448]*/);
 void synth_blob(uint64_t seed, double head_gain, float* blob_out /*[kBlobFloats]*/);
 void synth_lstm_blob(uint64_t seed, double head_gain, float* blob_out /*[kLstmBlobFloats]*/);
+void pack_lstm_kernels(const float* blob, float* out /*[kLstmPackFloats]*/);
 
 // TF-V2 checkpoint bundle reader (tf_ckpt_v2.cpp).  Returns 0 or a negative ETHCNN_ERR_*;
 // on error `err` holds the message.

@@ -202,4 +202,20 @@ void pack_fc1_image(const float* w_cat, int bn, int bk, float* img) {
             }
 }
 
+void pack_lstm_kernels(const float* blob, float* out) {
+    for (int lv = 0; lv < 3; ++lv) {
+        const int N = 64 << lv, NC = 2 * N / 16;
+        const float* K = blob + kLstmKernelOff[lv];  // [2N][4N], gate order i, j, f, o
+        float* o = out + kLstmPackOff[lv];
+        for (int t = 0; t < N / 16; ++t)
+            for (int q = 0; q < 4; ++q)
+                for (int kc = 0; kc < NC; ++kc)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 4; ++e) {
+                            const int col = lane & 15, g = lane >> 4;
+                            *o++ = K[(size_t)(16 * kc + 4 * g + e) * (4 * N) + q * N + 16 * t + col];
+                        }
+    }
+}
+
 }  // namespace ethcnn
