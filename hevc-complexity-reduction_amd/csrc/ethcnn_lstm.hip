@@ -58,10 +58,11 @@ __device__ __constant__ int kLstmOff[3][6] = {{723640, 723688, 727000, 727001, 7
                                               {0, 192, 50304, 50320, 53472, 54496}};
 
 // Two launches per frame, both latency-oriented (few hundred CTUs, lock-step with the encoder):
-//   k_lstm_cell : one block per (16 CTUs, hidden tile of 16 units), one wave per gate: its accumulator is a
-//                 dependent chain of 2 N / 4 MFMA steps fed by an 8-chunk-deep register prefetch of the kernel
-//                 rows (each weight is used once per wave: no LDS); the four gates of a unit meet through
-//                 1 KB of LDS and wave q updates unit r = q of every lane; writes (c, h) to state_out.
+//   k_lstm_cell : one block per (16 CG CTUs, hidden tile of 16 units), one wave per gate: its accumulator is a
+//                 dependent chain of 2 N / 4 MFMA steps; all of its kernel rows (packed copy, one dwordx4 per lane per
+//                 16 k) are requested into registers and the block's [x, h_prev] quads into LDS before the first
+//                 MFMA; the four gates of a unit meet through 1 KB of LDS and wave q updates unit r = q of every
+//                 lane; writes (c, h) to state_out.
 //   k_lstm_heads: one block per (16 CTUs, level): wave j owns fc2 tile j with h_new read back from
 //                 state_out (L2) as the B operand; h2 crosses waves through LDS in [tile][g][ctu][r]
 //                 order (the writer's C-layout quad and the reader's B-operand quad of lane (ctu, g)
@@ -76,14 +77,16 @@ struct LstmDims {
     static constexpr int NT = N / 16, NT2 = N2 / 16;
 };
 
-// One gate (wave q) of hidden tile t for CG column groups of 16 CTUs: the kernel rows fetched once feed CG MFMAs (the
-// weights are streamed from L2 by every block: at one column group per block a 1080p frame moves 85 MB at ~4 TB/s).
+// One gate (wave q) of hidden tile t for CG column groups of 16 CTUs: the kernel rows fetched once feed CG MFMAs.  What
+// set this kernel's time was not bandwidth but one exposed memory latency per prefetch window (a 4- or 8-chunk-deep
+// register prefetch: 20 us per 1080p frame with the weight loads, the x / h loads or the epilogue removed in turn);
+// with every operand requested before the first MFMA it is paid once per block: 12 us.
 template <int LV, int CG>
 __device__ __forceinline__ void lstm_cell(const LstmParams& lp, const float* __restrict__ vec, const float* __restrict__ state_in,
                                           float* __restrict__ state_out, int N_ctus, int group0, int lane, int q, int t,
-                                          f32x4* xch) {
+                                          f32x4* xch, f32x4* xh) {
     using D = LstmDims<LV>;
-    constexpr int N = D::N, O1 = D::O1, NC = 2 * N / 16, PF = (CG == 4) ? 4 : 8;
+    constexpr int N = D::N, O1 = D::O1, NC = 2 * N / 16;
     const int col = lane & 15, g = lane >> 4;
     const float* bk = lp.blob + kLstmOff[LV][4];
     // wave q owns gate q (i, j, f, o) of the tile: ONE accumulator per column group, the same chain as ever (k = 16 c + 4 g + e);
@@ -102,38 +105,40 @@ __device__ __forceinline__ void lstm_cell(const LstmParams& lp, const float* __r
         hsrc[c] = state_in ? state_in + row[c] * 2 * kNVec + kNVec + O1 + 4 * g : xsrc[c];  // null state: any valid address, zeroed below
     }
 
-    float4 a[PF];
-    float4 bv[PF][CG];
-    auto load = [&](int kc, int p) {  // [x, h_prev]: x first (array_ops.concat([inputs, m_prev], 1))
+    // every operand of the tile is requested before the first MFMA: the kernel rows of this gate into registers (NC dwordx4),
+    // the block's [x, h_prev] quads into LDS (each wave fetches a quarter of the chunks for all four) -- one memory latency
+    // per block instead of one per prefetch window
+    float4 a[NC];
+#pragma unroll
+    for (int kc = 0; kc < NC; ++kc) a[kc] = *reinterpret_cast<const float4*>(kpk + (size_t)kc * 256);
+#pragma unroll
+    for (int i = 0; i < NC / 4; ++i) {
+        const int kc = 4 * i + q;
         const bool in_x = kc < N / 16;
 #pragma unroll
         for (int c = 0; c < CG; ++c) {
             const float* src = in_x ? xsrc[c] + 16 * kc : hsrc[c] + 16 * (kc - N / 16);
             float4 v = *reinterpret_cast<const float4*>(src);
             if (!in_x && !state_in) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            bv[p][c] = v;
+            xh[(c * NC + kc) * 64 + lane] = (f32x4){v.x, v.y, v.z, v.w};
         }
-        a[p] = *reinterpret_cast<const float4*>(kpk + (size_t)kc * 256);
-    };
+    }
+    __syncthreads();
     f32x4 acc[CG];
 #pragma unroll
     for (int c = 0; c < CG; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int p = 0; p < PF; ++p) load(p, p);
-#pragma unroll 1
-    for (int kc = 0; kc < NC; kc += PF) {
+    for (int kc = 0; kc < NC; ++kc) {
+        f32x4 hq[CG];
 #pragma unroll
-        for (int p = 0; p < PF; ++p) {
+        for (int c = 0; c < CG; ++c) hq[c] = xh[(c * NC + kc) * 64 + lane];
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int c = 0; c < CG; ++c) {
-                    const float hv = (e == 0) ? bv[p][c].x : (e == 1) ? bv[p][c].y : (e == 2) ? bv[p][c].z : bv[p][c].w;
-                    const float av = (e == 0) ? a[p].x : (e == 1) ? a[p].y : (e == 2) ? a[p].z : a[p].w;
-                    acc[c] = MFMA16(av, hv, acc[c]);
-                }
-            load(min(kc + PF + p, NC - 1), p);  // the tail re-reads the last chunk (unused)
-        }
+            for (int c = 0; c < CG; ++c) {
+                const float av = (e == 0) ? a[kc].x : (e == 1) ? a[kc].y : (e == 2) ? a[kc].z : a[kc].w;
+                acc[c] = MFMA16(av, hq[c][e], acc[c]);
+            }
     }
     // the four gates of lane (ctu, g) meet in LDS; wave q then updates unit r = q of every lane: u = 16 t + 4 g + q
 #pragma unroll
@@ -159,17 +164,18 @@ __device__ __forceinline__ void lstm_cell(const LstmParams& lp, const float* __r
 
 // grid = (groups of 16 CG CTUs, 28 hidden tiles: 16 of level 16 first, then 8 of level 32, 4 of level 64); four waves per
 // block, one per gate: the dependent MFMA chain of a wave is a quarter of the tile's (128 steps at level 16) and four times
-// as many waves hide the weight-load latency.  CG = 1 for small frames (parallelism), 2 / 4 from 720p / 4K up (weight reuse).
+// as many waves share the loads.  CG = 1 for small frames (parallelism), 2 from 720p up (weight reuse; 73 KB of LDS).
 template <int CG>
 __global__ __launch_bounds__(256) void k_lstm_cell(const float* __restrict__ vec, const float* __restrict__ state_in,
                                                    float* __restrict__ state_out, LstmParams lp, int N) {
     __shared__ f32x4 xch[CG * 4 * 64];
+    __shared__ f32x4 xh[CG * 32 * 64];  // [x, h_prev] quads of the block: [column group][chunk <= 32][lane] (32 KB per group)
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int group0 = blockIdx.x * CG;
     const int ti = blockIdx.y;
-    if (ti < 16) lstm_cell<2, CG>(lp, vec, state_in, state_out, N, group0, lane, q, ti, xch);
-    else if (ti < 24) lstm_cell<1, CG>(lp, vec, state_in, state_out, N, group0, lane, q, ti - 16, xch);
-    else lstm_cell<0, CG>(lp, vec, state_in, state_out, N, group0, lane, q, ti - 24, xch);
+    if (ti < 16) lstm_cell<2, CG>(lp, vec, state_in, state_out, N, group0, lane, q, ti, xch, xh);
+    else if (ti < 24) lstm_cell<1, CG>(lp, vec, state_in, state_out, N, group0, lane, q, ti - 16, xch, xh);
+    else lstm_cell<0, CG>(lp, vec, state_in, state_out, N, group0, lane, q, ti - 24, xch, xh);
 }
 
 template <int LV>
@@ -290,10 +296,6 @@ __global__ __launch_bounds__(768) void k_lstm_heads(const float* __restrict__ st
     for (int i = threadIdx.x; i < 2 * chunks; i += 768) __hip_atomic_store(pred + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-#ifndef LSTM_CG4_MIN
-#define LSTM_CG4_MIN 96
-#endif
-
 unsigned lstm_heads_blocks(int n) { return (unsigned)((n + 15) / 16) * 3u; }
 
 void launch_lstm(const float* d_vec, const float* d_state_in, float* d_state_out, const float* d_lstm_blob, int n, int qp,
@@ -305,8 +307,7 @@ void launch_lstm(const float* d_vec, const float* d_state_in, float* d_state_out
     const int phase = ((i_frame % 4) + 4) % 4;
     for (int e = 0; e < 4; ++e) lp.efs[1 + e] = (e == phase) ? 1.0f : 0.0f;
     const unsigned groups = (unsigned)((n + 15) / 16);
-    if (groups >= LSTM_CG4_MIN) hipLaunchKernelGGL(k_lstm_cell<4>, dim3((groups + 3) / 4, 28), dim3(256), 0, s, d_vec, d_state_in, d_state_out, lp, n);
-    else if (groups >= 12) hipLaunchKernelGGL(k_lstm_cell<2>, dim3((groups + 1) / 2, 28), dim3(256), 0, s, d_vec, d_state_in, d_state_out, lp, n);
+    if (groups >= 12) hipLaunchKernelGGL(k_lstm_cell<2>, dim3((groups + 1) / 2, 28), dim3(256), 0, s, d_vec, d_state_in, d_state_out, lp, n);
     else hipLaunchKernelGGL(k_lstm_cell<1>, dim3(groups, 28), dim3(256), 0, s, d_vec, d_state_in, d_state_out, lp, n);
     hipLaunchKernelGGL(k_lstm_heads, dim3(groups, 3), dim3(768), 0, s, d_state_out, lp, n, thr1, thr2, d_raw, d_probs, d_gate,
                        ticket_target);
