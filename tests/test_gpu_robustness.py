@@ -42,6 +42,38 @@ def test_random_geometry_fuzz(ctx, oracle):
     ctx.set_thresholds(0.5, 0.5)
 
 
+def test_host_staging_fills_at_odd_alignments(ctx, oracle, tmp_path):
+    """The staging fills write pinned memory with non-temporal 16-byte stores (head / tail bytes by memcpy): frames whose
+    rows and bands start at every alignment (odd widths, odd pitches, a source buffer offset by 1..15 bytes), several
+    ~512 KiB bands per frame and several frames per ring slot, through the host-memory entry point and through both forms of
+    the file entry point (bounce buffer + non-temporal copy, and `pread` straight into the staging buffer)."""
+    blob = oracle.synth_blob(4, 8.0)
+    ctx.load_blob(blob)
+    ctx.set_thresholds(0.5, 0.5)
+    rng = np.random.default_rng(77)
+    for k, (w, h, pad, off, frames) in enumerate([(1283, 1031, 0, 0, 3), (1283, 1031, 5, 3, 2), (2049, 777, 1, 15, 2),
+                                                  (997, 2051, 63, 7, 2), (16, 16, 0, 1, 5), (4099, 515, 13, 9, 1)]):
+        pitch = w + pad
+        stride = pitch * h + 31
+        raw = rng.integers(0, 256, size=stride * frames + 64, dtype=np.uint8)
+        luma = raw[off:]                                   # a source pointer at an odd address
+        got = ctx.predict_luma(luma, w, h, frames, 30, pitch=pitch, frame_stride=stride)
+        want = oracle.predict_frames(blob, luma, w, h, frames, 30, 0.5, 0.5, mode=0, pitch=pitch, frame_stride=stride)
+        assert np.array_equal(_bits(got), _bits(want)), "host case %d: %dx%d pitch %d offset %d" % (k, w, h, pitch, off)
+    # file path: even sizes (4:2:0), rows at odd multiples of the width
+    w, h, frames = 1282, 1030, 4
+    planes = rng.integers(0, 256, size=(frames, h, w), dtype=np.uint8)
+    yuv = tmp_path / "odd.yuv"
+    with open(yuv, "wb") as f:
+        for k in range(frames):
+            f.write(planes[k].tobytes())
+            f.write(bytes([k]) * (w * h // 2))
+    want = oracle.predict_frames(blob, planes, w, h, frames, 30, 0.5, 0.5, mode=0)
+    out = tmp_path / "cu_depth.dat"
+    assert ctx.predict_yuv_file(str(yuv), w, h, 30, str(out)) == frames
+    assert np.array_equal(_bits(np.fromfile(out, dtype=np.float32)), _bits(want).reshape(-1))
+
+
 def test_concurrent_contexts(pkg, oracle):
     """One context per thread (the ABI's threading contract): 4 threads, own contexts, different
     weights and geometries, running at the same time on the same GPU."""
