@@ -829,7 +829,22 @@ static int host_pipeline(ethcnn_ctx* c, int w, int h, int nframes, int qp, Fill 
     if (rc) return rc;
     struct Group { int f0, nf; };
     std::vector<Group> groups;
-    for (int f = 0; f < nframes; f += fpg) groups.push_back({f, std::min(fpg, nframes - f)});
+    {   // short groups at both ends: the DMA engine (the bottleneck stage) starts after the FIRST fill and everything behind
+        // the LAST H2D (kernels, D2H, drain) is exposed -- 1, 2, then fpg frames per group, and 2, 1 at the end
+        std::vector<int> head, tail;
+        int left = nframes;
+        for (int sz = 1; sz < fpg && left > 4 * fpg; sz *= 2) {
+            head.push_back(sz);
+            tail.push_back(sz);
+            left -= 2 * sz;
+        }
+        int f = 0;
+        for (int sz : head) { groups.push_back({f, sz}); f += sz; }
+        int tail_sum = 0;
+        for (int sz : tail) tail_sum += sz;
+        for (; f < nframes - tail_sum; ) { const int nf = std::min(fpg, nframes - tail_sum - f); groups.push_back({f, nf}); f += nf; }
+        for (size_t i = tail.size(); i-- > 0;) { groups.push_back({f, tail[i]}); f += tail[i]; }
+    }
     const size_t ng = groups.size();
     auto retire = [&](size_t gi) -> int {  // group gi's probabilities are in pinned memory: hand them to the caller
         const int b = (int)(gi % kStageBufs);
