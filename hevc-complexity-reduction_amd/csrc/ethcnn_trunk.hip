@@ -8,12 +8,15 @@
 // D[row][col] lives in lane (col, g) as rows 4g..4g+3, which is exactly B[k = g][col] for the 4
 // k-steps r = 0..3 of the next layer when that layer's K is enumerated as (patch, r, g) with
 // ci = 4g + r.  So each layer's accumulator registers ARE the next layer's B operand: no LDS, no
-// cross-lane traffic (one lane-half swap for conv3's channels 16..23).  Weights of the branch
-// live in 84 VGPRs as A operands for the whole task loop.
+// cross-lane traffic (one lane-half swap for conv3's channels 16..23).  conv1's A operands and the
+// biases stay in VGPRs, the 80 conv2 / conv3 A fragments of the branch in 21 KB of LDS (one
+// conflict-free ds_read_b32 per MFMA costs the matrix pipe ~0.6 clocks).
 //
-// Two waves per SIMD (<= 256 VGPRs) overlap one wave's VALU epilogues with the other's MFMAs; the
+// Three waves per SIMD (156 VGPRs) overlap one wave's VALU epilogues with the others' MFMAs; the
 // next task's pixel record is prefetched a task ahead.  (A deeper in-wave software pipeline -- conv1(q+1) before leaky(conv1(q)) --
-// was measured: it needs > 256 VGPRs, drops to one wave per SIMD and is 20 % slower.)
+// was measured: it needs > 256 VGPRs, drops to one wave per SIMD and is 20 % slower.)  The task loop sits at 98 % of its
+// instruction-mix bound: 240 MFMAs + 375 VALU (each already the cheapest instruction that computes it exactly) + 98 LDS
+// + 14 VMEM = ~9960 predicted against 10,165 measured clocks per task.
 // Features are written as feat[group][k/4][16][4]: every store is a 256-byte run per k-group.
 //
 // Arithmetic contract (DESIGN.md "canonical order"; oracle/ethcnn_oracle.c mode 0 restates it):
