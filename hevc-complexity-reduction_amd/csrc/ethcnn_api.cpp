@@ -807,10 +807,10 @@ static int parallel_bands(ethcnn_ctx* c, int nframes, int w, int h, Fn fn) {
     return host_pool(c)->run(nframes * bands, unit);
 }
 
-// Generic double-buffered host pipeline: for each group of frames, `fill(buf, f0, nf)` packs
-// luma planes tightly (pitch = width) into pinned memory, then H2D -> kernels -> D2H run on
-// three streams so the copy of group i+1 overlaps the compute of group i, and
-// `drain(buf, f0, nf)` consumes the pinned probabilities.
+// Host pipeline over a ring of kStageBufs pinned + device buffer pairs: for each group of frames, `fill(buf, f0, nf)` packs
+// luma planes tightly (pitch = width) into pinned memory on the worker pool, then H2D -> kernels -> D2H run on three
+// streams, and `drain(buf, f0, nf)` consumes the pinned probabilities -- fill of group i+2, H2D of group i+1, kernels +
+// D2H of group i and the drain of group i-1 all overlap.
 template <typename Fill, typename Drain>
 static int host_pipeline(ethcnn_ctx* c, int w, int h, int nframes, int qp, Fill fill, Drain drain) {
     FrameGeom g;
