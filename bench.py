@@ -211,6 +211,7 @@ def main():
             "stages_ms_per_step": {k: v / 3.0 for k, v in st_all["ms"].items()},
             "stages_note": ("each stage alone on one stream (ethcnn_set_pass_pipeline off), 3 untimed steps; in the timed region the "
                             "tile stage of step i+1 runs beside FC1 of step i, so ms_per_step < the sum of these"),
+            "stages_frac_of_f32_mfma_peak": stage_fracs({k: v / 3.0 for k, v in st_all["ms"].items()}, ctus_per_step),
             "kernel_ms_per_step": kernel_ms,
             "whole_path_tflops": 2.0 * MAC_PER_CTU * total_ctus / elapsed / 1e12,
             "whole_path_frac_of_f32_mfma_peak": 2.0 * MAC_PER_CTU * total_ctus / elapsed / 1e12 / PEAK_F32_MFMA_TFLOPS / world,
@@ -221,6 +222,7 @@ def main():
         if ldp:
             result.pop("whole_path_tflops", None)  # MAC_PER_CTU is the All-Intra path's
             result.pop("whole_path_frac_of_f32_mfma_peak", None)
+            result.pop("stages_frac_of_f32_mfma_peak", None)
             result["roofline"]["note"] = ("latency-bound call (one frame, %d CTUs): the serial K chain of FC1 sets the "
                                           "launch time, not the MFMA rate; stage 'heads' = k_lstm_cell + k_lstm_heads" % nctu)
             result["config"]["sharding"] = "none (lock-step with the encoder): replicas only"
@@ -380,6 +382,13 @@ class YuvFile:
         import shutil
         shutil.rmtree(self.dir, ignore_errors=True)
         return False
+
+
+def stage_fracs(stage_ms, ctus):
+    """fraction of the fp32-MFMA peak each MFMA stage reaches alone on the GPU (algorithmic FLOP of the stage / its time):
+    trunk 279,552 MAC, FC1 1,204,224, heads 68,373 per CTU"""
+    mac = {"trunk": 279552, "fc1": 1204224, "heads": 68373}
+    return {k: (2.0 * m * ctus / (stage_ms[k] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS) for k, m in mac.items() if stage_ms.get(k)}
 
 
 def host_scopes(ctx, luma, W, H, NF, QP, yuv):
