@@ -71,21 +71,6 @@ struct HeadsParams {
     const float* b3[3];
 };
 
-// where the gate predicates of a pass live: chunk(c) = 1024-CTU sub-batch of the frame holding pass CTU c, counted from
-// the chunk of the pass's first CTU (video_to_cu_depth.py:61-73).  32-bit arithmetic with a float reciprocal (+-1 fix-up)
-// instead of two 64-bit divisions per wave.
-struct GateIndex {
-    int nctu, cpf, r0, c0;  // CTUs per frame, chunks per frame, ctu0 % nctu, chunk of ctu0 within its frame
-    float inv_nctu;
-};
-__device__ __forceinline__ int gate_chunk(const GateIndex& gi, int ctu) {
-    const int u = gi.r0 + ctu;  // < 2^24: exact in float
-    int f = (int)((float)u * gi.inv_nctu);
-    if (f * gi.nctu > u) --f;
-    if ((f + 1) * gi.nctu <= u) ++f;
-    return f * gi.cpf + (u - f * gi.nctu) / kSubBatch - gi.c0;
-}
-
 // compile-time description of head H: 0/1/2 -> (n1, n2, n3) = (64,48,1) / (128,96,4) / (256,192,16)
 template <int H>
 struct Hd {
@@ -306,12 +291,7 @@ void launch_heads(const Workspace& ws, const DeviceWeights& w, int n, float qn, 
         hp.w3[h] = w.fc3_w[h];
         hp.b3[h] = w.fc3_b[h];
     }
-    GateIndex gi;
-    gi.nctu = nctu;
-    gi.cpf = chunks_per_frame(nctu);
-    gi.r0 = (int)(ctu0 % nctu);
-    gi.c0 = gi.r0 / kSubBatch;
-    gi.inv_nctu = 1.0f / (float)nctu;
+    const GateIndex gi = make_gate_index(nctu, ctu0);
     const dim3 grid((n + 63) / 64, 3);
     hipLaunchKernelGGL(k_heads, grid, dim3(256), 0, s, ws.h1, hp, qn, n, gi, thr1, thr2, ws.h2, ws.logits, ws.raw, d_probs,
                        ws.flags);

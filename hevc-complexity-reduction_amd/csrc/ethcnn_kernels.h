@@ -54,4 +54,30 @@ void launch_lstm(const float* d_vec, const float* d_state_in, float* d_state_out
 
 int chunks_per_frame(int nctu);
 
+// where the gate predicates of a pass live: chunk(c) = 1024-CTU sub-batch of the frame holding pass CTU c, counted from
+// the chunk of the pass's first CTU (video_to_cu_depth.py:61-73).  32-bit arithmetic with a float reciprocal (+-1 fix-up)
+// instead of two 64-bit divisions per wave.
+struct GateIndex {
+    int nctu, cpf, r0, c0;  // CTUs per frame, chunks per frame, ctu0 % nctu, chunk of ctu0 within its frame
+    float inv_nctu;
+};
+__device__ __forceinline__ int gate_chunk(const GateIndex& gi, int ctu) {
+    const int u = gi.r0 + ctu;  // < 2^24: exact in float
+    int f = (int)((float)u * gi.inv_nctu);
+    if (f * gi.nctu > u) --f;
+    if ((f + 1) * gi.nctu <= u) ++f;
+    return f * gi.cpf + (u - f * gi.nctu) / kSubBatch - gi.c0;
+}
+
+inline GateIndex make_gate_index(int nctu, long ctu0) {
+    GateIndex gi;
+    gi.nctu = nctu;
+    gi.cpf = chunks_per_frame(nctu);
+    gi.r0 = (int)(ctu0 % nctu);
+    gi.c0 = gi.r0 / kSubBatch;
+    gi.inv_nctu = 1.0f / (float)nctu;
+    return gi;
+}
+
+
 }  // namespace ethcnn

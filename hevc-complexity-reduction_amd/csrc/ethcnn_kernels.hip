@@ -27,20 +27,15 @@ int chunks_per_frame(int nctu) { return (nctu + kSubBatch - 1) / kSubBatch; }
 
 // (k4: the fused FC2 + FC3 + sigmoid heads kernel lives in ethcnn_heads.hip)
 
-__device__ __forceinline__ long global_chunk(long gn, int nctu, int cpf) {
-    const long f = gn / nctu;
-    return f * cpf + (gn - f * nctu) / kSubBatch;
-}
-
 // =========================================================================== k5 ======
 // net_CNN.py:175  y32 = y32_tmp if any(y64 > thr1 over the fed sub-batch) else zeros
 // net_CNN.py:187  y16 = y16_tmp if any(y32 > thr2) else zeros      (uses the GATED y32)
 __global__ __launch_bounds__(256) void k5_gate(float* __restrict__ probs, const int* __restrict__ flags, int N,
-                                               int nctu, int cpf, long ctu0, float thr2) {
+                                               GateIndex gi, float thr2) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int i = idx / kNOut, j = idx % kNOut;
     if (i >= N || j == 0) return;
-    const long chunk = global_chunk(ctu0 + i, nctu, cpf) - global_chunk(ctu0, nctu, cpf);
+    const int chunk = gate_chunk(gi, i);
     const bool open32 = flags[2 * chunk] != 0;
     const bool open16 = open32 ? (flags[2 * chunk + 1] != 0) : (0.0f > thr2);
     if (j < 5 ? !open32 : !open16) probs[(size_t)i * kNOut + j] = 0.0f;
@@ -48,8 +43,8 @@ __global__ __launch_bounds__(256) void k5_gate(float* __restrict__ probs, const 
 
 void launch_gate(const Workspace& ws, int n, int nctu, long ctu0, float thr2, float* d_probs, hipStream_t s) {
     const long total = (long)n * kNOut;
-    hipLaunchKernelGGL(k5_gate, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_probs, ws.flags, n, nctu,
-                       chunks_per_frame(nctu), ctu0, thr2);
+    hipLaunchKernelGGL(k5_gate, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_probs, ws.flags, n,
+                       make_gate_index(nctu, ctu0), thr2);
 }
 
 }  // namespace ethcnn
