@@ -8,7 +8,12 @@ cu_depth.dat payload in HBM.  Default workload = BASELINE.json configs[2] at QP3
 north_star sets its target on); --workload picks another config (c2 = configs[1], ...).
 N > 1: frames shard across ranks with no data-path collective (weak scaling: every rank
 runs the same per-GPU workload on its own frames); torch.distributed is used only for the
-timing barrier and the max-over-ranks reduction.
+timing barrier and the max-over-ranks reduction.  `python bench.py --gpus N` launches its own
+N ranks (one per GPU, torch.distributed.run on 127.0.0.1) when it is not already running under
+torchrun, and REFUSES (non-zero exit) when fewer than N GPUs are visible: the printed `n_gpus`
+is always the number of GPUs that were measured.  N > 1 lines carry the same `roofline` and
+`cpu_baseline` objects plus the SHARDED host scopes (all ranks reading one 4:2:0 file / their own
+host memory at the same time: where host DRAM and PCIe contention decide).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline      dominant kernel = FC1 (77.6 % of the MACs): algorithmic FLOP / HIP-event
@@ -79,18 +84,24 @@ def main():
 
     import numpy as np
     import torch  # first: both torch and libethcnn bind libamdhip64.so.7 -> one HIP runtime in the process
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (libethcnn has no CPU fallback)")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_launch(args.gpus, torch.cuda.device_count())
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (libethcnn has no CPU fallback)")
+    if world != args.gpus:  # never print an n_gpus that is not what ran
+        raise SystemExit("bench.py: WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     # test hooks for exercising the multi-rank control flow on a ONE-GPU box (scripts/gpu_dist_smoke.sh):
     # BENCH_FORCE_DEVICE puts every rank on that device, BENCH_DIST_BACKEND=gloo replaces RCCL (which
     # refuses two ranks on one GPU).  Never set by the driver.
     if os.environ.get("BENCH_FORCE_DEVICE") is not None:
         local_rank = int(os.environ["BENCH_FORCE_DEVICE"])
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d has no GPU (%d visible): one rank per GPU" % (local_rank, torch.cuda.device_count()))
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dist = None
@@ -182,6 +193,11 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # collective side measurements (every rank takes part; never `value`): the sharded host scopes at N > 1
+    sharded = None
+    if dist is not None and not ldp and not args.no_host_scopes:
+        sharded = host_scopes_sharded(ctx, luma, W, H, NF, QP, rank, world, dist, backend, barrier)
+
     result = None
     if rank == 0:
         total_ctus = ctus_per_step * args.steps * world
@@ -200,14 +216,14 @@ def main():
             "data": "synthetic (seeded luma frames resident in HBM; seeded synthetic weights -- trained blobs absent from the reference)",
             "config": {"workload": wl["name"], "width": W, "height": H, "frames_per_gpu": NF, "qp": QP,
                        "ctus_per_step_per_gpu": ctus_per_step, "sharding": "frame ranges, no collective",
-                       "device": ctx.device_name, "host_affinity": numa},
-            "roofline": {"kernel": "FC1 stage = k_fc1_bulk / k_fc1_p3 (FC1 [N,2688]x[2688,448], v_mfma_f32_16x16x4_f32)",
+                       "device": ctx.device_name, "host_affinity": numa, "host_fill_threads_per_rank": ctx.host_threads},
+            "roofline": {"kernel": FC1_KERNEL_NOTE,
                          "bound": "mfma", "achieved": fc1_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": fc1_tflops / PEAK_F32_MFMA_TFLOPS, **pmc_traffic(args.workload),
                          "avg_launch_ms": fc1_ms, "launches_timed": st["timed"]["fc1"], "ctus_per_launch": ctus_per_launch,
                          "flop_per_ctu": FC1_FLOP_PER_CTU,
-                         "note": "timed inside the measured region, i.e. with the next step's CTU-load stage running beside it; "
-                                 "alone on the GPU the same launch takes stages_ms_per_step.fc1"},
+                         "note": "rank 0's launches, timed inside the measured region, i.e. with the next step's CTU-load stage "
+                                 "running beside them; alone on the GPU the same launch takes stages_ms_per_step.fc1"},
             "stages_ms_per_step": {k: v / 3.0 for k, v in st_all["ms"].items()},
             "stages_note": ("each stage alone on one stream (ethcnn_set_pass_pipeline off), 3 untimed steps; in the timed region the "
                             "tile stage of step i+1 runs beside FC1 of step i, so ms_per_step < the sum of these"),
@@ -219,6 +235,9 @@ def main():
                                "unit": "GB/s", "frac": tile_gbps / PEAK_HBM_GBPS, "avg_launch_ms": tile_ms,
                                "algorithmic_bytes_per_ctu": 4096},
         }
+        # N > 1: the CPU baseline is the same single-box measurement, on a shorter sample (the other ranks wait at the
+        # final barrier meanwhile); the per-GPU side measurements that need the GPU to themselves are N = 1 only
+        cpu_seconds = args.cpu_seconds if world == 1 else min(args.cpu_seconds, 8.0)
         if ldp:
             result.pop("whole_path_tflops", None)  # MAC_PER_CTU is the All-Intra path's
             result.pop("whole_path_frac_of_f32_mfma_peak", None)
@@ -226,15 +245,17 @@ def main():
             result["roofline"]["note"] = ("latency-bound call (one frame, %d CTUs): the serial K chain of FC1 sets the "
                                           "launch time, not the MFMA rate; stage 'heads' = k_lstm_cell + k_lstm_heads" % nctu)
             result["config"]["sharding"] = "none (lock-step with the encoder): replicas only"
-            if world == 1 and not args.no_cpu_baseline:
-                result["cpu_baseline"] = cpu_baseline_ldp(luma, W, H, QP, args.cpu_seconds)
+            if not args.no_cpu_baseline:
+                result["cpu_baseline"] = cpu_baseline_ldp(luma, W, H, QP, cpu_seconds)
             result["parity_first_frames_bit_exact"] = ldp_parity(ctx, luma, W, H, QP)
-        if not ldp and world == 1 and not (args.no_host_scopes and args.no_cpu_baseline):
+        if sharded is not None:
+            result["host_scopes"] = sharded
+        if not ldp and not (args.no_host_scopes and args.no_cpu_baseline):
             with YuvFile(luma, W, H) as yuv:
-                if not args.no_host_scopes:
+                if not args.no_host_scopes and world == 1:
                     result["host_scopes"] = host_scopes(ctx, luma, W, H, NF, QP, yuv)
                 if not args.no_cpu_baseline:
-                    result["cpu_baselines"] = cpu_baselines(luma, W, H, QP, args.cpu_seconds, yuv)
+                    result["cpu_baselines"] = cpu_baselines(luma, W, H, QP, cpu_seconds, yuv, full=(world == 1))
                     result["cpu_baseline"] = dict(result["cpu_baselines"][0])
         # sanity: the benchmark output is the real thing (first frame vs oracle), outside the timed region
         if not ldp:
@@ -247,9 +268,115 @@ def main():
     d_out.free()
     ctx.close()
     if dist is not None:
-        barrier()
+        if backend == "nccl":
+            dist.barrier(device_ids=[local_rank])
+        else:
+            dist.barrier()
         dist.destroy_process_group()
     return 0
+
+
+FC1_KERNEL_NOTE = "FC1 stage = k_fc1_bulk / k_fc1_p3 (FC1 [N,2688]x[2688,448], v_mfma_f32_16x16x4_f32)"
+
+
+def self_launch(ngpus, visible):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks ourselves (one per GPU), or refuse.  The line rank 0
+    prints goes to our stdout unchanged; our exit status is the launcher's."""
+    import socket
+    import subprocess
+    if visible < ngpus and os.environ.get("BENCH_FORCE_DEVICE") is None:
+        sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible on this node: refusing to print a line for GPUs that "
+                         "were not measured (run under torchrun with one rank per GPU, or lower --gpus)\n" % (ngpus, visible))
+        return 2
+    with socket.socket() as sk:  # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between the ranks needs it on these hosts
+    env.setdefault("OMP_NUM_THREADS", "1")             # torchrun's own default, said explicitly (no warning banner)
+    return subprocess.call(cmd, env=env)
+
+
+def host_scopes_sharded(ctx, luma, W, H, NF, QP, rank, world, dist, backend, barrier):
+    """N > 1 side measurements (never `value`), all ranks at once -- what a node really does with the reference's job:
+      S2 sharded: every rank pushes its own pageable host frames through its GPU at the same time (host DRAM + PCIe shared);
+      S3 sharded: ONE 4:2:0 file holding every rank's frames -> ONE cu_depth.dat, each rank preads its frame range and
+                  pwrites its slice (ethcnn_predict_yuv_shard) -- the multi-GPU form of 'Predicting Time'.
+    Rates are whole-job (sum over ranks / slowest rank's time), best of 3."""
+    import numpy as np
+    import shutil
+    import tempfile
+    import torch
+    nctu = ((W + 63) // 64) * ((H + 63) // 64)
+
+    def slowest(dt):
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    out = {"ranks": world, "fill_threads_per_rank": ctx.host_threads}
+    ctx.predict_luma(luma, W, H, NF, QP)  # warm the staging ring
+    best = 1e30
+    for _ in range(3):
+        barrier()
+        t0 = time.perf_counter()
+        ctx.predict_luma(luma, W, H, NF, QP)
+        best = min(best, slowest(time.perf_counter() - t0))
+    out["s2_host_to_host_ctus_per_s"] = world * NF * nctu / best
+    out["s2_h2d_gbps_total"] = world * NF * W * H / best / 1e9
+
+    # one shared file: rank 0 picks the directory (tmpfs when it has room), every rank writes its own frames into it
+    frame_bytes = W * H * 3 // 2
+    need = world * NF * frame_bytes + world * NF * nctu * 84 + (64 << 20)
+    box = [None]
+    if rank == 0:
+        for d in ("/dev/shm", tempfile.gettempdir()):
+            try:
+                sv = os.statvfs(d)
+                if sv.f_bavail * sv.f_frsize > need:
+                    box[0] = tempfile.mkdtemp(prefix="ethcnn_bench_", dir=d)
+                    break
+            except OSError:
+                pass
+    dist.broadcast_object_list(box, src=0)
+    if box[0] is None:
+        out["s3_note"] = "no file system with %.1f GB free for the shared YUV file: file scope skipped" % (need / 1e9)
+        return out
+    yuv, dat = os.path.join(box[0], "seq.yuv"), os.path.join(box[0], "cu_depth.dat")
+    try:
+        if rank == 0:
+            with open(yuv, "wb") as f:
+                f.truncate(world * NF * frame_bytes)
+            with open(dat, "wb") as f:
+                f.truncate(world * NF * nctu * 84)
+        barrier()
+        chroma = np.full(W * H // 2, 128, dtype=np.uint8).tobytes()
+        with open(yuv, "r+b") as f:
+            f.seek(rank * NF * frame_bytes)
+            for k in range(NF):
+                f.write(luma[k].tobytes())
+                f.write(chroma)
+        barrier()
+        f0, f1 = rank * NF, (rank + 1) * NF
+        ctx.predict_yuv_shard(yuv, W, H, QP, dat, f0, f1)
+        best = 1e30
+        for _ in range(3):
+            barrier()
+            t0 = time.perf_counter()
+            ctx.predict_yuv_shard(yuv, W, H, QP, dat, f0, f1)
+            best = min(best, slowest(time.perf_counter() - t0))
+        out["s3_file_to_file_ctus_per_s"] = world * NF * nctu / best
+        out["s3_luma_gbps_total"] = world * NF * W * H / best / 1e9
+        out["s3_file"] = "%d frames of %dx%d 4:2:0 (%.2f GB) in %s, one frame range per rank" % (world * NF, W, H, world * NF * frame_bytes / 1e9, os.path.dirname(box[0]))
+        barrier()
+    finally:
+        barrier()
+        if rank == 0:
+            shutil.rmtree(box[0], ignore_errors=True)
+    out["note"] = "best of 3, whole job: sum over ranks / slowest rank; every rank runs at the same time"
+    return out
 
 
 def pin_to_gpu_numa_node(device_name):
@@ -355,10 +482,24 @@ def pmc_traffic(workload):
     FETCH_SIZE is doubled (gfx950 under-counts wide coalesced reads by 2x, MI355X_MICROARCH.md)."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "fc1_traffic.json")))[workload]
+        # the committed PMC pass is only valid for the kernel source it was taken at: stamped with the git blob hash of
+        # ethcnn_dense.hip; a different kernel -> no number rather than a stale one (scripts/gpu_round.sh refreshes it)
+        now = git_blob_sha1(os.path.join(ROOT, "hevc-complexity-reduction_amd", "csrc", "ethcnn_dense.hip"))
+        if d.get("kernel_source_blob") != now:
+            return {"traffic": None, "traffic_note": "profiles/fc1_traffic.json was taken at ethcnn_dense.hip blob %s, the kernel "
+                                                     "is now %s: re-run scripts/gpu_round.sh" % (d.get("kernel_source_blob"), now)}
         return {"traffic": d["bytes_per_launch"], "traffic_unit": "B/launch",
-                "traffic_algorithmic": d["algorithmic_bytes_per_launch"], "traffic_source": d["source"]}
+                "traffic_algorithmic": d["algorithmic_bytes_per_launch"], "traffic_source": d["source"],
+                "traffic_kernel_source_blob": now}
     except Exception:
         return {"traffic": None}
+
+
+def git_blob_sha1(path):
+    """what `git hash-object <path>` prints (no git needed on the GPU box)"""
+    import hashlib
+    data = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
 
 
 class YuvFile:
@@ -442,7 +583,7 @@ def usable_host_cpus():
     return logical, usable, quota
 
 
-def cpu_baselines(luma, W, H, QP, target_seconds, yuv):
+def cpu_baselines(luma, W, H, QP, target_seconds, yuv, full=True):
     """CPU baselines on the host cores of this box, each on a bounded sample of the same workload
     (BASELINE.md section 4).  [0] is also reported as `cpu_baseline`:
       [0] B1/S1  oracle (C port of the reference's CPU path, OpenMP over CTUs), all USABLE cores (the cgroup CPU quota of
@@ -477,6 +618,9 @@ def cpu_baselines(luma, W, H, QP, target_seconds, yuv):
                 "sample": "%d pass(es) over %d frame(s) of %dx%d (%d CTUs), oracle/ethcnn_oracle.c canonical mode, OpenMP over the "
                           "CTUs of a frame group, %.1f s" % (reps, frames, W, H, n, dt)}
 
+    if not full:  # N > 1 lines: the all-cores oracle on a shorter sample only (rank 0; the other ranks are idle meanwhile)
+        out.append(timed_passes(min(NF, 10), target_seconds, "B1 oracle, all usable host cores", cores))
+        return out
     out.append(timed_passes(NF, budget["all"], "B1 oracle, all usable host cores", cores))
     # one thread: ~0.5 k CTU/s -> one frame is seconds of work; never more than one frame, one pass
     one = timed_passes(1, 0.0, "B1 oracle, 1 thread", 1)

@@ -4,7 +4,9 @@
 // Mirrors /root/reference/HM-16.5_Test_AI/bin/video_to_cu_depth.py (driver) around
 // net_CNN.py (network).  There is no CPU compute path in this library.
 #include <hip/hip_runtime.h>
+#if defined(__SSE2__)
 #include <emmintrin.h>
+#endif
 #include <sched.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -36,7 +38,8 @@ using namespace ethcnn;
 // the DMA engine then pulls every byte across the socket interconnect.
 struct NumaCpus {
     bool valid = false;
-    cpu_set_t set;
+    cpu_set_t set;  // the node's CPUs INTERSECTED with the affinity mask the process was started with (taskset, an
+                    // orchestrator's CPU set): threads are never moved onto CPUs the user excluded; empty -> no pinning
 };
 // runs the enclosed allocations / thread start-ups on the GPU's node, then puts the caller's affinity back
 class AffinityScope {
@@ -176,7 +179,8 @@ struct ethcnn_ctx {
     int last_parity = 0;     // of the last pass (debug_fetch reads its h1)
     int overlap = 1;         // 1 = pass pipeline on (tile stage on its own stream, beside FC1 of the previous pass);
                              // 0 = every stage on the main stream (ethcnn_set_pass_pipeline, env ETHCNN_OVERLAP=0)
-    int max_ctus = 131072;
+    int max_ctus = kMaxCtusPerPass;
+    int host_threads_opt = 0;  // ethcnn_options.host_threads (0 = automatic, see host_pool)
     int last_n = 0;  // CTUs of the last pass (debug_fetch)
     bool debug_capture = false;  // also store FC2 outputs, logits and ungated probabilities (1.7 KB/CTU of writes)
 
@@ -299,7 +303,10 @@ extern "C" int ethcnn_create(ethcnn_ctx** out, const ethcnn_options* opt) {
     if (!c) return set_err(nullptr, ETHCNN_ERR_NOMEM, "out of memory");
     c->device = dev;
     std::snprintf(c->devname, sizeof c->devname, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
-    if (opt && opt->max_ctus_per_pass > 0) c->max_ctus = std::max(1024, (opt->max_ctus_per_pass + 1023) / 1024 * 1024);
+    // the workspace is a whole number of 1024-CTU sub-batches, at most what the kernels' 32-bit offsets cover (ethcnn_spec.h)
+    if (opt && opt->max_ctus_per_pass > 0)
+        c->max_ctus = std::min(kMaxCtusPerPass, std::max(1024, (int)(((long long)opt->max_ctus_per_pass + 1023) / 1024 * 1024)));
+    if (opt && opt->host_threads > 0) c->host_threads_opt = opt->host_threads;
     if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->copy_in, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->copy_out, hipStreamNonBlocking) != hipSuccess ||
@@ -347,6 +354,14 @@ extern "C" int ethcnn_create(ethcnn_ctx** out, const ethcnn_options* opt) {
                         if (*end == '-') { q = end + 1; b = std::strtol(q, &end, 10); }
                         for (long k = a; k <= b && k < CPU_SETSIZE; ++k) { CPU_SET((int)k, &c->numa.set); ++n; }
                         q = (*end == ',') ? end + 1 : end;
+                    }
+                    cpu_set_t own;  // what this process may use: never pin outside it
+                    if (n > 0 && sched_getaffinity(0, sizeof own, &own) == 0) {
+                        n = 0;
+                        for (int k = 0; k < CPU_SETSIZE; ++k) {
+                            if (CPU_ISSET(k, &c->numa.set) && !CPU_ISSET(k, &own)) CPU_CLR(k, &c->numa.set);
+                            if (CPU_ISSET(k, &c->numa.set)) ++n;
+                        }
                     }
                     c->numa.valid = n > 0;
                     if (c->numa.valid) {
@@ -765,13 +780,38 @@ static int usable_cpus() {
     return n;
 }
 
+// Fill threads of ONE context when `local_workers` contexts (one process per GPU) share the node's CPU budget
+// (`usable`: the cgroup quota / logical count; <= 0 = probe it): the budget is divided, never multiplied -- 8 workers under
+// a 16-core quota get 2 threads each, not 8 x 16 runnable threads on 16 cores (the oversubscription that collapses any
+// OpenMP-style pool under CFS throttling: 256 threads ran 5x slower than 16 on the GPU boxes).  A single worker takes
+// min(16, usable, logical / 2): more than 16 fill threads measured slower (scripts/s3_threads.py).
+extern "C" int ethcnn_host_thread_budget(int local_workers, int usable) {
+    if (usable <= 0) usable = std::min(usable_cpus(), std::max(1, (int)std::thread::hardware_concurrency() / 2));
+    const int w = std::max(1, local_workers);
+    return std::max(1, std::min(16, usable / w));
+}
+
+// how many predictor processes share this node: the launcher says (ETHCNN_LOCAL_WORKERS; predict_sharded sets it for its
+// workers), else torchrun's LOCAL_WORLD_SIZE, else one
+static int local_workers() {
+    for (const char* name : {"ETHCNN_LOCAL_WORKERS", "LOCAL_WORLD_SIZE"})
+        if (const char* e = std::getenv(name))
+            if (std::atoi(e) > 0) return std::atoi(e);
+    return 1;
+}
+
 static HostPool* host_pool(ethcnn_ctx* c) {
     if (!c->pool) {
-        int nt = std::min(16, std::max(1, std::min(usable_cpus(), (int)std::thread::hardware_concurrency() / 2)));
-        if (const char* e = std::getenv("ETHCNN_HOST_THREADS")) nt = std::max(1, std::min(32, std::atoi(e)));  // 64+ threads measured slower (scripts/s3_threads.py)
+        int nt = ethcnn_host_thread_budget(local_workers(), 0);
+        if (c->host_threads_opt > 0) nt = std::min(32, c->host_threads_opt);
+        if (const char* e = std::getenv("ETHCNN_HOST_THREADS")) nt = std::max(1, std::min(32, std::atoi(e)));  // explicit override
         c->pool = new HostPool(nt, c->numa);
     }
     return c->pool;
+}
+
+extern "C" int ethcnn_host_threads(ethcnn_ctx* c) {  // the pool size this context uses (creates the pool)
+    return c ? host_pool(c)->size() : ETHCNN_ERR_ARG;
 }
 
 // Copy into page-locked staging memory with non-temporal stores: no read-for-ownership of the destination lines and no
@@ -779,6 +819,10 @@ static HostPool* host_pool(ethcnn_ctx* c) {
 // previous group at the same time (profiles/r02_host_copy.txt: 56 GB/s through the fill | H2D pipeline against 49 GB/s
 // with memcpy; the DMA engine alone moves 57.5).
 static void nt_copy(uint8_t* dst, const uint8_t* src, size_t n) {
+#if !defined(__SSE2__)
+    std::memcpy(dst, src, n);  // no streaming stores on this host ISA: plain copy, same result
+    return;
+#else
     const size_t head = std::min(n, (size_t)(-(uintptr_t)dst & 15));
     if (head) std::memcpy(dst, src, head);
     dst += head; src += head; n -= head;
@@ -793,6 +837,7 @@ static void nt_copy(uint8_t* dst, const uint8_t* src, size_t n) {
     }
     if (i < n) std::memcpy(dst + i, src + i, n - i);
     _mm_sfence();
+#endif
 }
 
 template <typename Fn>

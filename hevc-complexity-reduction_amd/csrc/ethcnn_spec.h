@@ -18,6 +18,14 @@ constexpr int kNVec = 448;   // FC1 outputs: 64 | 128 | 256
 constexpr int kNFc2 = 336;   // FC2 outputs: 48 | 96 | 192
 constexpr int kSubBatch = 1024;
 constexpr size_t kBlobFloats = 1288210;
+// Largest pass (CTUs) the kernels address: they use 32-bit BYTE offsets into the per-pass buffers (trunk: group image
+// offset grp * kNFeat * 64; FC1: buffer resource of M * kNVec * 4 bytes; heads: 4 * (ctu * kNVec + ..); gate_chunk: u < 2^24).
+// ethcnn_create clamps ethcnn_options.max_ctus_per_pass to this; a longer sequence simply takes more passes.
+constexpr int kMaxCtusPerPass = 131072;
+static_assert((long long)(kMaxCtusPerPass / 16) * kNFeat * 16 * 4 < (1ll << 31), "trunk: group image byte offset must fit int32");
+static_assert((long long)kMaxCtusPerPass * kNVec * 4 < (1ll << 31), "FC1 / heads: h1 byte offsets must fit int32");
+static_assert((long long)kMaxCtusPerPass * kNOut * 4 < (1ll << 31), "heads / gate: probability byte offsets must fit int32");
+static_assert(2 * kMaxCtusPerPass < (1 << 24), "gate_chunk: r0 + ctu must be exact in float");
 
 // branches in feature order S, M, L (net_CNN.py:150 concat order)
 enum Branch { kS = 0, kM = 1, kL = 2 };

@@ -29,7 +29,8 @@ class EthCnnError(RuntimeError):
 
 
 class Options(ctypes.Structure):
-    _fields_ = [("device", ctypes.c_int), ("max_ctus_per_pass", ctypes.c_int), ("reserved", ctypes.c_int * 6)]
+    _fields_ = [("device", ctypes.c_int), ("max_ctus_per_pass", ctypes.c_int), ("host_threads", ctypes.c_int),
+                ("reserved", ctypes.c_int * 5)]
 
 
 class StageTimes(ctypes.Structure):
@@ -93,6 +94,8 @@ SIGNATURES = {
     "ethcnn_set_debug_capture": (_i, [_vp, _i]),
     "ethcnn_ckpt_read_index": (_i, [_cp, ctypes.POINTER(CkptEntry), _i, ctypes.POINTER(_i), ctypes.c_char_p, _sz]),
     "ethcnn_crc32c_masked": (ctypes.c_uint32, [_vp, _sz]),
+    "ethcnn_host_thread_budget": (_i, [_i, _i]),
+    "ethcnn_host_threads": (_i, [_vp]),
 }
 
 _lib = None
@@ -178,6 +181,11 @@ def crc32c_masked(data):
     return load_library().ethcnn_crc32c_masked(b, len(b))
 
 
+def host_thread_budget(local_workers=1, usable_cpus=0):
+    """staging-fill threads ONE predictor process starts when `local_workers` of them share the node (no device needed)"""
+    return load_library().ethcnn_host_thread_budget(int(local_workers), int(usable_cpus))
+
+
 def ctus_per_frame(width, height):
     return ((width + 63) // 64) * ((height + 63) // 64)
 
@@ -211,9 +219,9 @@ class DeviceBuffer(object):
 class EthCnn(object):
     """One predictor context on one GPU (the reference's tf.Session + Saver + graph)."""
 
-    def __init__(self, device=0, max_ctus_per_pass=0):
+    def __init__(self, device=0, max_ctus_per_pass=0, host_threads=0):
         self.lib = load_library()
-        opt = Options(device=int(device), max_ctus_per_pass=int(max_ctus_per_pass))
+        opt = Options(device=int(device), max_ctus_per_pass=int(max_ctus_per_pass), host_threads=int(host_threads))
         h = ctypes.c_void_p()
         rc = self.lib.ethcnn_create(ctypes.byref(h), ctypes.byref(opt))
         if rc:
@@ -248,6 +256,14 @@ class EthCnn(object):
         buf = ctypes.create_string_buffer(128)
         self._chk(self.lib.ethcnn_device_name(self.h, buf, 128))
         return buf.value.decode()
+
+    @property
+    def host_threads(self):
+        """staging-fill threads of this context (the node budget divided by the local worker count)"""
+        n = self.lib.ethcnn_host_threads(self.h)
+        if n < 0:
+            self._chk(n)
+        return n
 
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)

@@ -17,7 +17,10 @@ step + heads + gates on the GPU).  Differences from the reference, none in the n
     encoder's critical path.  state.dat is still written every frame for protocol compatibility -- AFTER
     cu_depth.dat and pred_end.sig, while HM is already encoding -- and it is still the source whenever
     the resident state cannot be the right one (daemon restart, a frame out of sequence, a state.dat
-    somebody else replaced: size / mtime are checked);
+    somebody else replaced: inode / size / mtime are checked).  A sidecar `state.dat.idx` ("<i_frame> <w> <h>", written
+    after state.dat) says which frame the file belongs to: a restarted daemon that finds the state of the WRONG frame
+    there (the previous daemon died between pred_end.sig and the state write) refuses it instead of silently feeding
+    frame i-1's state to frame i+1; a state.dat without sidecar (the reference daemon's) is taken as it is;
   * resi.yuv is read straight into pinned host memory (DMA-able without a staging copy);
   * missing trained CNN blob (model_LDP_2000000_qp22~37.dat.data is not in the reference repo):
     ETHCNN_SYNTHETIC_SEED=<n> opts into seeded synthetic CNN weights, otherwise it is an error.
@@ -44,6 +47,7 @@ MINI_BATCH_SIZE = 1024    # :118 (gate scope; applied inside the library)
 COMPLETE_FILE = 'complete.dat'
 YUV_FILE = 'resi.yuv'
 STATE_FILE = 'state.dat'
+STATE_INDEX_SUFFIX = '.idx'   # ours: "<i_frame> <w> <h>" of the frame whose output state state.dat holds
 SAVE_FILE = 'cu_depth.dat'
 COMMAND_FILE = 'command.dat'
 START_FILE = 'pred_start.sig'
@@ -97,9 +101,19 @@ def get_images_from_one_file(yuv_file, frame_width, frame_height, CUwidth=IMAGE_
     return luma.reshape(frame_height, frame_width), _e.ctus_per_frame(frame_width, frame_height)
 
 
-def get_state_in_from_one_file(state_file, num_vectors, i_frame):
-    """:103-112: zeros for i_frame <= 1 (returned as None = zeros inside the library)."""
+def get_state_in_from_one_file(state_file, num_vectors, i_frame, geometry=None):
+    """:103-112: zeros for i_frame <= 1 (returned as None = zeros inside the library).  When the sidecar written by
+    this daemon is present it must name frame i_frame - 1 (and `geometry` = (w, h) when given): a stale state is an
+    error, never a silent wrong recurrence."""
     if i_frame > 1:
+        try:
+            with open(state_file + STATE_INDEX_SUFFIX, 'r') as f:
+                tag = [int(t) for t in f.read().split()]
+        except (IOError, OSError, ValueError):
+            tag = None  # no sidecar: somebody else's state.dat (the reference daemon writes none) -> trusted as there
+        if tag is not None and (len(tag) != 3 or tag[0] != i_frame - 1 or (geometry is not None and tuple(tag[1:]) != tuple(geometry))):
+            raise IOError('%s holds the state after frame %s, frame %d needs the state after frame %d'
+                          % (state_file, tag[:1] or '?', i_frame, i_frame - 1))
         want = num_vectors * LSTM_DEPTH * 2 * VECTOR_LENGTH
         state_in = np.fromfile(state_file, dtype=np.float32, count=want)
         if state_in.size != want:
@@ -119,7 +133,7 @@ def predict_cu_depth(ctx, luma, frame_width, frame_height, state_in, qp_seq, i_f
 def _file_sig(path):
     try:
         st = os.stat(path)
-        return st.st_size, st.st_mtime_ns
+        return st.st_ino, st.st_size, st.st_mtime_ns  # inode: a same-size replacement inside one timestamp tick is still seen
     except OSError:
         return None
 
@@ -131,7 +145,7 @@ def _write_atomic(path, arr):
     os.rename(tmp, path)
 
 
-def save_cu_depth_and_state(depth_out, state_out, save_file, state_file, end_file, num_vectors):
+def save_cu_depth_and_state(depth_out, state_out, save_file, state_file, end_file, num_vectors, tag=None):
     """:131-145 writes state.dat, cu_depth.dat, then the (empty) ending signal.  Here cu_depth.dat and the ending
     signal come FIRST (they are what HM waits for) and state.dat is refreshed afterwards, while HM is already
     encoding: `state_out` may be a callable that fetches the state from the GPU at that point.  Returns the state."""
@@ -140,7 +154,17 @@ def save_cu_depth_and_state(depth_out, state_out, save_file, state_file, end_fil
     open(end_file, 'wb').close()
     if callable(state_out):
         state_out = state_out()
+    if tag is not None:  # (i_frame, w, h): the old sidecar goes first, the new one appears only behind the new state
+        try:
+            os.remove(state_file + STATE_INDEX_SUFFIX)
+        except OSError:
+            pass
     _write_atomic(state_file, state_out)
+    if tag is not None:
+        tmp = '%s%s.tmp.%d' % (state_file, STATE_INDEX_SUFFIX, os.getpid())
+        with open(tmp, 'w') as f:
+            f.write('%d %d %d\n' % tuple(tag))
+        os.rename(tmp, state_file + STATE_INDEX_SUFFIX)
     return state_out
 
 
@@ -176,7 +200,7 @@ def serve(workdir='.', max_frames=None, idle_timeout=None, poll_s=2e-4, device=0
             print('Python: predictor initialized on %s.' % ctx.device_name)
         n_frame_total, qp_seq = 0, 0
         last_key, state_sig = None, None   # (w, h, i_frame) of the resident state; (size, mtime_ns) of the state.dat we wrote
-        pinned, pinned_probs = None, None
+        pinned, pinned_probs = None, None  # capacities tracked separately: 65x65 has fewer pixels but more CTUs than 128x64
         idle_since = time.time()
         while max_frames is None or n_frame_total < max_frames:
             if not os.path.isfile(p(START_FILE)):
@@ -195,21 +219,25 @@ def serve(workdir='.', max_frames=None, idle_timeout=None, poll_s=2e-4, device=0
                 if verbose:
                     print('Set QP = %d' % qp_seq)
                     print('LSTM model loaded (%s).' % name)
-            if pinned is None or pinned.size < frame_width * frame_height:
+            need_px, need_pr = frame_width * frame_height, _e.ctus_per_frame(frame_width, frame_height) * 21
+            if pinned is None or pinned.size < need_px or pinned_probs.size < need_pr:
+                need_px = max(need_px, 0 if pinned is None else pinned.size)
+                need_pr = max(need_pr, 0 if pinned_probs is None else pinned_probs.size)
                 ctx.free_host_buffers()
-                pinned = ctx.host_buffer(frame_width * frame_height)
-                pinned_probs = ctx.host_buffer(_e.ctus_per_frame(frame_width, frame_height) * 21 * 4).view(np.float32)
+                pinned = ctx.host_buffer(need_px)
+                pinned_probs = ctx.host_buffer(need_pr * 4).view(np.float32)
             luma, num_vectors = get_images_from_one_file(p(YUV_FILE), frame_width, frame_height, IMAGE_SIZE, into=pinned)
             # the state of frame i_frame - 1 is resident in HBM when this daemon produced it for this geometry and the
             # state.dat it wrote then is still the one on disk; anything else goes through the file, as in the reference
             resident = i_frame > 1 and last_key == (frame_width, frame_height, i_frame - 1) and state_sig == _file_sig(p(STATE_FILE))
-            state_in = None if (resident or i_frame <= 1) else get_state_in_from_one_file(p(STATE_FILE), num_vectors, i_frame)
+            state_in = None if (resident or i_frame <= 1) else get_state_in_from_one_file(p(STATE_FILE), num_vectors, i_frame,
+                                                                                           (frame_width, frame_height))
             if state_in is not None:
                 state_in = np.asarray(state_in, dtype=np.float32).reshape(num_vectors, 2, VECTOR_LENGTH)
             depth_out = ctx.ldp_step(luma, frame_width, frame_height, qp_seq, i_frame, state_in,
                                      probs_out=pinned_probs[:num_vectors * 21].reshape(num_vectors, 21))
             save_cu_depth_and_state(depth_out, lambda: ctx.ldp_get_state(frame_width, frame_height), p(SAVE_FILE),
-                                    p(STATE_FILE), p(END_FILE), num_vectors)
+                                    p(STATE_FILE), p(END_FILE), num_vectors, tag=(i_frame, frame_width, frame_height))
             last_key, state_sig = (frame_width, frame_height, i_frame), _file_sig(p(STATE_FILE))
             n_frame_total += 1
             idle_since = time.time()

@@ -58,8 +58,11 @@ def restore_model(ctx, qp_seq, model_dir='.'):
     return 'synthetic(seed=%s)' % seed
 
 
-def _shard_worker(device, yuv_file, width, height, qp_seq, out_path, f0, f1, thr):
-    """One process per GPU: own context, own frame range, pwrite into out_path."""
+def _shard_worker(device, yuv_file, width, height, qp_seq, out_path, f0, f1, thr, nworkers=1):
+    """One process per GPU: own context, own frame range, pwrite into out_path.
+    The node's host-CPU budget is shared: every worker starts budget / nworkers staging-fill threads
+    (ethcnn_host_thread_budget), not a full pool each."""
+    os.environ['ETHCNN_LOCAL_WORKERS'] = str(max(1, int(nworkers)))
     ctx = _e.EthCnn(device=device)
     ctx.set_thresholds(*thr)
     restore_model(ctx, qp_seq)
@@ -78,12 +81,12 @@ def predict_sharded(yuv_file, width, height, qp_seq, save_file, devices):
     sharding.presize_output(tmp, n_frames, width, height)
     mpctx = mp.get_context('spawn')
     procs = []
-    for g, dev in enumerate(devices):
-        f0, f1 = sharding.frame_range(n_frames, len(devices), g)
-        if f1 > f0:
-            p = mpctx.Process(target=_shard_worker, args=(dev, yuv_file, width, height, qp_seq, tmp, f0, f1, thr))
-            p.start()
-            procs.append(p)
+    ranges = [(dev,) + sharding.frame_range(n_frames, len(devices), g) for g, dev in enumerate(devices)]
+    ranges = [r for r in ranges if r[2] > r[1]]
+    for dev, f0, f1 in ranges:
+        p = mpctx.Process(target=_shard_worker, args=(dev, yuv_file, width, height, qp_seq, tmp, f0, f1, thr, len(ranges)))
+        p.start()
+        procs.append(p)
     ok = True
     for p in procs:
         p.join()

@@ -51,9 +51,12 @@ enum {
 
 typedef struct ethcnn_options {
     int device;            /* HIP device ordinal (default 0)                                 */
-    int max_ctus_per_pass; /* workspace size in CTUs; 0 = default (131072). Frames are never
-                              split across passes unless a single frame exceeds it.          */
-    int reserved[6];
+    int max_ctus_per_pass; /* workspace size in CTUs; 0 = default = maximum (131072: what the
+                              kernels' 32-bit offsets cover; larger values are clamped). Frames
+                              are never split across passes unless a single frame exceeds it. */
+    int host_threads;      /* staging-fill threads of the host / file entry points; 0 = automatic:
+                              ethcnn_host_thread_budget(local workers, usable CPUs)            */
+    int reserved[5];
 } ethcnn_options;
 
 /* ---- lifecycle (replaces tf.Session()/Saver construction, video_to_cu_depth.py:22-29) */
@@ -148,6 +151,13 @@ int ethcnn_ldp_get_state(ethcnn_ctx* ctx, float* state_out, size_t nfloats /* nc
  * the context is destroyed are freed with it. */
 int ethcnn_host_alloc(ethcnn_ctx* ctx, size_t bytes, void** out);
 int ethcnn_host_free(ethcnn_ctx* ctx, void* p);
+
+/* ---- host budget (multi-GPU): one process per GPU, and every process fills its pinned staging ring with a
+ *      pool of host threads.  The node's CPU budget (cgroup quota, else logical CPUs / 2) is DIVIDED by the number of
+ *      predictor processes on the node (env ETHCNN_LOCAL_WORKERS, else torchrun's LOCAL_WORLD_SIZE, else 1), capped at 16.
+ *      ethcnn_host_thread_budget is pure (no context, no device): usable <= 0 probes the box. */
+int ethcnn_host_thread_budget(int local_workers, int usable_cpus);
+int ethcnn_host_threads(ethcnn_ctx* ctx); /* the pool size this context uses */
 
 /* ---- device plumbing for callers without a HIP binding (ctypes, cgo, JNI ...) */
 int ethcnn_device_alloc(ethcnn_ctx* ctx, size_t bytes, void** out);

@@ -131,3 +131,59 @@ def test_native_c_tool_builds_and_fails_loudly(pkg, tmp_path):
     if not has_gpu:
         r = subprocess.run([tool, "x.yuv", "64", "64", "32"], capture_output=True, text=True, cwd=str(tmp_path))
         assert r.returncode == 1 and "no CPU fallback" in r.stderr
+
+
+def test_host_thread_budget_is_per_node_not_per_worker(pkg):
+    """one predictor process per GPU, each with a staging-fill pool.  The node's CPU budget is DIVIDED by the
+    local worker count: 8 workers under the GPU boxes' 16-core quota start <= 16 fill threads in total (they started
+    8 x 16 = 128 before), every worker keeps at least one, and a lone worker never takes more than 16."""
+    b = pkg.ethcnn.host_thread_budget
+    for usable in (1, 2, 8, 16, 24, 64, 256):
+        for workers in (1, 2, 3, 4, 8):
+            per = b(workers, usable)
+            assert 1 <= per <= 16
+            assert workers * per <= max(usable, workers), (workers, usable, per)
+    assert [b(w, 16) for w in (1, 2, 4, 8)] == [16, 8, 4, 2]
+    assert b(8, 16) * 8 <= 16
+    assert b(1, 256) == 16 and b(8, 256) == 16
+    assert b(1) >= 1  # usable <= 0: probes this box (cgroup quota, logical CPUs / 2)
+
+
+def test_shard_workers_are_told_how_many_share_the_node(pkg, monkeypatch):
+    """predict_sharded hands every worker the number of workers it started (-> ETHCNN_LOCAL_WORKERS -> the budget above)."""
+    import inspect
+    src = inspect.getsource(pkg.video_to_cu_depth.predict_sharded)
+    assert "len(ranges)" in src
+    seen = {}
+
+    class Fake(object):
+        def __init__(self, device=0):
+            seen["workers"] = os.environ.get("ETHCNN_LOCAL_WORKERS")
+            raise RuntimeError("stop here")
+
+    monkeypatch.setattr(pkg.video_to_cu_depth._e, "EthCnn", Fake)
+    monkeypatch.delenv("ETHCNN_LOCAL_WORKERS", raising=False)
+    with pytest.raises(RuntimeError, match="stop here"):
+        pkg.video_to_cu_depth._shard_worker(0, "x.yuv", 64, 64, 32, "o.dat", 0, 1, (0.5, 0.5), 8)
+    assert seen["workers"] == "8"
+    monkeypatch.delenv("ETHCNN_LOCAL_WORKERS", raising=False)
+
+
+def test_max_ctus_per_pass_is_bounded_by_the_kernels_32_bit_offsets():
+    """the kernels address a pass with 32-bit byte offsets; the bound is a compile-time contract."""
+    spec = open(os.path.join(ROOT, "hevc-complexity-reduction_amd", "csrc", "ethcnn_spec.h")).read()
+    m = re.search(r"constexpr int kMaxCtusPerPass = (\d+);", spec)
+    assert m and int(m.group(1)) == 131072
+    n = int(m.group(1))
+    assert (n // 16) * 2688 * 16 * 4 < 2 ** 31 and n * 448 * 4 < 2 ** 31 and 2 * n < 2 ** 24
+    api = open(os.path.join(ROOT, "hevc-complexity-reduction_amd", "csrc", "ethcnn_api.cpp")).read()
+    assert "std::min(kMaxCtusPerPass" in api
+
+
+def test_bench_refuses_without_gpu_or_with_mismatched_world(tmp_path):
+    """bench.py never prints a line for GPUs that were not measured: no GPU -> non-zero; WORLD_SIZE != --gpus -> non-zero."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by tests/test_gpu_bench_contract.py")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True)
+    assert r.returncode != 0 and not any(l.startswith("{") for l in r.stdout.splitlines())

@@ -1,0 +1,58 @@
+"""GPU box (ONE MI355X visible): the launch contract of bench.py.
+
+  * `python bench.py --gpus 2` on a 1-GPU box must exit non-zero with a clear message -- never a line whose n_gpus is not what ran;
+  * the N > 1 control flow (self-launch through torch.distributed.run, barriers, max-over-ranks, sharded host scopes, rank-0 JSON
+    with `roofline` + `cpu_baseline`) is exercised by two ranks sharing GPU 0 over gloo through the PLAIN command (test hooks
+    BENCH_FORCE_DEVICE / BENCH_DIST_BACKEND; RCCL refuses two ranks on one device).  The numbers of that run mean nothing."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(kw)
+    return env
+
+
+def test_more_gpus_than_visible_is_refused():
+    import torch
+    n = torch.cuda.device_count()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 1)], capture_output=True, text=True,
+                       env=_env(), timeout=300)
+    assert r.returncode != 0
+    assert "only %d GPU(s) visible" % n in r.stderr
+    assert not any(l.startswith("{") for l in r.stdout.splitlines())
+
+
+def test_world_size_mismatch_is_refused():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       env=_env(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE (1) != --gpus (2)" in r.stderr
+
+
+def test_two_ranks_through_the_plain_command():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c2", "--steps", "3", "--warmup", "1",
+                        "--ramp-ms", "20", "--cpu-seconds", "2"], capture_output=True, text=True,
+                       env=_env(BENCH_FORCE_DEVICE="0", BENCH_DIST_BACKEND="gloo"), timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
+    assert d["roofline"]["frac"] > 0 and d["roofline"]["bound"] == "mfma"
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+    hs = d["host_scopes"]
+    assert hs["ranks"] == 2 and hs["s2_host_to_host_ctus_per_s"] > 0 and hs["s3_file_to_file_ctus_per_s"] > 0
+    # the two ranks shared the node's host budget
+    import importlib
+    sys.path.insert(0, ROOT)
+    pkg = importlib.import_module("hevc-complexity-reduction_amd")
+    assert hs["fill_threads_per_rank"] == pkg.ethcnn.host_thread_budget(2)
+    assert d["parity_first_frame_bit_exact"] is True

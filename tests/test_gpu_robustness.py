@@ -166,17 +166,18 @@ def test_ldp_calls_between_pipelined_passes(pkg, oracle):
     blob = oracle.synth_blob(3, 1.0)
     c = pkg.EthCnn(device=0)
     c.load_blob(blob)
-    w, h = 1280, 720
-    luma = rng.integers(0, 256, size=(4, h, w), dtype=np.uint8)
+    w, h, nf = 1280, 720, 36   # 36 x 240 = 8640 CTUs per call: above the 8192-CTU threshold, so the tile stage of every
+                               # call really runs on the side stream (4 frames = 960 CTUs never left the main stream)
+    luma = rng.integers(0, 256, size=(nf, h, w), dtype=np.uint8)
     resi = np.clip(np.rint(128 + rng.laplace(0, 6, size=(h, w))), 0, 255).astype(np.uint8)
-    want_ai = oracle.predict_frames(blob, luma, w, h, 4, 32, 0.5, 0.5, mode=0)
+    want_ai = oracle.predict_frames(blob, luma, w, h, nf, 32, 0.5, 0.5, mode=0)
     want_vec = oracle.resi_vectors(blob, resi, w, h, mode=0)
     d_in, d_out = c.alloc(luma.nbytes), c.alloc(want_ai.nbytes)
     d_in.upload(luma)
     for _ in range(3):
-        c.predict_luma_device(d_in, w, h, 4, 32, d_out)
+        c.predict_luma_device(d_in, w, h, nf, 32, d_out)
         vec = c.resi_vectors(resi, w, h)                    # serial section right behind an unsynchronised pipelined pass
-        c.predict_luma_device(d_in, w, h, 4, 32, d_out)     # and a pipelined pass right behind it
+        c.predict_luma_device(d_in, w, h, nf, 32, d_out)     # and a pipelined pass right behind it
         assert np.array_equal(vec.view(np.uint32), want_vec.view(np.uint32))
     c.synchronize()
     got = d_out.download(np.float32, want_ai.size).reshape(want_ai.shape)

@@ -46,3 +46,27 @@ def test_constants(pkg):
     d = pkg.resi_to_cu_depth_LDP
     assert (d.VECTOR_LENGTH, d.LSTM_DEPTH, d.MINI_BATCH_SIZE, d.NUM_EXT_FEATURES) == (448, 1, 1024, 2)
     assert d.MODEL_CNN_FILE == "model_LDP_2000000_qp22~37.dat"
+
+
+def test_state_sidecar_refuses_the_wrong_frame(pkg, tmp_path):
+    """state.dat is refreshed AFTER pred_end.sig.  A daemon that died in between leaves the state of frame
+    i-1 on disk while HM goes on to frame i+1; the sidecar this daemon writes makes that an error instead of a silently
+    wrong recurrence.  A state.dat without sidecar (the reference daemon's) is accepted as it is."""
+    d = pkg.resi_to_cu_depth_LDP
+    nv, w, h = 4, 128, 128
+    rng = np.random.default_rng(1)
+    st = rng.standard_normal((nv, 1, 2, 448)).astype(np.float32)
+    depth = rng.random((nv, 21)).astype(np.float32)
+    s = tmp_path / "state.dat"
+    d.save_cu_depth_and_state(depth, st, str(tmp_path / "cu_depth.dat"), str(s), str(tmp_path / "pred_end.sig"), nv, tag=(5, w, h))
+    assert (tmp_path / "state.dat.idx").read_text().split() == ["5", str(w), str(h)]
+    assert np.array_equal(d.get_state_in_from_one_file(str(s), nv, 6, (w, h)), st)   # the right frame
+    with pytest.raises(IOError, match="needs the state after frame 6"):
+        d.get_state_in_from_one_file(str(s), nv, 7, (w, h))                          # frame 6's state was never written
+    with pytest.raises(IOError):
+        d.get_state_in_from_one_file(str(s), nv, 6, (w, 64))                         # another geometry
+    (tmp_path / "state.dat.idx").unlink()
+    assert np.array_equal(d.get_state_in_from_one_file(str(s), nv, 7, (w, h)), st)   # no sidecar: trusted, as in the reference
+    # a callable state (fetched from the GPU after the ending signal) + tag: sidecar appears behind the state
+    d.save_cu_depth_and_state(depth, lambda: st * 2, str(tmp_path / "cu_depth.dat"), str(s), str(tmp_path / "pred_end.sig"), nv, tag=(6, w, h))
+    assert np.array_equal(d.get_state_in_from_one_file(str(s), nv, 7, (w, h)), st * 2)
