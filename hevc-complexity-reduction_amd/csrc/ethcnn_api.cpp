@@ -177,6 +177,10 @@ struct ethcnn_ctx {
     int tile_blocks = 256;   // blocks of the side-stream tile stage: one per CU (ETHCNN_TILE_BLOCKS)
     unsigned pass_idx = 0;   // parity selects the buffer set
     int last_parity = 0;     // of the last pass (debug_fetch reads its h1)
+    int fused = 0;           // 1 = big passes run FC1 + heads + gates as ONE launch (ethcnn_set_fused_launch, env ETHCNN_FUSED=1).
+                             // Off by default: measured equal-to-1 % slower than the separate launches
+    int gate_fold = 0;       // 1 = the heads launch applies the gates itself (sub-batch arrival counters); 0 = k5_gate launch behind it.
+                             // Off by default: measured equal (single pictures) to 0.4 % slower (C3) than the separate launch (env ETHCNN_GATE_FOLD=1)
     int overlap = 1;         // 1 = pass pipeline on (tile stage on its own stream, beside FC1 of the previous pass);
                              // 0 = every stage on the main stream (ethcnn_set_pass_pipeline, env ETHCNN_OVERLAP=0)
     int max_ctus = kMaxCtusPerPass;
@@ -253,6 +257,7 @@ static Workspace ws_view(const ethcnn_ctx* c, int p) {
     return v;
 }
 
+// `chunks`: gate sub-batches of the pass; the sync area also holds the sub-batch arrival counters and the fused launch's tile counters (sync_words)
 static int ensure_workspace(ethcnn_ctx* c, int n, int chunks) {
     Workspace& w = c->ws;
     const int cap = (n + 15) / 16 * 16;
@@ -272,13 +277,15 @@ static int ensure_workspace(ethcnn_ctx* c, int n, int chunks) {
         HIPCHK(c, hipMalloc((void**)&c->h1_1, (size_t)cap * kNVec * 4));
         w.cap = cap;
     }
-    if (chunks > w.flags_cap) {
+    const int words = sync_words(std::max(n, w.cap), chunks);
+    if (words > w.flags_cap) {
         if (w.flags) (void)hipFree(w.flags);  // hipFree synchronises the device: no pass in flight still uses them
         if (c->flags1) (void)hipFree(c->flags1);
         w.flags = c->flags1 = nullptr;
-        HIPCHK(c, hipMalloc((void**)&w.flags, (size_t)chunks * 2 * sizeof(int)));
-        HIPCHK(c, hipMalloc((void**)&c->flags1, (size_t)chunks * 2 * sizeof(int)));
-        w.flags_cap = chunks;
+        w.flags_cap = 0;
+        HIPCHK(c, hipMalloc((void**)&w.flags, (size_t)words * sizeof(int)));
+        HIPCHK(c, hipMalloc((void**)&c->flags1, (size_t)words * sizeof(int)));
+        w.flags_cap = words;
     }
     return 0;
 }
@@ -323,6 +330,8 @@ extern "C" int ethcnn_create(ethcnn_ctx** out, const ethcnn_options* opt) {
             }
     }
     if (const char* e = std::getenv("ETHCNN_OVERLAP")) c->overlap = std::atoi(e) != 0;  // development knob (A/B runs)
+    if (const char* e = std::getenv("ETHCNN_FUSED")) c->fused = std::atoi(e) != 0;      // development knob (A/B runs)
+    if (const char* e = std::getenv("ETHCNN_GATE_FOLD")) c->gate_fold = std::atoi(e) != 0;  // development knob (A/B runs)
     c->tile_blocks = prop.multiProcessorCount;
     {   // the GPU's NUMA node -> its CPU list (/sys/devices/system/node/nodeN/cpulist: "64-127,192-255"); ETHCNN_NUMA_BIND=0 opts out
         int node = -1;
@@ -609,6 +618,13 @@ extern "C" int ethcnn_set_pass_pipeline(ethcnn_ctx* c, int on) {
     return ETHCNN_OK;
 }
 
+extern "C" int ethcnn_set_fused_launch(ethcnn_ctx* c, int on) {
+    if (!c) return ETHCNN_ERR_ARG;
+    c->fused = (on == 1);       // takes effect with the next pass enqueued; results do not depend on it
+    c->gate_fold = (on == 2);
+    return ETHCNN_OK;
+}
+
 extern "C" int ethcnn_get_stage_times(ethcnn_ctx* c, ethcnn_stage_times* out) {
     if (!c || !out) return ETHCNN_ERR_ARG;
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -680,7 +696,8 @@ static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, lo
         const hipError_t le_ = hipGetLastError();                                                                  \
         if (le_ != hipSuccess) return set_err(c, ETHCNN_ERR_DEVICE, "launch of the %s stage failed: %s", name, hipGetErrorString(le_)); \
     } while (0)
-    { StageTimer t(c, ETHCNN_STAGE_TILE, n, s_tile); launch_tile(d_luma, g, ctu0, n, w, (int)nchunks * 2, s_tile, side_tile ? c->tile_blocks : 0); }
+    // the tile stage also zeroes the pass's sync area (gate predicates, sub-batch arrival counters, tile completion counters of the fused launch)
+    { StageTimer t(c, ETHCNN_STAGE_TILE, n, s_tile); launch_tile(d_luma, g, ctu0, n, w, sync_words(n, (int)nchunks), s_tile, side_tile ? c->tile_blocks : 0); }
     LAUNCH_OK("tile");
     if (side_tile) {
         HIPCHK(c, hipEventRecord(c->e_tile[p], s_tile));
@@ -689,13 +706,19 @@ static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, lo
     { StageTimer t(c, ETHCNN_STAGE_TRUNK); launch_trunk(w, c->dw, n, false, c->stream); }
     LAUNCH_OK("trunk");
     if (side_tile) HIPCHK(c, hipEventRecord(c->e_trunk[p], c->stream));
-    { StageTimer t(c, ETHCNN_STAGE_FC1, n); launch_fc1(w, c->dw, n, w.h1, c->stream); }
-    LAUNCH_OK("FC1");
     Workspace wv = w;
     if (!c->debug_capture) wv.h2 = wv.logits = wv.raw = nullptr;
-    { StageTimer t(c, ETHCNN_STAGE_HEADS); launch_heads(wv, c->dw, n, qn, g.nctu, ctu0, c->thr1, c->thr2, d_probs_pass, c->stream); }
-    { StageTimer t(c, ETHCNN_STAGE_GATE); launch_gate(w, n, g.nctu, ctu0, c->thr2, d_probs_pass, c->stream); }
-    LAUNCH_OK("heads / gate");
+    if (c->fused && fc1_heads_fusable(n)) {
+        // big pass: FC1, the heads and the gates are ONE launch (ethcnn_fused.hip); its time is booked under the FC1 stage
+        { StageTimer t(c, ETHCNN_STAGE_FC1, n); launch_fc1_heads(wv, c->dw, n, qn, g.nctu, ctu0, c->thr1, c->thr2, d_probs_pass, (int)nchunks, c->stream); }
+        LAUNCH_OK("fused FC1 + heads + gate");
+    } else {
+        { StageTimer t(c, ETHCNN_STAGE_FC1, n); launch_fc1(w, c->dw, n, w.h1, c->stream); }
+        LAUNCH_OK("FC1");
+        { StageTimer t(c, ETHCNN_STAGE_HEADS); launch_heads(wv, c->dw, n, qn, g.nctu, ctu0, c->thr1, c->thr2, d_probs_pass, c->stream, c->gate_fold ? (int)nchunks : 0); }
+        if (!c->gate_fold) { StageTimer t(c, ETHCNN_STAGE_GATE); launch_gate(w, n, g.nctu, ctu0, c->thr2, d_probs_pass, c->stream); }
+        LAUNCH_OK("heads / gate");
+    }
 #undef LAUNCH_OK
     if (!side_tile && c->overlap) HIPCHK(c, hipEventRecord(c->e_main, c->stream));  // a later pipelined tile stage must wait for this pass
     c->times.ctus += n;

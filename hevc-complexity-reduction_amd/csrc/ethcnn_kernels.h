@@ -17,8 +17,8 @@ struct Workspace {
     float* h2 = nullptr;     // [cap][336]
     float* logits = nullptr; // [cap][21]
     float* raw = nullptr;    // [cap][21] ungated probabilities
-    int* flags = nullptr;    // [chunks][2]
-    int flags_cap = 0;
+    int* flags = nullptr;    // sync area: [chunks][2] gate predicates, [chunks] sub-batch arrival counters, (fused launch) tile completion counters
+    int flags_cap = 0;       // in ints
 };
 
 struct FrameGeom {
@@ -36,9 +36,18 @@ void launch_tile(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, co
 void launch_trunk(const Workspace& ws, const DeviceWeights& w, int n, bool resi, hipStream_t s);
 // k2: feat -> h1 (bias + leaky-ReLU fused); out may be ws.h1 or a caller buffer (resi vectors)
 void launch_fc1(const Workspace& ws, const DeviceWeights& w, int n, float* out, hipStream_t s);
-// k3+k4 fused: h1 -> h2 -> logits, raw probs, probs (ungated) and per-chunk gate flags
+// k3+k4 fused: h1 -> h2 -> logits, raw probs, probs and per-chunk gate flags.  gate_nchunks > 0: the batch gates are applied
+// inside the launch (ws.flags = sync area: arrival counters behind the 2 * gate_nchunks predicates, zero on
+// entry); 0: probs are left ungated for launch_gate
 void launch_heads(const Workspace& ws, const DeviceWeights& w, int n, float qn, int nctu_per_frame,
-                  long ctu0, float thr1, float thr2, float* d_probs, hipStream_t s);
+                  long ctu0, float thr1, float thr2, float* d_probs, hipStream_t s, int gate_nchunks = 0);
+// FC1 + heads + gates of a big pass as ONE launch (ethcnn_fused.hip): the heads blocks are appended to FC1's grid and wait on
+// per-M-tile completion counters; the last heads block applies the gates.  ws.flags = the pass's sync area
+// [2 * nchunks gate predicates][nchunks sub-batch arrival counters][tile counters], sync_words(n, nchunks) ints, ZERO on entry (the tile stage clears it).
+bool fc1_heads_fusable(int n);
+void launch_fc1_heads(const Workspace& ws, const DeviceWeights& w, int n, float qn, int nctu_per_frame, long ctu0, float thr1,
+                      float thr2, float* d_probs, int nchunks, hipStream_t s);
+inline int sync_words(int n, int nchunks) { return 3 * nchunks + (n + 63) / 64 + 8; }
 // k5: apply the batch gates in place on d_probs
 void launch_gate(const Workspace& ws, int n, int nctu_per_frame, long ctu0, float thr2, float* d_probs,
                  hipStream_t s);

@@ -17,10 +17,12 @@ step + heads + gates on the GPU).  Differences from the reference, none in the n
     encoder's critical path.  state.dat is still written every frame for protocol compatibility -- AFTER
     cu_depth.dat and pred_end.sig, while HM is already encoding -- and it is still the source whenever
     the resident state cannot be the right one (daemon restart, a frame out of sequence, a state.dat
-    somebody else replaced: inode / size / mtime are checked).  A sidecar `state.dat.idx` ("<i_frame> <w> <h>", written
-    after state.dat) says which frame the file belongs to: a restarted daemon that finds the state of the WRONG frame
-    there (the previous daemon died between pred_end.sig and the state write) refuses it instead of silently feeding
-    frame i-1's state to frame i+1; a state.dat without sidecar (the reference daemon's) is taken as it is;
+    somebody else replaced: inode / size / mtime are checked).  A sidecar `state.dat.idx` brackets the late write:
+    "pending <i_frame> <w> <h>" appears BEFORE pred_end.sig, "<i_frame> <w> <h>" replaces it once state.dat holds that
+    frame's state.  A restarted daemon that finds "pending" (the previous daemon died between the ending signal and the
+    state write, so state.dat still belongs to an earlier frame) refuses the file instead of silently feeding a stale
+    state into the recurrence; a state.dat without sidecar (the reference daemon's) is taken as it is, whatever frame
+    it is from -- as the reference does (HM may skip frames: intra pictures are not predicted);
   * resi.yuv is read straight into pinned host memory (DMA-able without a staging copy);
   * missing trained CNN blob (model_LDP_2000000_qp22~37.dat.data is not in the reference repo):
     ETHCNN_SYNTHETIC_SEED=<n> opts into seeded synthetic CNN weights, otherwise it is an error.
@@ -47,7 +49,7 @@ MINI_BATCH_SIZE = 1024    # :118 (gate scope; applied inside the library)
 COMPLETE_FILE = 'complete.dat'
 YUV_FILE = 'resi.yuv'
 STATE_FILE = 'state.dat'
-STATE_INDEX_SUFFIX = '.idx'   # ours: "<i_frame> <w> <h>" of the frame whose output state state.dat holds
+STATE_INDEX_SUFFIX = '.idx'   # ours: "[pending] <i_frame> <w> <h>": the frame whose output state state.dat holds / is about to hold
 SAVE_FILE = 'cu_depth.dat'
 COMMAND_FILE = 'command.dat'
 START_FILE = 'pred_start.sig'
@@ -102,18 +104,21 @@ def get_images_from_one_file(yuv_file, frame_width, frame_height, CUwidth=IMAGE_
 
 
 def get_state_in_from_one_file(state_file, num_vectors, i_frame, geometry=None):
-    """:103-112: zeros for i_frame <= 1 (returned as None = zeros inside the library).  When the sidecar written by
-    this daemon is present it must name frame i_frame - 1 (and `geometry` = (w, h) when given): a stale state is an
-    error, never a silent wrong recurrence."""
+    """:103-112: zeros for i_frame <= 1 (returned as None = zeros inside the library).  The sidecar this daemon writes
+    must not say "pending" (the state write behind an ending signal never completed: the file is an EARLIER frame's) and
+    must name `geometry` = (w, h) when given: a stale state is an error, never a silently wrong recurrence."""
     if i_frame > 1:
         try:
             with open(state_file + STATE_INDEX_SUFFIX, 'r') as f:
-                tag = [int(t) for t in f.read().split()]
-        except (IOError, OSError, ValueError):
+                tag = f.read().split()
+        except (IOError, OSError):
             tag = None  # no sidecar: somebody else's state.dat (the reference daemon writes none) -> trusted as there
-        if tag is not None and (len(tag) != 3 or tag[0] != i_frame - 1 or (geometry is not None and tuple(tag[1:]) != tuple(geometry))):
-            raise IOError('%s holds the state after frame %s, frame %d needs the state after frame %d'
-                          % (state_file, tag[:1] or '?', i_frame, i_frame - 1))
+        if tag is not None:
+            if tag[:1] == ['pending']:
+                raise IOError('%s is stale: the state of frame %s was never written (daemon stopped after its ending signal)'
+                              % (state_file, tag[1] if len(tag) > 1 else '?'))
+            if len(tag) != 3 or (geometry is not None and [str(int(g)) for g in geometry] != tag[1:]):
+                raise IOError('%s belongs to another sequence (%s), frame %d is %s' % (state_file, ' '.join(tag), i_frame, geometry))
         want = num_vectors * LSTM_DEPTH * 2 * VECTOR_LENGTH
         state_in = np.fromfile(state_file, dtype=np.float32, count=want)
         if state_in.size != want:
@@ -150,21 +155,21 @@ def save_cu_depth_and_state(depth_out, state_out, save_file, state_file, end_fil
     signal come FIRST (they are what HM waits for) and state.dat is refreshed afterwards, while HM is already
     encoding: `state_out` may be a callable that fetches the state from the GPU at that point.  Returns the state."""
     assert depth_out.size == num_vectors * (1 + 4 + 16)
+
+    def sidecar(text):  # tag = (i_frame, w, h)
+        tmp = '%s%s.tmp.%d' % (state_file, STATE_INDEX_SUFFIX, os.getpid())
+        with open(tmp, 'w') as f:
+            f.write(text + '\n')
+        os.rename(tmp, state_file + STATE_INDEX_SUFFIX)
+    if tag is not None:
+        sidecar('pending %d %d %d' % tuple(tag))  # from here until the state write below, state.dat is an earlier frame's
     _write_atomic(save_file, depth_out)
     open(end_file, 'wb').close()
     if callable(state_out):
         state_out = state_out()
-    if tag is not None:  # (i_frame, w, h): the old sidecar goes first, the new one appears only behind the new state
-        try:
-            os.remove(state_file + STATE_INDEX_SUFFIX)
-        except OSError:
-            pass
     _write_atomic(state_file, state_out)
     if tag is not None:
-        tmp = '%s%s.tmp.%d' % (state_file, STATE_INDEX_SUFFIX, os.getpid())
-        with open(tmp, 'w') as f:
-            f.write('%d %d %d\n' % tuple(tag))
-        os.rename(tmp, state_file + STATE_INDEX_SUFFIX)
+        sidecar('%d %d %d' % tuple(tag))
     return state_out
 
 

@@ -83,10 +83,10 @@ def gpu_daemon(workdir, max_frames, log):
     d = pkg.resi_to_cu_depth_LDP
     orig = d.save_cu_depth_and_state
 
-    def logging_save(depth_out, state_out, save_file, state_file, end_file, num_vectors):
+    def logging_save(depth_out, state_out, save_file, state_file, end_file, num_vectors, **kw):
         frame = len(log) + 1
         crc_p = zlib.crc32(np.ascontiguousarray(depth_out, np.float32).tobytes())  # before the signal: the buffer is reused
-        state = orig(depth_out, state_out, save_file, state_file, end_file, num_vectors)  # fetches the resident state after the signal
+        state = orig(depth_out, state_out, save_file, state_file, end_file, num_vectors, **kw)  # fetches the resident state after the signal
         log.append((frame, crc_p, zlib.crc32(np.ascontiguousarray(state, np.float32).tobytes())))
         return state
     d.save_cu_depth_and_state = logging_save
@@ -117,7 +117,7 @@ def main():
     t0 = time.time()
     r = subprocess.run([exe, "-c", os.path.join(ROOT, "scripts", "hm_ldp_test.cfg"), "-i", "seq.yuv", "-wdt", str(W), "-hgt", str(H),
                         "-fr", "30", "-f", str(FRAMES), "-q", str(QP), "-b", "str.bin", "-o", ""],
-                       cwd=work, capture_output=True, text=True, timeout=1200)
+                       cwd=work, capture_output=True, text=True, timeout=200)
     enc_s = time.time() - t0
     if r.returncode != 0:
         raise SystemExit("HM-LDP failed:\n" + r.stdout[-2000:] + r.stderr[-2000:])

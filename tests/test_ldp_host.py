@@ -48,10 +48,11 @@ def test_constants(pkg):
     assert d.MODEL_CNN_FILE == "model_LDP_2000000_qp22~37.dat"
 
 
-def test_state_sidecar_refuses_the_wrong_frame(pkg, tmp_path):
-    """state.dat is refreshed AFTER pred_end.sig.  A daemon that died in between leaves the state of frame
-    i-1 on disk while HM goes on to frame i+1; the sidecar this daemon writes makes that an error instead of a silently
-    wrong recurrence.  A state.dat without sidecar (the reference daemon's) is accepted as it is."""
+def test_state_sidecar_refuses_a_stale_state(pkg, tmp_path):
+    """state.dat is refreshed AFTER pred_end.sig.  A daemon that died in between leaves an EARLIER frame's state on
+    disk; the sidecar ("pending ..." before the ending signal, the plain tag once state.dat is written) makes that an error
+    instead of a silently wrong recurrence.  A state.dat without sidecar (the reference daemon's) is accepted as it is, and
+    so is a complete one from any earlier frame (HM does not predict every picture)."""
     d = pkg.resi_to_cu_depth_LDP
     nv, w, h = 4, 128, 128
     rng = np.random.default_rng(1)
@@ -60,13 +61,22 @@ def test_state_sidecar_refuses_the_wrong_frame(pkg, tmp_path):
     s = tmp_path / "state.dat"
     d.save_cu_depth_and_state(depth, st, str(tmp_path / "cu_depth.dat"), str(s), str(tmp_path / "pred_end.sig"), nv, tag=(5, w, h))
     assert (tmp_path / "state.dat.idx").read_text().split() == ["5", str(w), str(h)]
-    assert np.array_equal(d.get_state_in_from_one_file(str(s), nv, 6, (w, h)), st)   # the right frame
-    with pytest.raises(IOError, match="needs the state after frame 6"):
-        d.get_state_in_from_one_file(str(s), nv, 7, (w, h))                          # frame 6's state was never written
+    assert np.array_equal(d.get_state_in_from_one_file(str(s), nv, 6, (w, h)), st)   # the next frame
+    assert np.array_equal(d.get_state_in_from_one_file(str(s), nv, 9, (w, h)), st)   # a later one (frames HM did not predict)
     with pytest.raises(IOError):
         d.get_state_in_from_one_file(str(s), nv, 6, (w, 64))                         # another geometry
+    # the daemon dies between the ending signal and the state write of frame 6
+    seen = {}
+
+    def dying_fetch():
+        seen["sidecar"] = (tmp_path / "state.dat.idx").read_text().split()
+        raise KeyboardInterrupt
+    with pytest.raises(KeyboardInterrupt):
+        d.save_cu_depth_and_state(depth, dying_fetch, str(tmp_path / "cu_depth.dat"), str(s), str(tmp_path / "pred_end.sig"), nv, tag=(6, w, h))
+    assert seen["sidecar"] == ["pending", "6", str(w), str(h)] and (tmp_path / "pred_end.sig").exists()
+    with pytest.raises(IOError, match="stale"):
+        d.get_state_in_from_one_file(str(s), nv, 7, (w, h))                          # frame 5's state must not feed frame 7
     (tmp_path / "state.dat.idx").unlink()
     assert np.array_equal(d.get_state_in_from_one_file(str(s), nv, 7, (w, h)), st)   # no sidecar: trusted, as in the reference
-    # a callable state (fetched from the GPU after the ending signal) + tag: sidecar appears behind the state
     d.save_cu_depth_and_state(depth, lambda: st * 2, str(tmp_path / "cu_depth.dat"), str(s), str(tmp_path / "pred_end.sig"), nv, tag=(6, w, h))
     assert np.array_equal(d.get_state_in_from_one_file(str(s), nv, 7, (w, h)), st * 2)
