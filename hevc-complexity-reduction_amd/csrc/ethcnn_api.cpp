@@ -177,6 +177,14 @@ struct ethcnn_ctx {
     int tile_blocks = 256;   // blocks of the side-stream tile stage: one per CU (ETHCNN_TILE_BLOCKS)
     unsigned pass_idx = 0;   // parity selects the buffer set
     int last_parity = 0;     // of the last pass (debug_fetch reads its h1)
+    int small_launch = 1;    // 1 = a small pass (one picture) is ONE launch (ethcnn_small.hip); 0 = tile / trunk / FC1 / heads / gate
+                             // launches (ethcnn_set_small_pass_launch, env ETHCNN_SMALL=0)
+    bool luma_over_pcie = false;  // set around a call whose luma pointer is page-locked HOST memory used in place (ethcnn_ldp_step):
+                                  // the single-launch pass gathers every pixel three times (S / M / L units) in 8-16 byte pieces --
+                                  // fine in HBM, slow across PCIe -- so such a call keeps the tile stage (one coalesced read)
+    int* d_ssync = nullptr;  // its sync area: zero between launches by construction (every word is reset by its last user)
+    int ssync_cap = 0;       // in ints
+    bool ssync_clean = false;
     int fused = 0;           // 1 = big passes run FC1 + heads + gates as ONE launch (ethcnn_set_fused_launch, env ETHCNN_FUSED=1).
                              // Off by default: measured equal-to-1 % slower than the separate launches
     int gate_fold = 0;       // 1 = the heads launch applies the gates itself (sub-batch arrival counters); 0 = k5_gate launch behind it.
@@ -330,6 +338,7 @@ extern "C" int ethcnn_create(ethcnn_ctx** out, const ethcnn_options* opt) {
             }
     }
     if (const char* e = std::getenv("ETHCNN_OVERLAP")) c->overlap = std::atoi(e) != 0;  // development knob (A/B runs)
+    if (const char* e = std::getenv("ETHCNN_SMALL")) c->small_launch = std::atoi(e) != 0;  // development knob (A/B runs)
     if (const char* e = std::getenv("ETHCNN_FUSED")) c->fused = std::atoi(e) != 0;      // development knob (A/B runs)
     if (const char* e = std::getenv("ETHCNN_GATE_FOLD")) c->gate_fold = std::atoi(e) != 0;  // development knob (A/B runs)
     c->tile_blocks = prop.multiProcessorCount;
@@ -415,7 +424,7 @@ extern "C" void ethcnn_destroy(ethcnn_ctx* c) {
     delete c->pool;
     if (c->dw_arena) (void)hipFree(c->dw_arena);
     {
-        void* lp[] = {c->d_lstm, c->d_vec, c->d_state[0], c->d_state[1], c->d_lprobs, c->d_lgate};
+        void* lp[] = {c->d_lstm, c->d_vec, c->d_state[0], c->d_state[1], c->d_lprobs, c->d_lgate, c->d_ssync};
         for (void* p : lp)
             if (p) (void)hipFree(p);
     }
@@ -625,6 +634,12 @@ extern "C" int ethcnn_set_fused_launch(ethcnn_ctx* c, int on) {
     return ETHCNN_OK;
 }
 
+extern "C" int ethcnn_set_small_pass_launch(ethcnn_ctx* c, int on) {
+    if (!c) return ETHCNN_ERR_ARG;
+    c->small_launch = on ? 1 : 0;  // takes effect with the next pass enqueued; results do not depend on it
+    return ETHCNN_OK;
+}
+
 extern "C" int ethcnn_get_stage_times(ethcnn_ctx* c, ethcnn_stage_times* out) {
     if (!c || !out) return ETHCNN_ERR_ARG;
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -661,6 +676,32 @@ static int serial_end(ethcnn_ctx* c) {
     return 0;
 }
 
+// the single-launch form of a small pass (ethcnn_small.hip); fc1_out: ws.h1 (All-Intra) or the caller's vectors (resi).
+// Asynchronous on the main stream.
+static int run_small_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, bool resi, const Workspace& w,
+                          float* fc1_out, float qn, float* d_probs, int nchunks) {
+    const int words = small_pass_sync_words(n, nchunks);
+    if (words > c->ssync_cap || !c->ssync_clean) {
+        if (words > c->ssync_cap) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (c->d_ssync) (void)hipFree(c->d_ssync);
+            c->d_ssync = nullptr;
+            c->ssync_cap = 0;
+            const int cap = std::max(words, small_pass_sync_words(kSmallPassMaxCtus, kSmallPassMaxCtus));  // ~0.7 MB, once
+            HIPCHK(c, hipMalloc((void**)&c->d_ssync, (size_t)cap * sizeof(int)));
+            c->ssync_cap = cap;
+        }
+        HIPCHK(c, hipMemsetAsync(c->d_ssync, 0, (size_t)c->ssync_cap * sizeof(int), c->stream));  // stream-ordered
+    }
+    c->ssync_clean = false;  // until this launch has been enqueued without an error
+    (void)hipGetLastError();
+    { StageTimer t(c, ETHCNN_STAGE_FC1, n); launch_small_pass(d_luma, g, ctu0, n, resi, w, c->dw, fc1_out, qn, c->thr1, c->thr2, d_probs, nchunks, c->d_ssync, c->stream); }
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return set_err(c, ETHCNN_ERR_DEVICE, "launch of the single-launch small pass failed: %s", hipGetErrorString(le));
+    c->ssync_clean = true;
+    return 0;
+}
+
 // one pass over CTUs [ctu0, ctu0+n) of the sequence; ctu0 is sub-batch aligned.  input_ready: event after which d_luma
 // may be read (nullptr: the caller ordered it before the call).  Asynchronous; the pass ends on the main stream.
 static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, int qp,
@@ -678,6 +719,19 @@ static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, lo
     const Workspace w = ws_view(c, p);
     hipStream_t s_tile = side_tile ? c->s_tile : c->stream;
     if (input_ready) HIPCHK(c, hipStreamWaitEvent(s_tile, input_ready, 0));
+    if (!side_tile && c->small_launch && small_pass_ok(d_luma, g, n)) {
+        // one picture (the in-process encoder hook, the reference's own 768x512 case): CTU load + trunk -> FC1 -> heads -> gates
+        // as ONE launch instead of five dependent ones
+        Workspace wv = w;
+        if (!c->debug_capture) wv.h2 = wv.logits = wv.raw = nullptr;
+        rc = run_small_pass(c, d_luma, g, ctu0, n, false, wv, w.h1, qn, d_probs_pass, (int)nchunks);
+        if (rc) return rc;
+        if (c->overlap) HIPCHK(c, hipEventRecord(c->e_main, c->stream));  // a later pipelined tile stage must wait for this pass
+        c->times.ctus += n;
+        c->last_n = n;
+        c->last_parity = p;
+        return 0;
+    }
     if (side_tile) {
         // tile(i) overwrites the tile outputs and gate flags of buffer set p: last read by trunk(i-2) / gate(i-2).  Both are
         // ordered before trunk(i-1) on the main stream, so the wait for e_trunk[p ^ 1] below covers them; a main-stream
@@ -1082,6 +1136,14 @@ extern "C" int ethcnn_resi_vectors_device(ethcnn_ctx* c, const uint8_t* d_luma, 
         const int n = std::min(c->max_ctus, g.nctu - o);
         rc = ensure_workspace(c, n, 1);
         if (rc) return rc;
+        if (c->small_launch && !c->luma_over_pcie && small_pass_ok(d_luma, g, n)) {  // one LDP frame: CTU load + trunk -> FC1 as one launch
+            rc = run_small_pass(c, d_luma, g, o, n, true, c->ws, d_vec + (size_t)o * kNVec, 0.0f, nullptr, 1);
+            if (rc) return rc;
+            c->times.ctus += n;
+            c->last_n = n;
+            c->last_parity = 0;
+            continue;
+        }
         { StageTimer t(c, ETHCNN_STAGE_TILE, n); launch_tile(d_luma, g, o, n, c->ws, 0, c->stream); }
         { StageTimer t(c, ETHCNN_STAGE_TRUNK); launch_trunk(c->ws, c->dw, n, true, c->stream); }
         { StageTimer t(c, ETHCNN_STAGE_FC1, n); launch_fc1(c->ws, c->dw, n, d_vec + (size_t)o * kNVec, c->stream); }
@@ -1254,7 +1316,9 @@ static int ldp_step_impl(ethcnn_ctx* c, const uint8_t* luma, int w, int h, ptrdi
     else HIPCHK(c, hipMemcpyAsync(c->d_in[0], luma, lbytes, hipMemcpyHostToDevice, c->stream));
     const size_t pbytes = (size_t)nctu * kNOut * 4;
     float* d_probs = in_pinned(c, probs, pbytes) ? probs : c->d_lprobs;
+    c->luma_over_pcie = (d_luma == luma);
     rc = ethcnn_resi_vectors_device(c, d_luma, w, h, pitch, c->d_vec);
+    c->luma_over_pcie = false;
     if (rc) return rc;
     rc = ethcnn_lstm_step_device(c, c->d_vec, in >= 0 ? c->d_state[in] : nullptr, nctu, qp, i_frame, c->d_state[out], d_probs);
     if (rc) return rc;

@@ -65,7 +65,8 @@ __device__ __forceinline__ void fc1_block_to_tile(unsigned bid, int& mt, int& nb
 // one output tile: M tile `mt` (rows mt * BM ..), column block `nb`; smem: >= Fc1Shape<...>::LDS_FLOATS floats.
 // COHERENT: the h1 stores are agent-scope (sc1: written through this XCD's L2), for a consumer that runs in the SAME launch
 // on another XCD (the heads blocks of the fused launch, ethcnn_fused.hip); results are identical.
-template <int MS, int NS, int WM, int NSUB, int NST, bool COHERENT = false>
+// A_SC1: the features were written earlier in the SAME launch (single-launch small pass): fetched with agent-scope loads.
+template <int MS, int NS, int WM, int NSUB, int NST, bool COHERENT = false, bool A_SC1 = false>
 __device__ __forceinline__ void fc1_tile_at(float* __restrict__ smem, const float* __restrict__ feat, const float* __restrict__ Wimg,
                                             const float* __restrict__ bias, float* __restrict__ out, int M, const int mt, const int nb) {
     constexpr int BK = 16 * NSUB, BN = 16 * NS, BM = 16 * MS * WM;
@@ -134,14 +135,23 @@ __device__ __forceinline__ void fc1_tile_at(float* __restrict__ smem, const floa
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" \
                      : "=&s"(keep_) : "v"(lane16), "s"(sbase), "s"(lds_byte_addr) : "memory");          \
     }
+#define P3_DMA_SC1(sbase, lds_byte_addr)                                                               \
+    {                                                                                                  \
+        unsigned keep_;                                                                                \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1\n\ts_mov_b32 m0, %0" \
+                     : "=&s"(keep_) : "v"(lane16), "s"(sbase), "s"(lds_byte_addr) : "memory");          \
+    }
 #define P3_ISSUE(kc, st)                                                                               \
     {                                                                                                  \
         _Pragma("unroll") for (int i = 0; i < B_PER; ++i)                                              \
             P3_DMA(b_base[i] + (size_t)(kc) * B_FLOATS, lds_base + 4u * (st) * STAGE + b_dst[i]);      \
         _Pragma("unroll") for (int u = 0; u < NSUB; ++u)                                               \
-            _Pragma("unroll") for (int i = 0; i < MS; ++i)                                             \
-                P3_DMA(a_base[i] + ((size_t)(kc) * NSUB + u) * 256,                                    \
-                       a_dst0 + 4u * ((st) * STAGE + (u * MS + i) * 256));                             \
+            _Pragma("unroll") for (int i = 0; i < MS; ++i) {                                           \
+                if (A_SC1) P3_DMA_SC1(a_base[i] + ((size_t)(kc) * NSUB + u) * 256,                     \
+                                      a_dst0 + 4u * ((st) * STAGE + (u * MS + i) * 256))               \
+                else P3_DMA(a_base[i] + ((size_t)(kc) * NSUB + u) * 256,                               \
+                            a_dst0 + 4u * ((st) * STAGE + (u * MS + i) * 256))                         \
+            }                                                                                          \
     }
 #define P3_COMPUTE(st)                                                                                 \
     {                                                                                                  \
@@ -184,6 +194,7 @@ __device__ __forceinline__ void fc1_tile_at(float* __restrict__ smem, const floa
         for (int st = 0; st < NST; ++st) { P3_STEP(kc + st, st); }
     }
 #undef P3_DMA
+#undef P3_DMA_SC1
 #undef P3_ISSUE
 #undef P3_COMPUTE
 #undef P3_STEP

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void k_fc1_heads(FusedParams P) {
         head_pass<0, true, true>(smem, P.h1, P.hp, P.qn, lane, wvu, valid, ctu, h2row, P.logits, P.raw, P.probs, fl, fl + 1, P.thr1, P.thr2);
 
     // ---- gates: applied per sub-batch by the block that completes it (ethcnn_heads_pass.h)
-    heads_gates_arrive(P.sync, P.nchunks, P.gi, N, tile64 * 64, P.thr2, P.probs, &s_ga);
+    heads_gates_arrive(P.sync, P.sync + 2 * P.nchunks, P.gi, N, tile64 * 64, P.thr2, P.probs, &s_ga);
 }
 
 // the bulk part must run for several rounds of resident blocks (same rule as k_fc1_bulk, ethcnn_dense.hip): below that the

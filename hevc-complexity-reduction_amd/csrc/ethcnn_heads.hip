@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void k_heads(const float* __restrict__ H1, Hea
     else
         head_pass<0, false, GATE>(smem, H1, hp, qn, lane, wvu, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
     HEADS_STAMP(4);
-    if (GATE) heads_gates_arrive(flags, nchunks, gi, N, tile_ * 64, thr2, probs, &s_ga);
+    if (GATE) heads_gates_arrive(flags, flags + 2 * nchunks, gi, N, tile_ * 64, thr2, probs, &s_ga);
 }
 
 void launch_heads(const Workspace& ws, const DeviceWeights& w, int n, float qn, int nctu, long ctu0, float thr1,

@@ -87,7 +87,12 @@ constexpr int kHeadsStages = 2;  // prefetch distance 1: 24 KB of LDS, < 80 VGPR
 // every h1 read is an agent-scope load (sc1).  P_SC1 (gates applied inside the launch): the probabilities are agent-scope
 // stores -- the block that applies the gates at the end of the launch may run on another XCD and overwrites them.
 // Results are identical in every combination.
-template <int H, bool H1_SC1 = false, bool P_SC1 = false>
+// LAT (the single-launch small pass, ethcnn_small.hip): latency form of the K loop.  A picture's heads blocks are alone on
+// their CUs, so nothing hides a memory round trip per K chunk (16 chunks x ~2.5 us for agent-scope h1 loads that bypass the
+// L2): ALL h1 quads of the wave are requested up front into registers (one round trip), the W2 chunks run through a 3-stage
+// ring (prefetch distance 2) and the loop is fully unrolled.  Same chains: same results.
+constexpr int kHeadsLatStages = 3;
+template <int H, bool H1_SC1 = false, bool P_SC1 = false, bool LAT = false>
 __device__ __forceinline__ void head_pass(float* smem, const float* __restrict__ H1, const HeadsParams& hp, float qn,
                                           int lane, unsigned wvu, bool valid, int ctu, float* __restrict__ h2row,
                                           float* __restrict__ logits, float* __restrict__ raw, float* __restrict__ probs,
@@ -142,7 +147,7 @@ __device__ __forceinline__ void head_pass(float* smem, const float* __restrict__
         _Pragma("unroll") for (int i = 0; i < D::B_PER; ++i)                                             \
             HP_DMA(b_off[i], W2 + (size_t)(kc) * 16 * D::N2,                                             \
                    4u * ((st) * kHeadsStage + min(wvu + i * 4, (unsigned)(D::B_INST - 1)) * 256));       \
-        if (!D::H1REG) {                                                                                 \
+        if (!D::H1REG && !LAT) {                                                                         \
             if (H1_SC1) HP_DMA_SC1(a_off, H1 + (kc) * 16, 4u * ((st) * kHeadsStage + D::H1_AT + wvu * 256))  \
             else HP_DMA(a_off, H1 + (kc) * 16, 4u * ((st) * kHeadsStage + D::H1_AT + wvu * 256))         \
         }                                                                                                \
@@ -154,8 +159,37 @@ __device__ __forceinline__ void head_pass(float* smem, const float* __restrict__
     for (int j = 0; j < D::NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const __amdgpu_buffer_rsrc_t rH1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(H1), 0, -1, 0x00020000);
-    f32x4 avr = (f32x4){0.f, 0.f, 0.f, 0.f};
     constexpr int kH1Aux = H1_SC1 ? kAuxSc1 : 0;
+    if constexpr (LAT) {
+        f32x4 hq[D::NK];
+#pragma unroll
+        for (int kc = 0; kc < D::NK; ++kc) hq[kc] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rH1, a_off, kc * 64, kH1Aux));
+        __builtin_amdgcn_s_barrier();  // (block entry: nothing of a previous user of the LDS is still being read)
+        HP_ISSUE(0, 0);
+        if (D::NK > 1) { HP_ISSUE(1, 1); }
+        if (D::NK > 1) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D::B_PER) : "memory"); }  // all but the newest group: h1 + chunk 0
+        else { HP_WAIT(0); }
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int kc = 0; kc < D::NK; ++kc) {
+            const int st = kc % kHeadsLatStages;
+            if (kc + 2 < D::NK) { HP_ISSUE(kc + 2, (kc + 2) % kHeadsLatStages); }  // the stage every wave left at the last barrier
+            const float* bsE = smem + st * kHeadsStage + a_base[0];
+            const float* bsO = smem + st * kHeadsStage + a_base[1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float hv = hq[kc][e];
+#pragma unroll
+                for (int j = 0; j < D::NT; ++j)
+                    acc[j] = MFMA16((((D::COLSWZ ? j : e) & 1) ? bsO : bsE)[e * D::N2 + 16 * j], hv, acc[j]);  // rows = W2 columns
+            }
+            if (kc + 2 < D::NK) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D::B_PER) : "memory"); }  // chunk kc + 1 has landed
+            else { HP_WAIT(0); }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    } else {
+    f32x4 avr = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (D::H1REG) avr = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rH1, a_off, 0, kH1Aux));
     __builtin_amdgcn_s_barrier();  // the previous head's last stage has been consumed by every wave
     HEADS_STAMP(1);
@@ -191,6 +225,7 @@ __device__ __forceinline__ void head_pass(float* smem, const float* __restrict__
         st = st2;
         avr = avn;
     }
+    }  // !LAT
 #undef HP_DMA
 #undef HP_DMA_SC1
 #undef HP_ISSUE
@@ -255,6 +290,147 @@ __device__ __forceinline__ void head_pass(float* smem, const float* __restrict__
 }
 
 
+// ---- latency form for ONE group of 16 CTUs (the single-launch small pass, ethcnn_small.hip): the block's waves SPLIT the FC2
+// output tiles of the head (head 16: 12 tiles -> 3 per wave; 32: 2, 2, 2, -; 64: 1, 1, 1, -) instead of each taking 16
+// CTUs with all tiles: a wave's K loop is a quarter as long (head 16: 192 MFMAs instead of 768 -- the 64-CTU form keeps one
+// SIMD busy for 10 us, and a picture's heads blocks have the GPU to themselves).  Every wave requests all h1 quads of the
+// group up front (agent-scope loads), the W2 chunks run through the 3-stage LDS ring shared by the block, h2 crosses waves
+// through LDS in [tile][lane] order (the writer's C-layout quad of lane (ctu, g) is the reader's B-operand quad, as in
+// k_lstm_heads) and wave 0 runs FC3 + sigmoid + gate predicates.  Same chains per accumulator: same results.
+// smem: kHeadsLatStages * kHeadsStage floats of W2 stages + NT * 256 floats of h2.
+template <int H>
+__device__ __forceinline__ void head_pass_split(float* smem, const float* __restrict__ H1, const HeadsParams& hp, float qn, int lane,
+                                                unsigned wvu, bool valid, int ctu, float* __restrict__ h2row,
+                                                float* __restrict__ logits, float* __restrict__ raw, float* __restrict__ probs,
+                                                int* flag32, int* flag16, float thr1, float thr2) {
+    using D = Hd<H>;
+    constexpr int TPW = (D::NT + 3) / 4;                     // tiles per wave
+    const int col = lane & 15, g = lane >> 4;
+    const float* W2 = hp.w2[H];
+    const float* W3 = hp.w3[H];
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void*)smem);
+    f32x4* const h2T = reinterpret_cast<f32x4*>(smem + kHeadsLatStages * kHeadsStage);
+    unsigned b_off[D::B_PER];
+#pragma unroll
+    for (int i = 0; i < D::B_PER; ++i) {  // the W2 chunk's permuted LDS image, as in head_pass
+        const int q = min((int)wvu + i * 4, D::B_INST - 1);
+        const int e = q * 64 + lane;
+        int row = (e / (D::N2 / 4)) % 16;
+        int c4 = e % (D::N2 / 4);
+        if (D::COLSWZ) c4 ^= ((row >> 2) & 1) << 2;
+        else row ^= (row >> 2) & 1;
+        b_off[i] = 4u * (unsigned)(row * D::N2 + c4 * 4);
+    }
+    const unsigned a_off = 4u * (unsigned)(ctu * kNVec + D::O1 + 4 * g);
+    int a_base[2];
+    if (D::COLSWZ) { a_base[0] = 4 * g * D::N2 + col + 16 * (g & 1); a_base[1] = 4 * g * D::N2 + col - 16 * (g & 1); }
+    else { a_base[0] = 4 * g * D::N2 + col + D::N2 * (g & 1); a_base[1] = 4 * g * D::N2 + col - D::N2 * (g & 1); }
+    const int j0 = (int)wvu * TPW;  // this wave's tiles j0 .. j0 + TPW - 1 (those < NT)
+#define HS_DMA(voff, sbase, lds_byte_off)                                                                \
+    {                                                                                                    \
+        unsigned keep_;                                                                                  \
+        const unsigned dst_ = __builtin_amdgcn_readfirstlane(lds_base + (lds_byte_off));                 \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" \
+                     : "=&s"(keep_) : "v"(voff), "s"(sbase), "s"(dst_) : "memory");                      \
+    }
+#define HS_ISSUE(kc, st)                                                                                 \
+    {                                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < D::B_PER; ++i)                                             \
+            HS_DMA(b_off[i], W2 + (size_t)(kc) * 16 * D::N2,                                             \
+                   4u * ((st) * kHeadsStage + min(wvu + i * 4, (unsigned)(D::B_INST - 1)) * 256));       \
+    }
+    const __amdgpu_buffer_rsrc_t rH1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(H1), 0, -1, 0x00020000);
+    f32x4 hq[D::NK];
+#pragma unroll
+    for (int kc = 0; kc < D::NK; ++kc) hq[kc] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rH1, a_off, kc * 64, kAuxSc1));
+    // wave 0 runs FC3 at the end: ALL of its W3 operands are requested now (a tile-ahead prefetch would expose one L2 round
+    // trip per tile -- 12 x ~0.6 us for head 16 -- when nothing else runs on the CU); columns >= N3 read as 0
+    const __amdgpu_buffer_rsrc_t rW3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W3), 0, (D::N2 + 1) * D::N3 * 4, 0x00020000);
+    float w3q[D::NT][4];
+    if (wvu == 0) {
+        const int w3off = (4 * g * D::N3 + col) * 4;  // lane part of W3[(16 j + 4 g + r) * N3 + col]
+#pragma unroll
+        for (int j = 0; j < D::NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                w3q[j][r] = (col < D::N3) ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rW3, w3off, (16 * j + r) * D::N3 * 4, 0)) : 0.0f;
+    }
+    f32x4 acc[TPW];
+#pragma unroll
+    for (int jj = 0; jj < TPW; ++jj) acc[jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    HS_ISSUE(0, 0);
+    if (D::NK > 1) { HS_ISSUE(1, 1); }
+    if (D::NK > 1) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D::B_PER) : "memory"); }  // all but the newest group: h1 + chunk 0
+    else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int kc = 0; kc < D::NK; ++kc) {
+        const int st = kc % kHeadsLatStages;
+        if (kc + 2 < D::NK) { HS_ISSUE(kc + 2, (kc + 2) % kHeadsLatStages); }
+        const float* bsE = smem + st * kHeadsStage + a_base[0];
+        const float* bsO = smem + st * kHeadsStage + a_base[1];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float hv = hq[kc][e];
+#pragma unroll
+            for (int jj = 0; jj < TPW; ++jj) {
+                const int j = min(j0 + jj, D::NT - 1);  // (idle slots recompute the last tile; never stored)
+                acc[jj] = MFMA16((((D::COLSWZ ? j : e) & 1) ? bsO : bsE)[e * D::N2 + 16 * j], hv, acc[jj]);
+            }
+        }
+        if (kc + 2 < D::NK) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D::B_PER) : "memory"); }
+        else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+#undef HS_DMA
+#undef HS_ISSUE
+    // FC2 epilogue of this wave's tiles, then hand them to wave 0
+    const __amdgpu_buffer_rsrc_t rW2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W2), 0, (D::N1 + 1) * D::N2 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hp.b2[H]), 0, D::N2 * 4, 0x00020000);
+#pragma unroll
+    for (int jj = 0; jj < TPW; ++jj) {
+        const int j = j0 + jj;
+        if (j < D::NT) {  // wave-uniform
+            const f32x4 wq = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW2, 16 * g, (D::N1 * D::N2 + 16 * j) * 4, 0));
+            const f32x4 bv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rB2, 16 * g, 64 * j, 0));
+            f32x4 a = acc[jj];
+            a[0] = lrelu_h(fmaf(qn, wq.x, a[0]) + bv.x);
+            a[1] = lrelu_h(fmaf(qn, wq.y, a[1]) + bv.y);
+            a[2] = lrelu_h(fmaf(qn, wq.z, a[2]) + bv.z);
+            a[3] = lrelu_h(fmaf(qn, wq.w, a[3]) + bv.w);
+            if (valid && h2row) *reinterpret_cast<f32x4*>(h2row + D::O2 + 16 * j + 4 * g) = a;
+            h2T[j * 64 + lane] = a;
+        }
+    }
+    __syncthreads();
+    if (wvu != 0) return;
+    f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < D::NT; ++j) {
+        const f32x4 hv = h2T[j * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) z = MFMA16(w3q[j][r], hv[r], z);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int o = 4 * g + r;
+        if (o < D::N3 && valid) {
+            const float zz = fmaf(qn, W3[D::N2 * D::N3 + o], z[r]) + hp.b3[H][o];
+            const float p = 1.0f / (1.0f + expf_canonical_h(-zz));
+            const size_t idx = (size_t)ctu * kNOut + D::O3 + o;
+            if (logits) logits[idx] = zz;
+            if (raw) raw[idx] = p;
+            __hip_atomic_store(&probs[idx], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (H == 0 && p > thr1 && __hip_atomic_load(flag32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+                __hip_atomic_store(flag32, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (H == 1 && p > thr2 && __hip_atomic_load(flag16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+                __hip_atomic_store(flag16, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+
 // The tf.cond gates (net_CNN.py:175,187) applied INSIDE the launch that computes the probabilities.  Every heads block
 // publishes its probabilities and predicates with agent-scope stores, waits for them (s_waitcnt vmcnt(0)), and then adds 1 to
 // the ARRIVAL COUNTER of every gate sub-batch its 64 CTUs touch; the block whose add completes a sub-batch (3 heads x the
@@ -274,19 +450,21 @@ __device__ __forceinline__ void gate_chunk_range(const GateIndex& gi, int ch, in
     c1 = min(u1 - gi.r0, N);
 }
 // first_ctu: first CTU of this block's 64-CTU tile.  All threads of the block must call it (barriers inside).
-__device__ __forceinline__ void heads_gates_arrive(int* sync, int nchunks, const GateIndex& gi, int N, int first_ctu, float thr2,
+// SELF_CLEAN (the single-launch small pass): the completer hands the sub-batch's predicate and arrival words back as zeros.
+// TILE: CTUs per heads block (64; 16 in the single-launch small pass).
+template <bool SELF_CLEAN = false, int TILE = 64>
+__device__ __forceinline__ void heads_gates_arrive(int* sync, int* arrived, const GateIndex& gi, int N, int first_ctu, float thr2,
                                                    float* probs, GateArrive* ga) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this block's probabilities and predicates have completed
     __syncthreads();
     if (threadIdx.x == 0) {
-        int* const arrived = sync + 2 * nchunks;
-        const int last_ctu = min(first_ctu + 63, N - 1);
+        const int last_ctu = min(first_ctu + TILE - 1, N - 1);
         const int ca = gate_chunk(gi, first_ctu), cb = gate_chunk(gi, last_ctu);
         int n = 0;
         for (int ch = ca; ch <= cb; ++ch) {
             int c0, c1;
             gate_chunk_range(gi, ch, N, c0, c1);
-            const int expected = 3 * (((c1 - 1) >> 6) - (c0 >> 6) + 1);  // 3 heads x tiles overlapping [c0, c1)
+            const int expected = 3 * ((c1 - 1) / TILE - c0 / TILE + 1);  // 3 heads x tiles overlapping [c0, c1)
             if (__hip_atomic_fetch_add(arrived + ch, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == expected) ga->ch[n++] = ch;
         }
         ga->n = n;
@@ -297,6 +475,14 @@ __device__ __forceinline__ void heads_gates_arrive(int* sync, int nchunks, const
         const bool open32 = __hip_atomic_load(sync + 2 * ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
         // y16 is gated on the GATED y32: a closed L1 gate leaves zeros, and any(0 > thr2) decides
         const bool open16 = open32 ? (__hip_atomic_load(sync + 2 * ch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) : (0.0f > thr2);
+        if (SELF_CLEAN) {
+            __syncthreads();  // every thread has read the predicates
+            if (threadIdx.x == 0) {
+                __hip_atomic_store(sync + 2 * ch, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(sync + 2 * ch + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(arrived + ch, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
         if (open32 && open16) continue;
         int c0, c1;
         gate_chunk_range(gi, ch, N, c0, c1);

@@ -1,0 +1,284 @@
+// ethcnn_small.hip -- a SMALL pass (one picture: the in-process encoder hook, every Low-Delay-P frame, the reference's own
+// 768x512 case) as ONE launch: CTU load + trunk -> FC1 -> heads -> gates (video_to_cu_depth.py:61-73 + net_CNN.py:103-187; LDP
+// front-end: resi_cnn, net_CNN_LSTM_one_step.py:151-199, stops after FC1).
+//
+// Why: a picture of a few hundred CTUs was five dependent launches (tile, trunk, FC1, heads, gate) of 10-20 us each with the
+// GPU < 10 % occupied -- every one pays its own dispatch, kernarg fetch, cold instruction cache, weight staging and drain, and
+// the stages cannot overlap (profiles/r02_latency.txt: 69 us for a 1080p picture whose longest dependent chain, FC1's 672 MFMA
+// steps, is 9 us of issue time).  Here the whole pass is a DATAFLOW inside one grid:
+//
+//   blocks [0, nT)          trunk: one wave = one unit position of 16 CTUs, pixels gathered STRAIGHT from the luma frame
+//                           (Trunk<.., DIRECT>: the CTU-load stage folded into its consumer; no record buffers, no tile launch)
+//   blocks [nT, +nF)        FC1 64 x (16 NS) tiles; a block starts when the 4 x 21 trunk tasks of its 64 CTUs have landed
+//   blocks [.., +3 groups)  one head of a group of 16 CTUs (its waves split the head's FC2 tiles: head_pass_split); starts when
+//                           the NSPLIT FC1 column blocks of its 64-CTU tile have landed; applies the gates per sub-batch
+//
+// Every consumer block has a higher block id than its producers and workgroups are dispatched in id order, so a waiting block
+// can only wait for blocks that are resident or finished, and producers never wait: no deadlock whatever the grid size (all
+// blocks of a 1080p pass are co-resident anyway).  All hand-offs are agent-scope (sc1) stores / loads, completed
+// (s_waitcnt vmcnt(0)) before the producer's counter moves -- the fused big-pass launch's scheme (ethcnn_fused.hip, DESIGN.md
+// "hand-offs inside a launch") -- with the signalling shaped for LATENCY (see SmallSync below): finisher-notifies-private-flag
+// instead of polled counters.  The stages' launch overheads, weight staging and drains overlap instead of adding up.
+// The sync area is ZERO between launches by construction: every word is reset by its unique last user.
+// Same device functions, same accumulation chains as the multi-launch path: bit-identical results (tests run both).
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+#include "ethcnn_fc1_tile.h"
+#include "ethcnn_heads_pass.h"
+#include "ethcnn_kernels.h"
+#include "ethcnn_trunk_task.h"
+
+namespace ethcnn {
+
+struct SmallParams {
+    DirectSrc src;
+    const float* trunk_w;
+    const float* trunk_b;
+    float* feat;
+    int n, ngroups, ntiles, nchunks;
+    int bS, bM, bL;               // trunk blocks per branch (S / M: 4 waves = 4 tasks; L: one task per block)
+    const float* wimg;
+    const float* fc1_b;
+    float* h1;                    // FC1 output: the pass's h1 (AI) or the caller's 448-vectors (LDP front-end)
+    unsigned fc1_blocks, heads_blocks;
+    int* sync;                    // SmallSync layout below; zero on entry, zero again on exit
+    HeadsParams hp;
+    float qn;
+    GateIndex gi;
+    float thr1, thr2;
+    float *h2, *logits, *raw, *probs;
+    int exp;  // timing experiments only (env ETHCNN_SMALL_EXP): 1 = consumers do not wait (WRONG results)
+};
+
+// ---- signalling.  Measured on MI355X (profiles/r03_small_pass.txt): agent-scope atomics and polls on ONE address are served
+// one at a time, ~150 ns each -- 224 blocks drawing tickets from one word cost 35 us, 28 blocks polling one counter delay the
+// producer's own add by microseconds.  So:
+//   * counters are only ever ADDED to (never polled): the add returns the old value, and the adder that completes a counter
+//     is its FINISHER -- it resets the counter to zero (nobody else will touch it again in this launch) and notifies the
+//     consumers;
+//   * every consumer block polls a PRIVATE flag word in its own 128-byte line, written once by a finisher, and resets it
+//     itself: one poller, one writer per address;
+//   * counters and flags are padded to one per 128-byte line (one memory channel queue each);
+//   * the trunk signals per BLOCK (the four tasks of an S / M block belong to one group): 6 adds per group, not 21.
+// Every word is reset by its unique finisher / consumer, so the area is zero again when the launch ends: no clearing pass,
+// no launch-wide ticket.
+constexpr int kPad = 32;  // ints per 128-byte line
+struct SmallSync {
+    int* pred;         // [2 nchunks]          gate predicates (dense)
+    int* arrive;       // [nchunks]            heads blocks arrived per gate sub-batch (dense)
+    int* feat_done;    // [ngroups] x kPad     trunk tasks finished per group of 16 CTUs (21 = complete)
+    int* tile_groups;  // [ntiles] x kPad      complete groups per 64-CTU tile
+    int* fc1_flag;     // [fc1_blocks] x kPad  "your tile's features have landed", one per FC1 block
+    int* fc1_done;     // [ntiles] x kPad      FC1 column blocks finished per tile
+    int* heads_flag;   // [3 ngroups] x kPad   "your tile's h1 has landed", one per heads block (16 CTUs x head)
+    int words;
+};
+__host__ __device__ inline SmallSync small_sync(int* base, int nchunks, int ngroups, int ntiles, int fc1_blocks) {  // (heads blocks = 3 ngroups)
+    SmallSync s;
+    s.pred = base;
+    s.arrive = s.pred + 2 * nchunks;
+    s.feat_done = s.arrive + (nchunks + kPad - 1) / kPad * kPad + kPad;  // (first padded line starts on a fresh 128 B)
+    s.tile_groups = s.feat_done + ngroups * kPad;
+    s.fc1_flag = s.tile_groups + ntiles * kPad;
+    s.fc1_done = s.fc1_flag + fc1_blocks * kPad;
+    s.heads_flag = s.fc1_done + ntiles * kPad;
+    s.words = (int)(s.heads_flag + 3 * ngroups * kPad - base);
+    return s;
+}
+
+__device__ __forceinline__ int add_ret(int* p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void put(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int get(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// one thread polls its block's private flag (bounded: a trap is a loud launch failure, never a hung GPU), then resets it
+__device__ __forceinline__ void wait_flag(int* p, int exp) {
+    if (exp == 1) return;
+    unsigned long long t0;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+    while (get(p) == 0) {
+        __builtin_amdgcn_s_sleep(1);
+        unsigned long long t;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        if (t - t0 > 200000000ull) __builtin_trap();  // 2 s at 100 MHz
+    }
+    put(p, 0);
+}
+
+#ifdef SMALL_STAMPS
+// development probe (scripts/ubench/small_probe.hip): device-wide 100 MHz stamps per block: entry, woken, computed, exit
+__device__ unsigned long long g_small_stamps[1 << 13][4];
+__device__ __forceinline__ void small_stamp(int slot) {
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    if (threadIdx.x == 0) g_small_stamps[blockIdx.x & 0x1fff][slot] = t;
+}
+#define SMALL_STAMP(i) small_stamp(i)
+#else
+#define SMALL_STAMP(i)
+#endif
+
+template <int A, int B>
+struct MaxOf { static constexpr int value = A > B ? A : B; };
+
+template <int NS, int NSUB, bool RESI>
+__global__ __launch_bounds__(256, 2) void k_small_pass(SmallParams P) {  // <= 256 registers: two blocks per CU
+    constexpr int NSPLIT = kNVec / (16 * NS);
+    constexpr int LDS_FLOATS = MaxOf<MaxOf<Fc1Shape<1, NS, 4, NSUB, 3>::LDS_FLOATS, kTrunkWFrags * 64 + 8 * 64 * 4>::value, kHeadsLatStages * kHeadsStage + 12 * 256>::value;
+    __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
+    __shared__ GateArrive s_ga;
+    const int bid = (int)blockIdx.x;
+    const int nT = P.bS + P.bM + P.bL;
+    const SmallSync Y = small_sync(P.sync, P.nchunks, P.ngroups, P.ntiles, (int)P.fc1_blocks);
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    SMALL_STAMP(0);
+
+    if (bid < nT) {  // ---- trunk (+ CTU load): the block's tasks all belong to ONE group of 16 CTUs
+        int grp, ntask;
+        if (bid < P.bS) {
+            grp = bid >> 2; ntask = 4;
+            Trunk<0, RESI, true, true>::run(nullptr, P.ngroups * 16, bid * 4 + wv, P.bS * 4, P.trunk_w, P.trunk_b, P.feat, P.n, smem, &P.src);
+        } else if (bid < P.bS + P.bM) {
+            grp = bid - P.bS; ntask = 4;
+            Trunk<1, RESI, true, true>::run(nullptr, P.ngroups * 4, (bid - P.bS) * 4 + wv, P.bM * 4, P.trunk_w, P.trunk_b, P.feat, P.n, smem, &P.src);
+        } else {  // L: one task per BLOCK (the four waves gather the 64 KB of pixels together, wave 0 computes)
+            grp = bid - P.bS - P.bM; ntask = 1;
+            Trunk<2, RESI, true, true>::run(nullptr, P.ngroups, grp, P.bL, P.trunk_w, P.trunk_b, P.feat, P.n, smem, &P.src);
+        }
+        SMALL_STAMP(1);
+        // the block's features (agent-scope stores) have completed before its group's counter moves
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        SMALL_STAMP(2);
+        if (threadIdx.x == 0 && add_ret(Y.feat_done + grp * kPad, ntask) + ntask == 21) {  // 16 S + 4 M + 1 L: group complete
+            put(Y.feat_done + grp * kPad, 0);
+            const int tile = grp >> 2, in_tile = min(4, P.ngroups - 4 * tile);
+            if (add_ret(Y.tile_groups + tile * kPad, 1) + 1 == in_tile) {             // tile complete: wake its FC1 blocks
+                put(Y.tile_groups + tile * kPad, 0);
+                for (int nb = 0; nb < NSPLIT; ++nb) put(Y.fc1_flag + (tile * NSPLIT + nb) * kPad, 1);
+            }
+        }
+        SMALL_STAMP(3);
+        return;
+    }
+
+    if (bid < nT + (int)P.fc1_blocks) {  // ---- FC1: 64 CTUs x 16 NS columns
+        const int fb = bid - nT;
+        const int nb = fb % NSPLIT, mt = fb / NSPLIT;
+        if (threadIdx.x == 0) wait_flag(Y.fc1_flag + fb * kPad, P.exp);
+        __syncthreads();
+        SMALL_STAMP(1);
+        fc1_tile_at<1, NS, 4, NSUB, 3, true, true>(smem, P.feat, P.wimg, P.fc1_b, P.h1, P.n, mt, nb);
+        SMALL_STAMP(2);
+        if (RESI) return;  // the vectors are the launch's output: nothing waits for them inside it
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0 && add_ret(Y.fc1_done + mt * kPad, 1) + 1 == NSPLIT) {  // all column blocks of the tile: wake its heads
+            put(Y.fc1_done + mt * kPad, 0);
+            const int g1 = min(4 * mt + 4, P.ngroups);
+            for (int hb = 12 * mt; hb < 3 * g1; ++hb) put(Y.heads_flag + hb * kPad, 1);  // (group, head) blocks of the tile
+        }
+        SMALL_STAMP(3);
+        return;
+    }
+
+    if (RESI) return;  // (no heads blocks are launched for the LDP front-end)
+    // ---- one head of one group of 16 CTUs (the block's waves split the head's FC2 tiles: head_pass_split)
+    const int hb = bid - nT - (int)P.fc1_blocks;
+    const int grp = hb / 3, head_ = hb % 3;
+    if (threadIdx.x == 0) wait_flag(Y.heads_flag + hb * kPad, P.exp);
+    __syncthreads();
+    SMALL_STAMP(1);
+    const int lane = threadIdx.x & 63;
+    const unsigned wvu = (unsigned)wv;
+    const int N = P.n;
+    const int ctu_raw = grp * 16 + (lane & 15);
+    const bool valid = ctu_raw < N;
+    const int ctu = min(ctu_raw, N - 1);
+    float* h2row = P.h2 ? P.h2 + (size_t)ctu * kNFc2 : nullptr;
+    int* fl = Y.pred;
+    if (head_ != 0) fl += 2 * gate_chunk(P.gi, ctu);
+    if (head_ == 0) head_pass_split<2>(smem, P.h1, P.hp, P.qn, lane, wvu, valid, ctu, h2row, P.logits, P.raw, P.probs, fl, fl + 1, P.thr1, P.thr2);
+    else if (head_ == 1) head_pass_split<1>(smem, P.h1, P.hp, P.qn, lane, wvu, valid, ctu, h2row, P.logits, P.raw, P.probs, fl, fl + 1, P.thr1, P.thr2);
+    else head_pass_split<0>(smem, P.h1, P.hp, P.qn, lane, wvu, valid, ctu, h2row, P.logits, P.raw, P.probs, fl, fl + 1, P.thr1, P.thr2);
+    // gates per sub-batch, applied by the block that completes it, which also hands its words back as zeros
+    SMALL_STAMP(2);
+    heads_gates_arrive<true, 16>(Y.pred, Y.arrive, P.gi, N, grp * 16, P.thr2, P.probs, &s_ga);
+    SMALL_STAMP(3);
+}
+
+// upper bound over the FC1 shapes (28 column blocks per tile at most)
+int small_pass_sync_words(int n, int nchunks) { return small_sync(nullptr, nchunks, (n + 15) / 16, (n + 63) / 64, (n + 63) / 64 * 28).words; }
+
+// rows must be 16-byte aligned for the direct gather (the tile stage's own fast-path condition)
+bool small_pass_ok(const uint8_t* d_luma, const FrameGeom& g, int n) {
+    return n > 0 && n <= kSmallPassMaxCtus && (g.width % 16 == 0) && (g.pitch % 16 == 0) && (g.frame_stride % 16 == 0) &&
+           (reinterpret_cast<uintptr_t>(d_luma) % 16 == 0);
+}
+
+template <bool RESI>
+static void launch_small_t(const SmallParams& P, int shape, unsigned blocks, hipStream_t s) {
+    // FC1 shape by row count, as fc1_short_variant (ethcnn_dense.hip): narrow tiles = short per-chunk chains for few rows
+    if (shape == 0) hipLaunchKernelGGL((k_small_pass<1, 4, RESI>), dim3(blocks), dim3(256), 0, s, P);       // 64 x 16, BK 64
+    else if (shape == 1) hipLaunchKernelGGL((k_small_pass<2, 2, RESI>), dim3(blocks), dim3(256), 0, s, P);  // 64 x 32, BK 32
+    else hipLaunchKernelGGL((k_small_pass<4, 2, RESI>), dim3(blocks), dim3(256), 0, s, P);                  // 64 x 64, BK 32
+}
+
+void launch_small_pass(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, bool resi, const Workspace& ws,
+                       const DeviceWeights& w, float* fc1_out, float qn, float thr1, float thr2, float* d_probs, int nchunks,
+                       int* d_sync, hipStream_t s) {
+    SmallParams P;
+    P.src.luma = d_luma;
+    P.src.width = g.width;
+    P.src.height = g.height;
+    P.src.pitch = g.pitch;
+    P.src.frame_stride = g.frame_stride;
+    P.src.cw = g.cw;
+    P.src.nctu = g.nctu;
+    P.src.ctu0 = ctu0;
+    P.src.n_total = n;
+    P.trunk_w = w.trunk_w;
+    P.trunk_b = w.trunk_b;
+    P.feat = ws.feat;
+    P.n = n;
+    P.ngroups = (n + 15) / 16;
+    P.ntiles = (n + 63) / 64;
+    P.nchunks = nchunks;
+    P.bS = (P.ngroups * 16 + 3) / 4;
+    P.bM = (P.ngroups * 4 + 3) / 4;
+    P.bL = P.ngroups;  // one L task per block
+    static const int force = [] { const char* e = getenv("ETHCNN_SMALL_SHAPE"); return e ? atoi(e) : -1; }();  // development knob
+    int shape = n <= 576 ? 0 : (n <= 2304 ? 1 : 2);
+    if (force >= 0 && force <= 2) shape = force;
+    const int nsplit = shape == 0 ? 28 : (shape == 1 ? 14 : 7);
+    P.wimg = shape == 0 ? w.fc1_img16 : (shape == 1 ? w.fc1_img32 : w.fc1_img64);
+    P.fc1_b = w.fc1_b;
+    P.h1 = fc1_out;
+    P.fc1_blocks = (unsigned)(P.ntiles * nsplit);
+    P.heads_blocks = resi ? 0u : (unsigned)P.ngroups * 3u;
+    P.sync = d_sync;
+    for (int h = 0; h < 3; ++h) {
+        P.hp.w2[h] = w.fc2_w[h];
+        P.hp.b2[h] = w.fc2_b[h];
+        P.hp.w3[h] = w.fc3_w[h];
+        P.hp.b3[h] = w.fc3_b[h];
+    }
+    P.qn = qn;
+    P.gi = make_gate_index(g.nctu, ctu0);
+    P.thr1 = thr1;
+    P.thr2 = thr2;
+    P.h2 = ws.h2;
+    P.logits = ws.logits;
+    P.raw = ws.raw;
+    P.probs = d_probs;
+    static const int exp_mode = [] { const char* e = getenv("ETHCNN_SMALL_EXP"); return e ? atoi(e) : 0; }();
+    P.exp = exp_mode;
+    unsigned blocks = (unsigned)(P.bS + P.bM + P.bL) + P.fc1_blocks + P.heads_blocks;
+    if (exp_mode == 2) blocks = (unsigned)(P.bS + P.bM + P.bL);                  // trunk part alone (timing only)
+    if (exp_mode == 3) blocks = (unsigned)(P.bS + P.bM + P.bL) + P.fc1_blocks;   // trunk + FC1
+    if (resi) launch_small_t<true>(P, shape, blocks, s);
+    else launch_small_t<false>(P, shape, blocks, s);
+}
+
+}  // namespace ethcnn

@@ -64,6 +64,7 @@ SIGNATURES = {
     "ethcnn_predict_luma_device": (_i, [_vp, _vp, _i, _i, _pd, _pd, _i, _i, _vp]),
     "ethcnn_set_pass_pipeline": (_i, [_vp, _i]),
     "ethcnn_set_fused_launch": (_i, [_vp, _i]),
+    "ethcnn_set_small_pass_launch": (_i, [_vp, _i]),
     "ethcnn_ldp_step": (_i, [_vp, _vp, _i, _i, _pd, _i, _i, _vp, _fp]),
     "ethcnn_ldp_get_state": (_i, [_vp, _fp, _sz]),
     "ethcnn_host_alloc": (_i, [_vp, _sz, ctypes.POINTER(_vp)]),
@@ -457,6 +458,10 @@ class EthCnn(object):
         """launch plan of FC1 / heads / gates: 0 = three launches (default), 1 = one fused launch for big passes,
         2 = FC1 + a heads launch that applies the gates itself.  Same results in every mode."""
         self._chk(self.lib.ethcnn_set_fused_launch(self.h, int(mode)))
+
+    def set_small_pass_launch(self, on=True):
+        """one picture (<= 8192 CTUs, 16-byte aligned rows) as ONE launch (default on); off = five launches.  Same results."""
+        self._chk(self.lib.ethcnn_set_small_pass_launch(self.h, 1 if on else 0))
 
     def reset_stage_times(self):
         self._chk(self.lib.ethcnn_reset_stage_times(self.h))

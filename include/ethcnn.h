@@ -206,6 +206,13 @@ int ethcnn_reset_stage_times(ethcnn_ctx* ctx);
  * are equal to 1 % slower than plan 0 (the matrix pipe has no idle time to give in FC1's drain, and agent-scope hand-offs cost
  * what the boundaries did: DESIGN.md section 3), so plan 0 stays the default. */
 int ethcnn_set_fused_launch(ethcnn_ctx* ctx, int mode);
+/* Single-launch small pass (default on): a pass of <= 2304 CTUs (up to one 3840x2160 picture) whose rows are 16-byte aligned (width, pitch, frame stride and
+ * base pointer multiples of 16) -- one picture from the in-process encoder hook, every Low-Delay-P frame, the reference's own
+ * 768x512 case -- runs CTU load + trunk -> FC1 -> heads -> gates as ONE kernel launch (a dataflow inside one grid, per-group /
+ * per-tile completion counters; csrc/ethcnn_small.hip) instead of five dependent launches; the LDP front-end
+ * (ethcnn_resi_vectors*) likewise as one launch instead of three.  Time is booked under ETHCNN_STAGE_FC1.  Off, or for other
+ * geometries: the tile / trunk / FC1 / heads / gate launches.  Results do not depend on it.  Env: ETHCNN_SMALL=0. */
+int ethcnn_set_small_pass_launch(ethcnn_ctx* ctx, int on);
 
 /* ---- parity-test introspection: intermediates of the LAST pass, copied to host. */
 enum {

@@ -1,0 +1,137 @@
+"""GPU: the single-launch small pass (csrc/ethcnn_small.hip: CTU load + trunk -> FC1 -> heads -> gates as a dataflow inside one
+grid) against the oracle and against the five-launch path (ethcnn_set_small_pass_launch off): bit-identical probabilities,
+features, FC1 outputs, LDP vectors and LDP recurrences over aligned geometries of every FC1 shape, zero-padded edges, pitched
+planes, several frames per pass, closed / mixed gates, and long call sequences (the launch's last block must leave its sync
+area zero for the next one)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _luma(rng, frames, h, pitch, w):
+    a = rng.integers(0, 256, size=(frames, h, pitch), dtype=np.uint8)
+    a[:, : h // 3] = a[:, : h // 3] // 16 + 100          # a smooth band: low split probabilities
+    a[:, :, w:] = 0xEE                                    # the pitch gap must never be read as pixels
+    return a
+
+
+GEOMS = [  # (width, height, frames, pitch): every FC1 shape of the launch (<= 576, <= 2304, more rows), ragged right / bottom CTUs
+    (768, 512, 1, 768), (1920, 1080, 1, 1920), (416, 240, 1, 416), (400, 136, 3, 448), (832, 480, 2, 832),
+    (3840, 2160, 1, 3840), (4928, 3264, 1, 4928), (1920, 1080, 3, 2048), (64, 64, 1, 64), (16, 16, 5, 16), (1280, 720, 8, 1280)]
+
+
+@pytest.mark.parametrize("geom", GEOMS)
+def test_single_launch_pass_matches_oracle_and_five_launches(pkg, oracle, geom):
+    w, h, frames, pitch = geom
+    rng = np.random.default_rng(w * 31 + h)
+    blob = oracle.synth_blob(6, 4.0)
+    luma = _luma(rng, frames, h, pitch, w)
+    nctu = pkg.ethcnn.ctus_per_frame(w, h)
+    c = pkg.EthCnn(device=0)
+    c.load_blob(blob)
+    try:
+        d_in, d_out = c.alloc(luma.nbytes), c.alloc(frames * nctu * 84)
+        d_in.upload(luma)
+
+        def run(on):
+            c.set_small_pass_launch(on)
+            c.predict_luma_device(d_in, w, h, frames, 30, d_out, pitch=pitch)
+            c.synchronize()
+            return d_out.download(np.float32, frames * nctu * 21).reshape(-1, 21)
+        c.set_thresholds(-1.0, -1.0)
+        raw = run(True)
+        m64 = float(raw[: min(1024, nctu), 0].max())
+        for t1, t2 in ((0.5, 0.5), (m64, 0.5), (float(np.median(raw[:, 0])), float(np.median(raw[:, 1:5]))), (2.0, -0.5)):
+            c.set_thresholds(t1, t2)
+            want = oracle.predict_frames(blob, luma, w, h, frames, 30, t1, t2, mode=0, pitch=pitch)
+            got1 = run(True)
+            st = c.stage_times()
+            assert np.array_equal(_bits(got1), _bits(want)), (geom, t1, t2)
+            assert np.array_equal(_bits(run(False)), _bits(want)), (geom, t1, t2)
+        # the launch really was ONE kernel; intermediates are where debug_fetch expects them
+        c.set_profiling(2)
+        c.reset_stage_times()
+        run(True)
+        st = c.stage_times()["launches"]
+        n = frames * nctu
+        if n <= 2304:   # up to one 3840x2160 picture; beyond that five full launches win and the library keeps them
+            assert (st["tile"], st["trunk"], st["fc1"], st["heads"], st["gate"]) == (0, 0, 1, 0, 0), st
+        else:
+            assert st["tile"] == 1 and st["heads"] == 1
+        f1, h1 = c.debug_fetch(pkg.ethcnn.DBG_FEATURES, n), c.debug_fetch(pkg.ethcnn.DBG_FC1, n)
+        c.reset_stage_times()
+        run(False)
+        st = c.stage_times()["launches"]
+        assert st["tile"] == 1 and st["trunk"] == 1 and st["fc1"] >= 1 and st["heads"] == 1
+        assert np.array_equal(_bits(f1), _bits(c.debug_fetch(pkg.ethcnn.DBG_FEATURES, n)))
+        assert np.array_equal(_bits(h1), _bits(c.debug_fetch(pkg.ethcnn.DBG_FC1, n)))
+        c.set_profiling(0)
+        d_in.free()
+        d_out.free()
+    finally:
+        c.close()
+
+
+def test_ldp_front_end_and_recurrence_single_launch(pkg, oracle):
+    import ethcnn_lstm_np as ol
+    rng = np.random.default_rng(12)
+    blob, lblob = oracle.synth_blob(8, 1.0), ol.synth_lstm_blob(4, 3.0)
+    c = pkg.EthCnn(device=0)
+    c.load_blob(blob)
+    c.load_lstm_blob(lblob)
+    c.set_thresholds(0.6, 0.7)
+    try:
+        for (w, h) in ((1920, 1080), (416, 240), (3840, 2160), (64, 16)):
+            frames = [np.clip(np.rint(128 + rng.laplace(0, 7, size=(h, w))), 0, 255).astype(np.uint8) for _ in range(3)]
+            want_vec = oracle.resi_vectors(blob, frames[0], w, h, mode=0)
+            for on in (True, False):
+                c.set_small_pass_launch(on)
+                assert np.array_equal(_bits(c.resi_vectors(frames[0], w, h)), _bits(want_vec)), (w, h, on)
+                gs = os_ = None
+                for i, fr in enumerate(frames, 1):
+                    gp, gs = c.ldp_predict_frame(fr, w, h, 32, i, gs)
+                    op, os_ = ol.lstm_step(lblob, oracle.resi_vectors(blob, fr, w, h), os_, 32, i, 0.6, 0.7, mode=0)
+                    assert np.array_equal(_bits(gp), _bits(op)) and np.array_equal(_bits(gs), _bits(os_)), (w, h, on, i)
+    finally:
+        c.close()
+
+
+def test_long_sequences_of_single_launch_passes(pkg, oracle):
+    """600 back-to-back calls over changing geometries, thresholds and both entry points, asynchronous runs in between: every
+    launch finds the sync area its predecessor's last block cleared"""
+    rng = np.random.default_rng(99)
+    blob = oracle.synth_blob(2, 8.0)
+    c = pkg.EthCnn(device=0)
+    c.load_blob(blob)
+    try:
+        cases = []
+        for (w, h, frames) in ((768, 512, 1), (1920, 1088, 1), (416, 240, 4), (128, 64, 1), (2560, 1440, 1)):
+            luma = _luma(rng, frames, h, w, w)
+            nctu = pkg.ethcnn.ctus_per_frame(w, h)
+            d_in, d_out = c.alloc(luma.nbytes), c.alloc(frames * nctu * 84)
+            d_in.upload(luma)
+            want = {}
+            for thr in ((0.5, 0.5), (0.97, 0.5), (2.0, 0.0)):
+                want[thr] = oracle.predict_frames(blob, luma, w, h, frames, 37, thr[0], thr[1], mode=0)
+            cases.append((w, h, frames, nctu, d_in, d_out, want))
+        thrs = list(cases[0][6].keys())
+        for k in range(600):
+            w, h, frames, nctu, d_in, d_out, want = cases[int(rng.integers(len(cases)))]
+            thr = thrs[int(rng.integers(len(thrs)))]
+            c.set_thresholds(*thr)
+            reps = 1 + int(rng.integers(3))
+            for _ in range(reps):  # unsynchronised repeats: launch i+1 is enqueued while launch i runs
+                c.predict_luma_device(d_in, w, h, frames, 37, d_out)
+            c.synchronize()
+            got = d_out.download(np.float32, frames * nctu * 21).reshape(-1, 21)
+            assert np.array_equal(_bits(got), _bits(want[thr])), (k, w, h, thr)
+        for case in cases:
+            case[4].free()
+            case[5].free()
+    finally:
+        c.close()
