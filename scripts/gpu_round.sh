@@ -9,9 +9,10 @@ export TMPDIR=/tmp
 REPO=$PWD
 WL=${WL:-c3}
 if [ -z "${SKIP_TESTS:-}" ]; then
-  python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+  python -m pytest tests -m gpu -x -q --timeout 400 2>&1 | tail -4
   python __graft_entry__.py smoke 2>&1 | tail -3
 fi
+bash scripts/gpu_dist_smoke.sh 2>&1 | tail -6
 python bench.py > gpurun_out/bench_c3.json 2> gpurun_out/bench_c3.err || tail -5 gpurun_out/bench_c3.err
 python bench.py --workload c2 --no-cpu-baseline > gpurun_out/bench_c2.json 2> gpurun_out/bench_c2.err || tail -5 gpurun_out/bench_c2.err
 python bench.py --workload c4 --no-cpu-baseline --steps 5 > gpurun_out/bench_c4.json 2> gpurun_out/bench_c4.err || tail -5 gpurun_out/bench_c4.err
@@ -24,6 +25,13 @@ for e in d.get("cpu_baselines", []): print("cpu:", {k: e.get(k) for k in ("name"
 print("host_scopes:", d.get("host_scopes"))
 PY
 python scripts/latency.py > gpurun_out/latency.txt 2>&1; cat gpurun_out/latency.txt
+{ echo "# the same with the single-launch small pass OFF (ETHCNN_SMALL=0: tile / trunk / FC1 / heads / gate launches)"; ETHCNN_SMALL=0 python scripts/latency.py; } > gpurun_out/latency_five_launches.txt 2>&1; cat gpurun_out/latency_five_launches.txt
+if [ -x scripts/ubench/small_probe ]; then (cd scripts/ubench && ./small_probe 1920 1080 0 && ./small_probe 1920 1080 1 && ./small_probe 768 512 0 && ./small_probe 3840 2160 0) > gpurun_out/small_pass_timeline.txt 2>&1; cat gpurun_out/small_pass_timeline.txt; fi
+# launch plans of the big pass, same box, back to back (plan 0 = default)
+for rep in 1 2; do for plan in "0:" "1:ETHCNN_FUSED=1" "2:ETHCNN_GATE_FOLD=1"; do
+  env ${plan#*:} python bench.py --no-cpu-baseline --no-host-scopes --steps 30 > gpurun_out/plan${plan%%:*}_$rep.json 2>/dev/null
+done; done
+python scripts/summarize.py "gpurun_out/plan*.json" | tee gpurun_out/launch_plans.txt
 python scripts/latency_ldp.py --cpu > gpurun_out/latency_ldp.txt 2>&1; cat gpurun_out/latency_ldp.txt
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_$WL -o $WL -- python $REPO/bench.py --workload $WL --no-cpu-baseline --no-host-scopes > $REPO/gpurun_out/prof_$WL.log 2>&1
