@@ -1010,11 +1010,53 @@ static int host_pipeline(ethcnn_ctx* c, int w, int h, int nframes, int qp, Fill 
     return result;
 }
 
+// [p, p + bytes) inside a buffer from ethcnn_host_alloc: page-locked, DMA-able (and device-addressable) as it is
+static bool in_pinned(const ethcnn_ctx* c, const void* p, size_t bytes);
+
+// One picture (or a few small ones): a single pass of <= 8192 CTUs.  The staging ring above is built for throughput -- a pool
+// wake-up, three streams and two events per group -- which is most of the time of a one-frame call.  Here: (copy into pinned
+// staging unless the caller's buffer IS pinned) -> H2D -> the pass -> D2H, all on the main stream, one synchronisation.
+static int predict_luma_latency(ethcnn_ctx* c, const uint8_t* luma, int w, int h, ptrdiff_t pitch, ptrdiff_t fstride, int nframes,
+                                int qp, float* probs) {
+    FrameGeom g;
+    int rc = make_geom(c, w, h, w, (ptrdiff_t)w * h, &g);
+    if (rc) return rc;
+    if (!c->have_weights) return set_err(c, ETHCNN_ERR_NOWEIGHTS, "no weights loaded");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t plane = (size_t)w * h, in_bytes = plane * nframes, out_bytes = (size_t)nframes * g.nctu * kNOut * 4;
+    rc = ensure_staging(c, in_bytes, out_bytes, 1);
+    if (rc) return rc;
+    const bool packed = pitch == w && fstride == (ptrdiff_t)plane;
+    const uint8_t* src = luma;
+    if (!(packed && in_pinned(c, luma, in_bytes))) {  // tight planes into the pinned staging buffer
+        for (int f = 0; f < nframes; ++f) {
+            const uint8_t* s = luma + (size_t)f * fstride;
+            uint8_t* d = c->h_in[0] + (size_t)f * plane;
+            if (pitch == w) std::memcpy(d, s, plane);
+            else for (int y = 0; y < h; ++y) std::memcpy(d + (size_t)y * w, s + (size_t)y * pitch, (size_t)w);
+        }
+        src = c->h_in[0];
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_in[0], src, in_bytes, hipMemcpyHostToDevice, c->stream));
+    for (const Pass& p : plan_passes(g.nctu, nframes, c->max_ctus)) {
+        rc = run_pass(c, c->d_in[0], g, p.ctu0, p.n, qp, c->d_out[0] + (size_t)p.ctu0 * kNOut);
+        if (rc) break;
+    }
+    if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
+    float* dst = in_pinned(c, probs, out_bytes) ? probs : c->h_out[0];
+    HIPCHK(c, hipMemcpyAsync(dst, c->d_out[0], out_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (dst != probs) std::memcpy(probs, dst, out_bytes);
+    return ETHCNN_OK;
+}
+
 extern "C" int ethcnn_predict_luma(ethcnn_ctx* c, const uint8_t* luma, int w, int h, ptrdiff_t pitch, ptrdiff_t fstride,
                                    int nframes, int qp, float* probs) {
     if (!c || !luma || !probs || nframes < 0) return c ? set_err(c, ETHCNN_ERR_ARG, "null pointer / negative frame count") : ETHCNN_ERR_ARG;
     if (pitch < w) return set_err(c, ETHCNN_ERR_ARG, "pitch %td < width %d", pitch, w);
     const int nctu = ((w + 63) / 64) * ((h + 63) / 64);
+    if (w > 0 && h > 0 && nframes > 0 && (long)nframes * nctu <= kPipelineMinCtus)  // a picture, not a sequence
+        return predict_luma_latency(c, luma, w, h, pitch, fstride, nframes, qp, probs);
     auto fill = [&](uint8_t* dst, int f0, int nf) -> int {
         return parallel_bands(c, nf, w, h, [&](int f, int r0, int rows) -> int {
             const uint8_t* src = luma + (size_t)(f0 + f) * fstride + (size_t)r0 * pitch;

@@ -64,18 +64,18 @@ fail:
 /* ---- per-picture entry (the real in-process hook) ------------------------------------------- */
 static ethcnn_ctx* g_ctx = NULL;
 static int g_qp = -1;
-static unsigned char* g_luma8 = NULL;
+static unsigned char* g_luma8 = NULL; /* page-locked (ethcnn_host_alloc): DMA-ed to the GPU as it is, no staging copy */
 static size_t g_luma8_cap = 0;
 static long g_pictures = 0;
 
 static void close_predictor(void) {
     if (g_ctx) {
         printf("ethcnn (in-process): %ld picture(s) predicted from the encoder's own luma buffers\n", g_pictures);
-        ethcnn_destroy(g_ctx);
+        ethcnn_destroy(g_ctx); /* frees the page-locked luma buffer with it */
     }
     g_ctx = NULL;
-    free(g_luma8);
     g_luma8 = NULL;
+    g_luma8_cap = 0;
 }
 
 /* luma: `height` rows of `width` 16-bit samples, `stride` samples apart, `bit_depth` bits each (HM's
@@ -88,17 +88,25 @@ int ethcnn_hm_predict_picture(const short* luma, int stride, int width, int heig
     int x, y;
     if (!luma || !probs || width <= 0 || height <= 0 || stride < width) return 1;
     if (!g_ctx || qp != g_qp) {
-        if (g_ctx) ethcnn_destroy(g_ctx);
-        else atexit(close_predictor);
+        if (g_ctx) {
+            ethcnn_destroy(g_ctx); /* its page-locked buffers go with it */
+            g_luma8 = NULL;
+            g_luma8_cap = 0;
+        } else {
+            atexit(close_predictor);
+        }
         g_ctx = open_predictor(qp);
         g_qp = qp;
         if (!g_ctx) return 1;
     }
     if (need > g_luma8_cap) {
-        free(g_luma8);
-        g_luma8 = (unsigned char*)malloc(need);
-        g_luma8_cap = g_luma8 ? need : 0;
-        if (!g_luma8) return 1;
+        void* p = NULL;
+        if (g_luma8) (void)ethcnn_host_free(g_ctx, g_luma8);
+        g_luma8 = NULL;
+        g_luma8_cap = 0;
+        if (ethcnn_host_alloc(g_ctx, need, &p) != ETHCNN_OK) return 1;
+        g_luma8 = (unsigned char*)p;
+        g_luma8_cap = need;
     }
     for (y = 0; y < height; ++y) {
         const short* src = luma + (size_t)y * stride;
