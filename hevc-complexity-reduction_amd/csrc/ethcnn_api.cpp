@@ -1354,7 +1354,12 @@ static int ldp_step_impl(ethcnn_ctx* c, const uint8_t* luma, int w, int h, ptrdi
     // reads the luma over PCIe while it runs, the heads / gate stages write the 84 B per CTU straight into the caller's
     // memory -- instead of two copy launches around the kernels
     const uint8_t* d_luma = c->d_in[0];
-    if (in_pinned(c, luma, lbytes)) d_luma = luma;
+    // page-locked luma is read in place over PCIe by the tile stage (one coalesced pass while it runs): measured 123.8 us per
+    // 1080p call against 128.3 us for "DMA it into HBM first, then the single-launch pass" (profiles/r03_latency_ldp.txt;
+    // ETHCNN_LDP_INPLACE=0 selects the latter for A/B runs)
+    static const bool copy_first = [] { const char* e = std::getenv("ETHCNN_LDP_INPLACE"); return e && std::atoi(e) == 0; }();
+    const bool in_place = in_pinned(c, luma, lbytes) && !copy_first;
+    if (in_place) d_luma = luma;
     else HIPCHK(c, hipMemcpyAsync(c->d_in[0], luma, lbytes, hipMemcpyHostToDevice, c->stream));
     const size_t pbytes = (size_t)nctu * kNOut * 4;
     float* d_probs = in_pinned(c, probs, pbytes) ? probs : c->d_lprobs;
