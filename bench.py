@@ -482,17 +482,23 @@ def pmc_traffic(workload):
     FETCH_SIZE is doubled (gfx950 under-counts wide coalesced reads by 2x, MI355X_MICROARCH.md)."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "fc1_traffic.json")))[workload]
-        # the committed PMC pass is only valid for the kernel source it was taken at: stamped with the git blob hash of
-        # ethcnn_dense.hip; a different kernel -> no number rather than a stale one (scripts/gpu_round.sh refreshes it)
-        now = git_blob_sha1(os.path.join(ROOT, "hevc-complexity-reduction_amd", "csrc", "ethcnn_dense.hip"))
+        # the committed PMC pass is only valid for the kernel source it was taken at: stamped with the git blob hashes of
+        # ethcnn_dense.hip + ethcnn_fc1_tile.h; a different kernel -> no number rather than a stale one (scripts/gpu_round.sh refreshes it)
+        now = fc1_source_stamp()
         if d.get("kernel_source_blob") != now:
-            return {"traffic": None, "traffic_note": "profiles/fc1_traffic.json was taken at ethcnn_dense.hip blob %s, the kernel "
+            return {"traffic": None, "traffic_note": "profiles/fc1_traffic.json was taken at FC1 kernel source %s, the kernel "
                                                      "is now %s: re-run scripts/gpu_round.sh" % (d.get("kernel_source_blob"), now)}
         return {"traffic": d["bytes_per_launch"], "traffic_unit": "B/launch",
                 "traffic_algorithmic": d["algorithmic_bytes_per_launch"], "traffic_source": d["source"],
                 "traffic_kernel_source_blob": now}
     except Exception:
         return {"traffic": None}
+
+
+def fc1_source_stamp():
+    """identifies the FC1 kernel source: the git blob hashes of the two files that hold its device code"""
+    src = os.path.join(ROOT, "hevc-complexity-reduction_amd", "csrc")
+    return "+".join(git_blob_sha1(os.path.join(src, f))[:12] for f in ("ethcnn_dense.hip", "ethcnn_fc1_tile.h"))
 
 
 def git_blob_sha1(path):

@@ -170,9 +170,8 @@ struct ethcnn_ctx {
     int* flags1 = nullptr;
     hipStream_t s_tile = nullptr;
     hipEvent_t e_tile[2] = {}, e_trunk[2] = {}, e_main = nullptr;
-    int* d_lgate = nullptr;  // LSTM heads launch: ticket counter + gate predicates [2 * chunks]
-    int lgate_chunks = 0;
-    unsigned lgate_tickets = 0;
+    int* d_lgate = nullptr;  // LSTM heads launch: gate predicates + ticket tree (lstm_gate_words)
+    int lgate_chunks = 0;    // its capacity in ints
     bool lgate_clean = false;
     int tile_blocks = 256;   // blocks of the side-stream tile stage: one per CU (ETHCNN_TILE_BLOCKS)
     unsigned pass_idx = 0;   // parity selects the buffer set
@@ -1288,26 +1287,25 @@ extern "C" int ethcnn_lstm_step_device(ethcnn_ctx* c, const float* d_vec, const 
     int rc = ensure_workspace(c, std::min(n, c->max_ctus), chunks);
     if (rc) return rc;
     if (n > c->ws.cap) return set_err(c, ETHCNN_ERR_ARG, "frame of %d CTUs exceeds max_ctus_per_pass", n);
-    // gate predicates + ticket counter of the LSTM heads launch: zero between launches by construction (the launch's last
-    // block clears what it used); (re)established here after an allocation or after any failure on this path
-    if (chunks > c->lgate_chunks || !c->lgate_clean) {
+    // gate predicates + ticket tree of the LSTM heads launch: zero between launches by construction (every word is reset by its
+    // last user); (re)established here after an allocation or after any failure on this path
+    const int gwords = lstm_gate_words(n);
+    if (gwords > c->lgate_chunks || !c->lgate_clean) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (chunks > c->lgate_chunks) {
+        if (gwords > c->lgate_chunks) {
             if (c->d_lgate) (void)hipFree(c->d_lgate);
             c->d_lgate = nullptr;
             c->lgate_chunks = 0;
-            HIPCHK(c, hipMalloc((void**)&c->d_lgate, ((size_t)chunks * 2 + 1) * sizeof(int)));
-            c->lgate_chunks = chunks;
+            HIPCHK(c, hipMalloc((void**)&c->d_lgate, (size_t)gwords * sizeof(int)));
+            c->lgate_chunks = gwords;
         }
-        HIPCHK(c, hipMemsetAsync(c->d_lgate, 0, ((size_t)c->lgate_chunks * 2 + 1) * sizeof(int), c->stream));  // stream-ordered
-        c->lgate_tickets = 0;
+        HIPCHK(c, hipMemsetAsync(c->d_lgate, 0, (size_t)c->lgate_chunks * sizeof(int), c->stream));  // stream-ordered
     }
     c->lgate_clean = false;  // until this launch has been enqueued without an error
-    c->lgate_tickets += lstm_heads_blocks(n);
     {
         StageTimer t(c, ETHCNN_STAGE_HEADS);
         launch_lstm(d_vec, d_state_in, d_state_out, c->d_lstm, n, qp, i_frame, c->thr1, c->thr2, c->debug_capture ? c->ws.raw : nullptr,
-                    d_probs, c->d_lgate, c->lgate_tickets, c->stream);
+                    d_probs, c->d_lgate, c->stream);
     }
     HIPCHK(c, hipGetLastError());
     c->lgate_clean = true;

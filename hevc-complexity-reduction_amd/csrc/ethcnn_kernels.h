@@ -63,13 +63,12 @@ void launch_gate(const Workspace& ws, int n, int nctu_per_frame, long ctu0, floa
                  hipStream_t s);
 
 // LDP: one ETH-LSTM step + heads + gates over the n CTUs of ONE frame (gates per 1024-CTU mini-batch, applied by the last
-// block of the heads launch).  d_state_in may be null (zeros, i_frame <= 1).  d_gate: one ticket counter followed by 2 * ceil(n / 1024)
-// predicate words that are ZERO on entry and zero again on exit; ticket_target = the counter's value after this launch
-// (previous target + lstm_heads_blocks(n), modulo 2^32).
+// block of the heads launch).  d_state_in may be null (zeros, i_frame <= 1).  d_gate: lstm_gate_words(n) ints -- two predicate
+// words per mini-batch + a two-level ticket tree -- ZERO on entry and zero again on exit (every word is reset by its last user).
 unsigned lstm_heads_blocks(int n);
+int lstm_gate_words(int n);
 void launch_lstm(const float* d_vec, const float* d_state_in, float* d_state_out, const float* d_lstm_blob, int n, int qp,
-                 int i_frame, float thr1, float thr2, float* d_raw, float* d_probs, int* d_gate, unsigned ticket_target,
-                 hipStream_t s);
+                 int i_frame, float thr1, float thr2, float* d_raw, float* d_probs, int* d_gate, hipStream_t s);
 
 int chunks_per_frame(int nctu);
 

@@ -189,40 +189,58 @@ __device__ __forceinline__ void lstm_heads(const LstmParams& lp, const float* __
     const float* W2 = lp.blob + kLstmOff[LV][1];
     const float* b3 = lp.blob + kLstmOff[LV][2];
     const float* W3 = lp.blob + kLstmOff[LV][3];
-    // fc2^T: wave j owns output tile j; step (t, r) consumes k = 16 t + 4 g + r
+    // fc2^T: wave j owns output tile j; step (t, r) consumes k = 16 t + 4 g + r.  Latency form: ALL operands of the tile (64 W2
+    // values and 16 h quads per lane at level 16) are requested before the first MFMA -- fetched a step ahead, the loop paid
+    // one L2 round trip per step with the GPU otherwise idle (round 3: 1080p LSTM heads 17 -> see profiles/r03_latency_ldp.txt)
     if (wave < NT2) {
         const int j = wave;
         f32x4 a2 = (f32x4){0.f, 0.f, 0.f, 0.f};
         const float* wcol = W2 + 16 * j + col + (size_t)(4 * g) * N2;
         const float* hsrc = hrow + O1 + 4 * g;
+        float wv[NT][4];
+        float4 hq[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const float4 hv4 = *reinterpret_cast<const float4*>(hsrc + 16 * t);
-            const float hv[4] = {hv4.x, hv4.y, hv4.z, hv4.w};
+            hq[t] = *reinterpret_cast<const float4*>(hsrc + 16 * t);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) a2 = MFMA16(wcol[(size_t)(16 * t + r) * N2], hv[r], a2);
+            for (int r = 0; r < 4; ++r) wv[t][r] = wcol[(size_t)(16 * t + r) * N2];
+        }
+        float we[4][5];  // the efs rows + bias of this lane's four outputs
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int e = 0; e < 5; ++e) we[r][e] = W2[(N + e) * N2 + 16 * j + 4 * g + r];
+        asm volatile("" ::: "memory");  // every request above is issued before the first MFMA below waits for its operands
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float hv[4] = {hq[t].x, hq[t].y, hq[t].z, hq[t].w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a2 = MFMA16(wv[t][r], hv[r], a2);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int idx = 16 * j + 4 * g + r;
             float v = a2[r];
 #pragma unroll
-            for (int e = 0; e < 5; ++e) v = fmaf(lp.efs[e], W2[(N + e) * N2 + idx], v);
+            for (int e = 0; e < 5; ++e) v = fmaf(lp.efs[e], we[r][e], v);
             a2[r] = lrelu_l(v + b2[idx]);
         }
         h2T[(j * 4 + g) * 16 + col] = a2;
     }
     __syncthreads();
-    if (wave == 0) {  // fc3^T
+    if (wave == 0) {  // fc3^T (operands requested up front, as above)
         f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float w3v[NT2][4];
+#pragma unroll
+        for (int j = 0; j < NT2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w3v[j][r] = (col < N3) ? W3[(16 * j + 4 * g + r) * N3 + col] : 0.0f;
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int j = 0; j < NT2; ++j) {
             const f32x4 hv = h2T[(j * 4 + g) * 16 + col];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float w = (col < N3) ? W3[(16 * j + 4 * g + r) * N3 + col] : 0.0f;
-                z = MFMA16(w, hv[r], z);
-            }
+            for (int r = 0; r < 4; ++r) z = MFMA16(w3v[j][r], hv[r], z);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -253,7 +271,7 @@ __device__ __forceinline__ void lstm_heads(const LstmParams& lp, const float* __
 // launch instead of three (memset of the predicates, heads, gate) in a latency-bound chain.
 __global__ __launch_bounds__(768) void k_lstm_heads(const float* __restrict__ state_out, LstmParams lp, int N, float thr1,
                                                     float thr2, float* __restrict__ raw, float* __restrict__ probs,
-                                                    int* __restrict__ gate, unsigned ticket_target) {
+                                                    int* __restrict__ gate) {
     __shared__ f32x4 h2T[12 * 64];
     __shared__ int s_last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -261,23 +279,39 @@ __global__ __launch_bounds__(768) void k_lstm_heads(const float* __restrict__ st
     const bool valid = ctu_raw < N;
     const int ctu = min(ctu_raw, N - 1);
     const float* hrow = state_out + (size_t)ctu * 2 * kNVec + kNVec;
-    int* const pred = gate + 1;               // gate[0] = ticket counter, then two predicate words per mini-batch
+    const int chunks = (N + kSubBatch - 1) / kSubBatch;
+    int* const pred = gate;                   // two predicate words per mini-batch, then the ticket tree (lstm_gate_words)
     int* fl = pred + 2 * (ctu / kSubBatch);  // one frame: mini-batches of 1024 in raster order
     const int lv = 2 - (int)blockIdx.y;
     if (lv == 0) lstm_heads<0>(lp, hrow, valid, ctu, lane, wave, h2T, raw, probs, fl, fl + 1, thr1, thr2);
     else if (lv == 1) lstm_heads<1>(lp, hrow, valid, ctu, lane, wave, h2T, raw, probs, fl, fl + 1, thr1, thr2);
     else lstm_heads<2>(lp, hrow, valid, ctu, lane, wave, h2T, raw, probs, fl, fl + 1, thr1, thr2);
 
-    const int chunks = (N + kSubBatch - 1) / kSubBatch;
-    unsigned* tickets = reinterpret_cast<unsigned*>(gate);
     // This block's probabilities and predicates are agent-scope atomic stores: once they have completed (vmcnt 0) they are
-    // visible to every XCD, so the ticket needs no release fence (on the 8-XCD part that is a write-back of the whole L2:
-    // measured 36 -> 58 us for a 1080p frame).  The gate block only reads predicates (atomic loads) and overwrites
-    // probabilities, so it needs no acquire either.
+    // visible to every XCD, so the ticket needs no release fence ("hand-offs inside a launch"; with plain stores
+    // every block would need an L2 write-back: measured 36 -> 58 us for a 1080p frame).  The gate block only reads predicates
+    // (atomic loads) and overwrites probabilities, so it needs no acquire either.
+    // The ticket is a two-level TREE: all blocks of a frame finish within a microsecond of each other, and agent-scope
+    // atomics on one word are served one at a time (~150 ns each: 96 blocks on a single ticket word kept the 1080p launch
+    // open for ~14 us after its last MFMA).  Eight blocks share a first-level word (own 128-byte line), its finisher moves the
+    // root; every word is reset by its finisher, so the tree is zero again when the launch ends.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0)  // tickets run on across launches (mod 2^32)
-        s_last = (__hip_atomic_fetch_add(tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == ticket_target);
+    if (threadIdx.x == 0) {
+        const unsigned bid = blockIdx.y * gridDim.x + blockIdx.x, nblk = gridDim.x * gridDim.y;
+        const unsigned l1 = bid >> 3, n_l1 = (nblk + 7) >> 3, in_l1 = min(8u, nblk - 8u * l1);
+        int* const root = gate + 2 * chunks + 32;  // (a fresh line behind the predicates)
+        int* const leaf = root + 32 * (1 + (int)l1);
+        int last = 0;
+        if ((unsigned)__hip_atomic_fetch_add(leaf, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == in_l1) {
+            __hip_atomic_store(leaf, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)__hip_atomic_fetch_add(root, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == n_l1) {
+                __hip_atomic_store(root, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = 1;
+            }
+        }
+        s_last = last;
+    }
     __syncthreads();
     if (!s_last) return;
     for (int ch = 0; ch < chunks; ++ch) {
@@ -297,10 +331,11 @@ __global__ __launch_bounds__(768) void k_lstm_heads(const float* __restrict__ st
 }
 
 unsigned lstm_heads_blocks(int n) { return (unsigned)((n + 15) / 16) * 3u; }
+// ints of the gate area of one frame of n CTUs: predicates + the ticket tree (root and one leaf per 8 blocks, a line each)
+int lstm_gate_words(int n) { return 2 * ((n + kSubBatch - 1) / kSubBatch) + 32 + 32 * (1 + ((int)lstm_heads_blocks(n) + 7) / 8); }
 
 void launch_lstm(const float* d_vec, const float* d_state_in, float* d_state_out, const float* d_lstm_blob, int n, int qp,
-                 int i_frame, float thr1, float thr2, float* d_raw, float* d_probs, int* d_gate, unsigned ticket_target,
-                 hipStream_t s) {
+                 int i_frame, float thr1, float thr2, float* d_raw, float* d_probs, int* d_gate, hipStream_t s) {
     LstmParams lp;
     lp.blob = d_lstm_blob;
     lp.efs[0] = ((float)qp / 51.0f) * 0.18f;  // net():283  qp / 51.0 * 0.18
@@ -309,8 +344,7 @@ void launch_lstm(const float* d_vec, const float* d_state_in, float* d_state_out
     const unsigned groups = (unsigned)((n + 15) / 16);
     if (groups >= 12) hipLaunchKernelGGL(k_lstm_cell<2>, dim3((groups + 1) / 2, 28), dim3(256), 0, s, d_vec, d_state_in, d_state_out, lp, n);
     else hipLaunchKernelGGL(k_lstm_cell<1>, dim3(groups, 28), dim3(256), 0, s, d_vec, d_state_in, d_state_out, lp, n);
-    hipLaunchKernelGGL(k_lstm_heads, dim3(groups, 3), dim3(768), 0, s, d_state_out, lp, n, thr1, thr2, d_raw, d_probs, d_gate,
-                       ticket_target);
+    hipLaunchKernelGGL(k_lstm_heads, dim3(groups, 3), dim3(768), 0, s, d_state_out, lp, n, thr1, thr2, d_raw, d_probs, d_gate);
 }
 
 }  // namespace ethcnn

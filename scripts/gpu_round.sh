@@ -56,9 +56,10 @@ def per_step(tag, counter):
     return (tot / steps, steps) if steps else (None, 0)
 (fe, n1), (wr, n2) = per_step("FETCH_SIZE","FETCH_SIZE"), per_step("WRITE_SIZE","WRITE_SIZE")
 if fe is not None and wr is not None:
-    import hashlib
-    _src = open("hevc-complexity-reduction_amd/csrc/ethcnn_dense.hip", "rb").read()
-    out = {wl: {"kernel_source_blob": hashlib.sha1(b"blob %d\0" % len(_src) + _src).hexdigest(),
+    import sys
+    sys.path.insert(0, ".")
+    import bench
+    out = {wl: {"kernel_source_blob": bench.fc1_source_stamp(),
                 "bytes_per_launch": int(fe*1024*2 + wr*1024), "fetch_size_kb_reported": fe, "write_size_kb_reported": wr,
                 "steps_averaged": n1, "algorithmic_bytes_per_launch": n*2688*4 + 2688*448*4 + n*448*4,
                 "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of `python bench.py --workload %s --no-cpu-baseline --no-host-scopes --steps 5 --warmup 1` (scripts/gpu_round.sh), summed over the FC1 dispatches of a step; FETCH_SIZE x2 (gfx950 correction)" % wl}}
