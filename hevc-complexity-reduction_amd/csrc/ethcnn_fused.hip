@@ -142,8 +142,10 @@ void launch_fc1_heads(const Workspace& ws, const DeviceWeights& w, int n, float 
     P.rem_blocks = (unsigned)((P.rem_tiles + 7) / 8) * 8 * 4;  // GROUP mapping: tiles in eights, 4 column blocks
     P.fc1_blocks = P.rem_blocks + (unsigned)((big_tiles + 7) / 8) * 8 * 4;
     P.heads_blocks = (unsigned)((n + 63) / 64) * 3u;
-    static const int exp_mode = [] { const char* e = getenv("ETHCNN_FUSED_EXP"); return e ? atoi(e) : 0; }();  // timing experiments only
-    if (exp_mode == 1) P.heads_blocks = 0;  // FC1 part alone (agent-scope stores + completion counters), no heads blocks: WRONG results
+#ifdef ETHCNN_EXPERIMENTS  // A/B builds only (scripts/build_variant.sh NAME -DETHCNN_EXPERIMENTS): these produce WRONG results
+    static const int exp_mode = [] { const char* e = getenv("ETHCNN_FUSED_EXP"); return e ? atoi(e) : 0; }();
+    if (exp_mode == 1) P.heads_blocks = 0;  // FC1 part alone (agent-scope stores + completion counters), no heads blocks
+#endif
     P.sync = ws.flags;
     P.nchunks = nchunks;
     for (int h = 0; h < 3; ++h) {

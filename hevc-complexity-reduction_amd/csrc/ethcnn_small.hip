@@ -49,7 +49,7 @@ struct SmallParams {
     GateIndex gi;
     float thr1, thr2;
     float *h2, *logits, *raw, *probs;
-    int exp;  // timing experiments only (env ETHCNN_SMALL_EXP): 1 = consumers do not wait (WRONG results)
+    int exp;  // 0 in production; timing experiments of -DETHCNN_EXPERIMENTS builds: 1 = consumers do not wait (WRONG results)
 };
 
 // ---- signalling.  Measured on MI355X (profiles/r03_small_pass.txt): agent-scope atomics and polls on ONE address are served
@@ -272,11 +272,14 @@ void launch_small_pass(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int
     P.logits = ws.logits;
     P.raw = ws.raw;
     P.probs = d_probs;
-    static const int exp_mode = [] { const char* e = getenv("ETHCNN_SMALL_EXP"); return e ? atoi(e) : 0; }();
-    P.exp = exp_mode;
+    P.exp = 0;
     unsigned blocks = (unsigned)(P.bS + P.bM + P.bL) + P.fc1_blocks + P.heads_blocks;
-    if (exp_mode == 2) blocks = (unsigned)(P.bS + P.bM + P.bL);                  // trunk part alone (timing only)
+#ifdef ETHCNN_EXPERIMENTS  // A/B builds only (scripts/build_variant.sh NAME -DETHCNN_EXPERIMENTS): these produce WRONG results
+    static const int exp_mode = [] { const char* e = getenv("ETHCNN_SMALL_EXP"); return e ? atoi(e) : 0; }();
+    P.exp = exp_mode;                                                            // 1: consumers do not wait
+    if (exp_mode == 2) blocks = (unsigned)(P.bS + P.bM + P.bL);                  // trunk part alone
     if (exp_mode == 3) blocks = (unsigned)(P.bS + P.bM + P.bL) + P.fc1_blocks;   // trunk + FC1
+#endif
     if (resi) launch_small_t<true>(P, shape, blocks, s);
     else launch_small_t<false>(P, shape, blocks, s);
 }
