@@ -188,6 +188,8 @@ struct ethcnn_ctx {
                              // Off by default: measured equal-to-1 % slower than the separate launches
     int gate_fold = 0;       // 1 = the heads launch applies the gates itself (sub-batch arrival counters); 0 = k5_gate launch behind it.
                              // Off by default: measured equal (single pictures) to 0.4 % slower (C3) than the separate launch (env ETHCNN_GATE_FOLD=1)
+    bool main_dirty = false; // main-stream work since e_main was last recorded (single-picture passes, LDP steps): the event is
+                             // recorded lazily, by the next PIPELINED pass -- not as a barrier packet behind every small call
     int overlap = 1;         // 1 = pass pipeline on (tile stage on its own stream, beside FC1 of the previous pass);
                              // 0 = every stage on the main stream (ethcnn_set_pass_pipeline, env ETHCNN_OVERLAP=0)
     int max_ctus = kMaxCtusPerPass;
@@ -671,7 +673,7 @@ static int make_geom(ethcnn_ctx* c, int w, int h, ptrdiff_t pitch, ptrdiff_t fst
 // "after all passes enqueued so far" is simply main-stream order.  Main-stream users of the workspace outside run_pass (LDP
 // front-end, LSTM step) only have to tell the NEXT pipelined tile stage, which runs on the side stream, to wait for them:
 static int serial_end(ethcnn_ctx* c) {
-    HIPCHK(c, hipEventRecord(c->e_main, c->stream));  // the next pipelined tile stage waits for it
+    c->main_dirty = true;  // the next pipelined tile stage records e_main behind this work and waits for it
     return 0;
 }
 
@@ -725,7 +727,7 @@ static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, lo
         if (!c->debug_capture) wv.h2 = wv.logits = wv.raw = nullptr;
         rc = run_small_pass(c, d_luma, g, ctu0, n, false, wv, w.h1, qn, d_probs_pass, (int)nchunks);
         if (rc) return rc;
-        if (c->overlap) HIPCHK(c, hipEventRecord(c->e_main, c->stream));  // a later pipelined tile stage must wait for this pass
+        c->main_dirty = true;  // a later pipelined tile stage must wait for this pass
         c->times.ctus += n;
         c->last_n = n;
         c->last_parity = p;
@@ -738,7 +740,11 @@ static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, lo
         // main stream is a barrier packet between two kernels (~7 us of idle GPU, rocprofv3 kernel trace): there is exactly
         // one per pipelined pass (e_trunk).  A never-recorded event is a no-op.
         HIPCHK(c, hipStreamWaitEvent(s_tile, c->e_trunk[p], 0));
-        HIPCHK(c, hipStreamWaitEvent(s_tile, c->e_main, 0));      // main-stream users of the workspace outside run_pass (LDP)
+        if (c->main_dirty) {  // main-stream users of the workspace since the last pipelined pass (small passes, LDP steps)
+            HIPCHK(c, hipEventRecord(c->e_main, c->stream));
+            c->main_dirty = false;
+        }
+        HIPCHK(c, hipStreamWaitEvent(s_tile, c->e_main, 0));
         // ... and it should run beside FC1(i-1), not beside trunk(i-1): with the trunk it competes for VALU issue and HBM
         // (measured: trunk 556 -> 819 us, tile 180 -> 511 us, step period 2.60 -> 2.73 ms; profiles/r02_overlap_trace.txt)
         HIPCHK(c, hipStreamWaitEvent(s_tile, c->e_trunk[p ^ 1], 0));
@@ -773,7 +779,7 @@ static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, lo
         LAUNCH_OK("heads / gate");
     }
 #undef LAUNCH_OK
-    if (!side_tile && c->overlap) HIPCHK(c, hipEventRecord(c->e_main, c->stream));  // a later pipelined tile stage must wait for this pass
+    if (!side_tile) c->main_dirty = true;  // a later pipelined tile stage must wait for this pass
     c->times.ctus += n;
     c->last_n = n;
     c->last_parity = p;

@@ -52,7 +52,7 @@ struct SmallParams {
     int exp;  // 0 in production; timing experiments of -DETHCNN_EXPERIMENTS builds: 1 = consumers do not wait (WRONG results)
 };
 
-// ---- signalling.  Measured on MI355X (profiles/r03_small_pass.txt): agent-scope atomics and polls on ONE address are served
+// ---- signalling.  Measured on MI355X (profiles/r03_small_pass_timeline.txt): agent-scope atomics and polls on ONE address are served
 // one at a time, ~150 ns each -- 224 blocks drawing tickets from one word cost 35 us, 28 blocks polling one counter delay the
 // producer's own add by microseconds.  So:
 //   * counters are only ever ADDED to (never polled): the add returns the old value, and the adder that completes a counter
