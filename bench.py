@@ -257,6 +257,8 @@ def main():
                 if not args.no_cpu_baseline:
                     result["cpu_baselines"] = cpu_baselines(luma, W, H, QP, cpu_seconds, yuv, full=(world == 1))
                     result["cpu_baseline"] = dict(result["cpu_baselines"][0])
+        if not ldp and world == 1 and not args.no_host_scopes:
+            result["single_picture_latency"] = single_picture_latency(ctx, QP)
         # sanity: the benchmark output is the real thing (first frame vs oracle), outside the timed region
         if not ldp:
             result["parity_first_frame_bit_exact"] = first_frame_parity(ctx, d_out, luma, W, H, QP, nctu)
@@ -411,6 +413,38 @@ def first_frame_parity(ctx, d_out, luma, W, H, QP, nctu):
         return bool(np.array_equal(got.view(np.uint32), want.view(np.uint32)))
     except Exception as exc:  # the oracle is a checker only; never fatal for the measurement
         return "unchecked: %s" % exc
+
+
+def single_picture_latency(ctx, QP):
+    """Side measurement (never `value`): one picture per call, luma resident in HBM, call + synchronise -- what the in-process
+    encoder hook and the LDP daemon pay per picture.  Single-launch pass (csrc/ethcnn_small.hip) vs the five-launch path."""
+    out = {"unit": "us per call (device-resident luma -> probabilities, incl. launch + synchronise)",
+           "note": "one launch = CTU gather + trunk -> FC1 -> heads -> gates as a dataflow inside one grid (default); five launches = "
+                   "tile / trunk / FC1 / heads / gate (ethcnn_set_small_pass_launch off)"}
+    try:
+        for name, w, h in (("768x512", 768, 512), ("1920x1080", 1920, 1080)):
+            luma = synth_luma(w, h, 1, 3)
+            nctu = ((w + 63) // 64) * ((h + 63) // 64)
+            d_in, d_out = ctx.alloc(luma.nbytes), ctx.alloc(nctu * 84)
+            d_in.upload(luma)
+            row = {}
+            for label, on in (("one_launch", True), ("five_launches", False)):
+                ctx.set_small_pass_launch(on)
+                for _ in range(30):
+                    ctx.predict_luma_device(d_in, w, h, 1, QP, d_out)
+                    ctx.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(200):
+                    ctx.predict_luma_device(d_in, w, h, 1, QP, d_out)
+                    ctx.synchronize()
+                row[label] = (time.perf_counter() - t0) / 200 * 1e6
+            ctx.set_small_pass_launch(True)
+            d_in.free()
+            d_out.free()
+            out[name] = row
+    except Exception as exc:  # a side measurement is never fatal
+        out["error"] = str(exc)
+    return out
 
 
 def decision_stability(ctx, luma, W, H, QP, frames=2):
