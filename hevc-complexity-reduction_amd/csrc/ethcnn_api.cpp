@@ -184,6 +184,7 @@ struct ethcnn_ctx {
     int* d_ssync = nullptr;  // its sync area: zero between launches by construction (every word is reset by its last user)
     int ssync_cap = 0;       // in ints
     bool ssync_clean = false;
+    int small_epoch = 0;     // claim tag of the last single-launch pass (1 .. 2^30, wraps: the area is re-zeroed then)
     int fused = 0;           // 1 = big passes run FC1 + heads + gates as ONE launch (ethcnn_set_fused_launch, env ETHCNN_FUSED=1).
                              // Off by default: measured equal-to-1 % slower than the separate launches
     int gate_fold = 0;       // 1 = the heads launch applies the gates itself (sub-batch arrival counters); 0 = k5_gate launch behind it.
@@ -682,21 +683,24 @@ static int serial_end(ethcnn_ctx* c) {
 static int run_small_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, bool resi, const Workspace& w,
                           float* fc1_out, float qn, float* d_probs, int nchunks) {
     const int words = small_pass_sync_words(n, nchunks);
+    if (c->small_epoch >= (1 << 30)) c->ssync_clean = false;  // tags start over on a freshly zeroed area
     if (words > c->ssync_cap || !c->ssync_clean) {
         if (words > c->ssync_cap) {
             HIPCHK(c, hipStreamSynchronize(c->stream));
             if (c->d_ssync) (void)hipFree(c->d_ssync);
             c->d_ssync = nullptr;
             c->ssync_cap = 0;
-            const int cap = std::max(words, small_pass_sync_words(kSmallPassMaxCtus, kSmallPassMaxCtus));  // ~0.7 MB, once
+            const int cap = words;  // fixed size (~0.5 MB), once
             HIPCHK(c, hipMalloc((void**)&c->d_ssync, (size_t)cap * sizeof(int)));
             c->ssync_cap = cap;
         }
         HIPCHK(c, hipMemsetAsync(c->d_ssync, 0, (size_t)c->ssync_cap * sizeof(int), c->stream));  // stream-ordered
+        c->small_epoch = 0;
     }
+    ++c->small_epoch;
     c->ssync_clean = false;  // until this launch has been enqueued without an error
     (void)hipGetLastError();
-    { StageTimer t(c, ETHCNN_STAGE_FC1, n); launch_small_pass(d_luma, g, ctu0, n, resi, w, c->dw, fc1_out, qn, c->thr1, c->thr2, d_probs, nchunks, c->d_ssync, c->stream); }
+    { StageTimer t(c, ETHCNN_STAGE_FC1, n); launch_small_pass(d_luma, g, ctu0, n, resi, w, c->dw, fc1_out, qn, c->thr1, c->thr2, d_probs, nchunks, c->d_ssync, c->small_epoch, c->stream); }
     const hipError_t le = hipGetLastError();
     if (le != hipSuccess) return set_err(c, ETHCNN_ERR_DEVICE, "launch of the single-launch small pass failed: %s", hipGetErrorString(le));
     c->ssync_clean = true;

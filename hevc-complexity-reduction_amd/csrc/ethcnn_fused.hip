@@ -21,6 +21,10 @@
 //     launch failure instead of a hung GPU).
 //   * the gates (tf.cond, net_CNN.py:175,187) are applied per sub-batch by the heads block that completes it (arrival
 //     counters, ethcnn_heads_pass.h): probabilities and predicates are agent-scope stores, completed before the block arrives.
+// SHARED GPUs: the "only waits for dispatched blocks" argument holds for ONE such launch on the GPU.  Two of them from different
+// processes can fill each other's XCDs with waiting blocks while their FC1 blocks queue behind (ethcnn_small.hip met exactly
+// that and grew a claim-or-execute path).  This launch plan has none: it is opt-in, measured slower than three launches, and
+// must not be selected when several processes share the GPU.
 // Counters and gate predicates live in one "sync area" that the pass's CTU-load stage zeroes (ethcnn_tile.hip).
 // Same accumulation chains as the separate kernels: results are bit-identical (the parity suite runs over both paths).
 #include <hip/hip_runtime.h>

@@ -50,14 +50,15 @@ void launch_fc1_heads(const Workspace& ws, const DeviceWeights& w, int n, float 
 inline int sync_words(int n, int nchunks) { return 3 * nchunks + (n + 63) / 64 + 8; }
 // A small pass (<= kSmallPassMaxCtus CTUs: up to one 3840x2160 picture; 16-byte aligned rows) as ONE launch (ethcnn_small.hip): CTU load + trunk -> FC1 ->
 // heads -> gates as a dataflow inside one grid (per-group / per-tile completion counters).  resi: the LDP front-end (stops
-// after FC1, fc1_out = the 448-vectors).  d_sync: small_pass_sync_words(n, nchunks) ints, ZERO on entry and zero again when
-// the launch has finished (its last block clears them).
+// after FC1, fc1_out = the 448-vectors).  d_sync: small_pass_sync_words(n, nchunks) ints, zeroed once; counters and flags are
+// zero again when a launch has finished (each is reset by its last user), claim words keep the epoch of their last launch.
+// epoch: a tag that differs from every earlier launch on this sync area and is never 0.
 constexpr int kSmallPassMaxCtus = 2304;  // beyond ~2300 CTUs the grid no longer fits the GPU at once and five full launches win (measured)
 bool small_pass_ok(const uint8_t* d_luma, const FrameGeom& g, int n);
 int small_pass_sync_words(int n, int nchunks);
 void launch_small_pass(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, bool resi, const Workspace& ws,
                        const DeviceWeights& w, float* fc1_out, float qn, float thr1, float thr2, float* d_probs, int nchunks,
-                       int* d_sync, hipStream_t s);
+                       int* d_sync, int epoch, hipStream_t s);
 // k5: apply the batch gates in place on d_probs
 void launch_gate(const Workspace& ws, int n, int nctu_per_frame, long ctu0, float thr2, float* d_probs,
                  hipStream_t s);

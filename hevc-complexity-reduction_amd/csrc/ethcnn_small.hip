@@ -50,6 +50,9 @@ struct SmallParams {
     float thr1, thr2;
     float *h2, *logits, *raw, *probs;
     int exp;  // 0 in production; timing experiments of -DETHCNN_EXPERIMENTS builds: 1 = consumers do not wait (WRONG results)
+    int epoch;      // this launch's claim tag (never 0; claim words hold the tag of the last launch that claimed them)
+    int steal_test; // 0 in production; k > 0: role blocks with id % k == 1 leave WITHOUT claiming and consumers have no patience,
+                    // so the items must be executed by the consumers that depend on them (tests; results stay correct)
 };
 
 // ---- signalling.  Measured on MI355X (profiles/r03_small_pass_timeline.txt): agent-scope atomics and polls on ONE address are served
@@ -73,8 +76,17 @@ struct SmallSync {
     int* fc1_flag;     // [fc1_blocks] x kPad  "your tile's features have landed", one per FC1 block
     int* fc1_done;     // [ntiles] x kPad      FC1 column blocks finished per tile
     int* heads_flag;   // [3 ngroups] x kPad   "your tile's h1 has landed", one per heads block (16 CTUs x head)
-    int words;
+    int words;         // of the part above: every word of it is zero between launches (reset by its last user)
+    // claim words (epoch tags, NEVER reset: a stale tag simply differs from the current one) live at FIXED offsets behind the
+    // largest possible self-cleaning part, because the layout above moves with the geometry and a stale tag must never be
+    // read as a counter or a flag of a later launch
+    int* claim_t;      // [trunk blocks] x kPad  claim word per trunk work item
+    int* claim_f;      // [fc1_blocks] x kPad    claim word per FC1 work item
 };
+constexpr int kMaxGroups = (kSmallPassMaxCtus + 15) / 16, kMaxTiles = (kSmallPassMaxCtus + 63) / 64, kMaxFc1Blocks = kMaxTiles * 28;
+constexpr int kClaimBase = 2 * kSmallPassMaxCtus + (kSmallPassMaxCtus + kPad - 1) / kPad * kPad + kPad +
+                           (kMaxGroups + kMaxTiles + kMaxFc1Blocks + kMaxTiles + 3 * kMaxGroups) * kPad;  // >= words for any n, nchunks <= n
+constexpr int kSyncTotalWords = kClaimBase + (6 * kMaxGroups + kMaxFc1Blocks) * kPad;
 __host__ __device__ inline SmallSync small_sync(int* base, int nchunks, int ngroups, int ntiles, int fc1_blocks) {  // (heads blocks = 3 ngroups)
     SmallSync s;
     s.pred = base;
@@ -85,6 +97,8 @@ __host__ __device__ inline SmallSync small_sync(int* base, int nchunks, int ngro
     s.fc1_done = s.fc1_flag + fc1_blocks * kPad;
     s.heads_flag = s.fc1_done + ntiles * kPad;
     s.words = (int)(s.heads_flag + 3 * ngroups * kPad - base);
+    s.claim_t = base + kClaimBase;
+    s.claim_f = s.claim_t + 6 * kMaxGroups * kPad;  // trunk blocks: 4 S + 1 M + 1 L per group
     return s;
 }
 
@@ -92,19 +106,25 @@ __device__ __forceinline__ int add_ret(int* p, int v) { return __hip_atomic_fetc
 __device__ __forceinline__ void put(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int get(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// one thread polls its block's private flag (bounded: a trap is a loud launch failure, never a hung GPU), then resets it
-__device__ __forceinline__ void wait_flag(int* p, int exp) {
-    if (exp == 1) return;
+// one thread polls its block's private flag, then resets it.  budget (100 MHz ticks) > 0: give up after that long and
+// return false (the caller then executes the unclaimed items it depends on); budget 0: wait until it comes -- every item
+// it stands for is claimed by a resident block by then.  The trap after 30 s of wall clock is a last resort against a hung
+// GPU (wall clock: a process descheduled under GPU sharing must not trip it).
+__device__ __forceinline__ bool wait_flag(int* p, int exp, unsigned long long budget) {
+    if (exp == 1) return true;
     unsigned long long t0;
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
     while (get(p) == 0) {
         __builtin_amdgcn_s_sleep(1);
         unsigned long long t;
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-        if (t - t0 > 200000000ull) __builtin_trap();  // 2 s at 100 MHz
+        if (budget != 0 && t - t0 > budget) return false;
+        if (t - t0 > 3000000000ull) __builtin_trap();
     }
     put(p, 0);
+    return true;
 }
+constexpr unsigned long long kPatience = 10000;  // 100 us
 
 #ifdef SMALL_STAMPS
 // development probe (scripts/ubench/small_probe.hip): device-wide 100 MHz stamps per block: entry, woken, computed, exit
@@ -122,56 +142,88 @@ __device__ __forceinline__ void small_stamp(int slot) {
 template <int A, int B>
 struct MaxOf { static constexpr int value = A > B ? A : B; };
 
-template <int NS, int NSUB, bool RESI>
-__global__ __launch_bounds__(256, 2) void k_small_pass(SmallParams P) {  // <= 256 registers: two blocks per CU
-    constexpr int NSPLIT = kNVec / (16 * NS);
-    constexpr int LDS_FLOATS = MaxOf<MaxOf<Fc1Shape<1, NS, 4, NSUB, 3>::LDS_FLOATS, kTrunkWFrags * 64 + 8 * 64 * 4>::value, kHeadsLatStages * kHeadsStage + 12 * 256>::value;
-    __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
-    __shared__ GateArrive s_ga;
-    const int bid = (int)blockIdx.x;
-    const int nT = P.bS + P.bM + P.bL;
-    const SmallSync Y = small_sync(P.sync, P.nchunks, P.ngroups, P.ntiles, (int)P.fc1_blocks);
+struct SmallShared {  // block-uniform scratch of the roles
+    int owned;   // this block holds the claim of the item it is working on
+    int woken;   // wait_flag's answer
+    GateArrive ga;
+};
+
+// ---- a trunk work item (+ CTU gather): items [0, 4 G) = S blocks (four tasks each), [4 G, 5 G) = M blocks, [5 G, 6 G) = L
+// blocks (one task, gathered by the four waves together), G = groups of 16 CTUs; every item belongs to ONE group.  Claims
+// the item (inside Trunk::run, under its first loads); the owner signals the group, the group's finisher the tile, the
+// tile's finisher wakes the FC1 blocks.  Called by the block the item was meant for -- or by a consumer tired of waiting.
+template <int NSPLIT, bool RESI>
+__device__ __forceinline__ void do_trunk_item(const SmallParams& P, const SmallSync& Y, int item, float* smem, SmallShared* sh) {
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    SMALL_STAMP(0);
-
-    if (bid < nT) {  // ---- trunk (+ CTU load): the block's tasks all belong to ONE group of 16 CTUs
-        int grp, ntask;
-        if (bid < P.bS) {
-            grp = bid >> 2; ntask = 4;
-            Trunk<0, RESI, true, true>::run(nullptr, P.ngroups * 16, bid * 4 + wv, P.bS * 4, P.trunk_w, P.trunk_b, P.feat, P.n, smem, &P.src);
-        } else if (bid < P.bS + P.bM) {
-            grp = bid - P.bS; ntask = 4;
-            Trunk<1, RESI, true, true>::run(nullptr, P.ngroups * 4, (bid - P.bS) * 4 + wv, P.bM * 4, P.trunk_w, P.trunk_b, P.feat, P.n, smem, &P.src);
-        } else {  // L: one task per BLOCK (the four waves gather the 64 KB of pixels together, wave 0 computes)
-            grp = bid - P.bS - P.bM; ntask = 1;
-            Trunk<2, RESI, true, true>::run(nullptr, P.ngroups, grp, P.bL, P.trunk_w, P.trunk_b, P.feat, P.n, smem, &P.src);
-        }
-        SMALL_STAMP(1);
-        // the block's features (agent-scope stores) have completed before its group's counter moves
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        SMALL_STAMP(2);
-        if (threadIdx.x == 0 && add_ret(Y.feat_done + grp * kPad, ntask) + ntask == 21) {  // 16 S + 4 M + 1 L: group complete
-            put(Y.feat_done + grp * kPad, 0);
-            const int tile = grp >> 2, in_tile = min(4, P.ngroups - 4 * tile);
-            if (add_ret(Y.tile_groups + tile * kPad, 1) + 1 == in_tile) {             // tile complete: wake its FC1 blocks
-                put(Y.tile_groups + tile * kPad, 0);
-                for (int nb = 0; nb < NSPLIT; ++nb) put(Y.fc1_flag + (tile * NSPLIT + nb) * kPad, 1);
-            }
-        }
-        SMALL_STAMP(3);
-        return;
+    int* const claim = Y.claim_t + item * kPad;
+    int grp, ntask;
+    if (item < P.bS) {
+        grp = item >> 2; ntask = 4;
+        Trunk<0, RESI, true, true>::run(nullptr, P.ngroups * 16, item * 4 + wv, P.bS * 4, P.trunk_w, P.trunk_b, P.feat, P.n, smem, &P.src, claim, P.epoch, &sh->owned);
+    } else if (item < P.bS + P.bM) {
+        grp = item - P.bS; ntask = 4;
+        Trunk<1, RESI, true, true>::run(nullptr, P.ngroups * 4, (item - P.bS) * 4 + wv, P.bM * 4, P.trunk_w, P.trunk_b, P.feat, P.n, smem, &P.src, claim, P.epoch, &sh->owned);
+    } else {
+        grp = item - P.bS - P.bM; ntask = 1;
+        Trunk<2, RESI, true, true>::run(nullptr, P.ngroups, grp, P.bL, P.trunk_w, P.trunk_b, P.feat, P.n, smem, &P.src, claim, P.epoch, &sh->owned);
     }
+    // the block's features (agent-scope stores) have completed before its group's counter moves
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0 && sh->owned && add_ret(Y.feat_done + grp * kPad, ntask) + ntask == 21) {  // 16 S + 4 M + 1 L: group complete
+        put(Y.feat_done + grp * kPad, 0);
+        const int tile = grp >> 2, in_tile = min(4, P.ngroups - 4 * tile);
+        if (add_ret(Y.tile_groups + tile * kPad, 1) + 1 == in_tile) {             // tile complete: wake its FC1 items
+            put(Y.tile_groups + tile * kPad, 0);
+            for (int nb = 0; nb < NSPLIT; ++nb) put(Y.fc1_flag + (tile * NSPLIT + nb) * kPad, 1);
+        }
+    }
+    __syncthreads();  // (smem and sh are free for the caller's next item)
+}
 
-    if (bid < nT + (int)P.fc1_blocks) {  // ---- FC1: 64 CTUs x 16 NS columns
-        const int fb = bid - nT;
-        const int nb = fb % NSPLIT, mt = fb / NSPLIT;
-        if (threadIdx.x == 0) wait_flag(Y.fc1_flag + fb * kPad, P.exp);
-        __syncthreads();
-        SMALL_STAMP(1);
-        fc1_tile_at<1, NS, 4, NSUB, 3, true, true>(smem, P.feat, P.wimg, P.fc1_b, P.h1, P.n, mt, nb);
-        SMALL_STAMP(2);
-        if (RESI) return;  // the vectors are the launch's output: nothing waits for them inside it
+// every thread of the block; patience: 0 = wait for the flag, whatever it takes
+__device__ __forceinline__ bool block_wait(int* flag, const SmallParams& P, SmallShared* sh, unsigned long long patience) {
+    if (threadIdx.x == 0) sh->woken = wait_flag(flag, P.exp, patience) ? 1 : 0;
+    __syncthreads();
+    const bool w = sh->woken != 0;
+    __syncthreads();
+    return w;
+}
+
+// ---- an FC1 work item: column block nb of 64-CTU tile mt.  Claims it, waits for the tile's features (executing the tile's
+// unclaimed trunk items itself when that takes too long), computes, signals the tile; the tile's finisher wakes its heads.
+template <int NS, int NSUB, bool RESI>
+__device__ __forceinline__ void do_fc1_item(const SmallParams& P, const SmallSync& Y, int fb, float* smem, SmallShared* sh) {
+    constexpr int NSPLIT = kNVec / (16 * NS);
+    if (threadIdx.x == 0) sh->owned = (__hip_atomic_exchange(Y.claim_f + fb * kPad, P.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != P.epoch);
+    __syncthreads();
+    const bool mine = sh->owned != 0;
+    __syncthreads();
+    if (!mine) return;
+    const int nb = fb % NSPLIT, mt = fb / NSPLIT;
+    if (!block_wait(Y.fc1_flag + fb * kPad, P, sh, P.steal_test ? 1 : kPatience)) {
+        // claim or execute: the trunk items of this tile's groups that nobody has claimed yet (an item that already carries
+        // this launch's tag needs no second look: the claim inside Trunk::run is only answered after its first loads)
+        const int g0 = 4 * mt, g1 = min(4 * mt + 4, P.ngroups);
+#pragma unroll 1
+        for (int g = g0; g < g1; ++g)
+#pragma unroll 1
+            for (int k = 0; k < 6; ++k) {  // 4 S blocks, the M block, the L block of the group
+                const int item = k < 4 ? 4 * g + k : (k == 4 ? P.bS + g : P.bS + P.bM + g);
+                // ONE thread looks and the block follows its answer: sixty-four loads of a word that is changing under them
+                // would split the block on the way into a function full of barriers
+                if (threadIdx.x == 0) sh->woken = (get(Y.claim_t + item * kPad) != P.epoch);
+                __syncthreads();
+                const bool unclaimed = __builtin_amdgcn_readfirstlane(sh->woken) != 0;
+                __syncthreads();
+                if (unclaimed) do_trunk_item<NSPLIT, RESI>(P, Y, item, smem, sh);
+            }
+        (void)block_wait(Y.fc1_flag + fb * kPad, P, sh, 0);  // every item of the tile is claimed by a resident block now
+    }
+    SMALL_STAMP(1);
+    fc1_tile_at<1, NS, 4, NSUB, 3, true, true>(smem, P.feat, P.wimg, P.fc1_b, P.h1, P.n, mt, nb);
+    SMALL_STAMP(2);
+    if (!RESI) {  // (LDP front-end: the vectors are the launch's output, nothing waits for them inside it)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0 && add_ret(Y.fc1_done + mt * kPad, 1) + 1 == NSPLIT) {  // all column blocks of the tile: wake its heads
@@ -179,19 +231,49 @@ __global__ __launch_bounds__(256, 2) void k_small_pass(SmallParams P) {  // <= 2
             const int g1 = min(4 * mt + 4, P.ngroups);
             for (int hb = 12 * mt; hb < 3 * g1; ++hb) put(Y.heads_flag + hb * kPad, 1);  // (group, head) blocks of the tile
         }
+    }
+    __syncthreads();
+}
+
+template <int NS, int NSUB, bool RESI>
+__global__ __launch_bounds__(256, 2) void k_small_pass(SmallParams P) {  // <= 256 registers: two blocks per CU
+    constexpr int NSPLIT = kNVec / (16 * NS);
+    constexpr int LDS_FLOATS = MaxOf<MaxOf<Fc1Shape<1, NS, 4, NSUB, 3>::LDS_FLOATS, kTrunkWFrags * 64 + 8 * 64 * 4>::value, kHeadsLatStages * kHeadsStage + 12 * 256>::value;
+    __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
+    __shared__ SmallShared sh;
+    const int bid = (int)blockIdx.x;
+    const int nT = P.bS + P.bM + P.bL;
+    const SmallSync Y = small_sync(P.sync, P.nchunks, P.ngroups, P.ntiles, (int)P.fc1_blocks);
+    SMALL_STAMP(0);
+    const bool is_producer = bid < nT + (int)P.fc1_blocks;
+    // tests: "this producer block never got a slot" -- only blocks somebody in this launch waits for (nobody waits for the FC1
+    // blocks of the LDP front-end: a late one of those simply runs late)
+    if (P.steal_test > 0 && (RESI ? bid < nT : is_producer) && bid % P.steal_test == 1) return;
+
+    if (bid < nT) {
+        do_trunk_item<NSPLIT, RESI>(P, Y, bid, smem, &sh);
         SMALL_STAMP(3);
         return;
     }
-
+    if (is_producer) {
+        do_fc1_item<NS, NSUB, RESI>(P, Y, bid - nT, smem, &sh);
+        SMALL_STAMP(3);
+        return;
+    }
     if (RESI) return;  // (no heads blocks are launched for the LDP front-end)
     // ---- one head of one group of 16 CTUs (the block's waves split the head's FC2 tiles: head_pass_split)
     const int hb = bid - nT - (int)P.fc1_blocks;
     const int grp = hb / 3, head_ = hb % 3;
-    if (threadIdx.x == 0) wait_flag(Y.heads_flag + hb * kPad, P.exp);
-    __syncthreads();
+    if (!block_wait(Y.heads_flag + hb * kPad, P, &sh, P.steal_test ? 1 : kPatience)) {
+        // claim or execute: the FC1 items of this group's tile (each of which does the same for its trunk items)
+        const int mt = grp >> 2;
+#pragma unroll 1
+        for (int nb = 0; nb < NSPLIT; ++nb) do_fc1_item<NS, NSUB, RESI>(P, Y, mt * NSPLIT + nb, smem, &sh);
+        (void)block_wait(Y.heads_flag + hb * kPad, P, &sh, 0);
+    }
     SMALL_STAMP(1);
     const int lane = threadIdx.x & 63;
-    const unsigned wvu = (unsigned)wv;
+    const unsigned wvu = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int N = P.n;
     const int ctu_raw = grp * 16 + (lane & 15);
     const bool valid = ctu_raw < N;
@@ -204,12 +286,16 @@ __global__ __launch_bounds__(256, 2) void k_small_pass(SmallParams P) {  // <= 2
     else head_pass_split<0>(smem, P.h1, P.hp, P.qn, lane, wvu, valid, ctu, h2row, P.logits, P.raw, P.probs, fl, fl + 1, P.thr1, P.thr2);
     // gates per sub-batch, applied by the block that completes it, which also hands its words back as zeros
     SMALL_STAMP(2);
-    heads_gates_arrive<true, 16>(Y.pred, Y.arrive, P.gi, N, grp * 16, P.thr2, P.probs, &s_ga);
+    heads_gates_arrive<true, 16>(Y.pred, Y.arrive, P.gi, N, grp * 16, P.thr2, P.probs, &sh.ga);
     SMALL_STAMP(3);
 }
 
-// upper bound over the FC1 shapes (28 column blocks per tile at most)
-int small_pass_sync_words(int n, int nchunks) { return small_sync(nullptr, nchunks, (n + 15) / 16, (n + 63) / 64, (n + 63) / 64 * 28).words; }
+// the whole area (fixed size: self-cleaning part for the largest pass + the claim words)
+int small_pass_sync_words(int n, int nchunks) {
+    (void)n;
+    (void)nchunks;
+    return kSyncTotalWords;
+}
 
 // rows must be 16-byte aligned for the direct gather (the tile stage's own fast-path condition)
 bool small_pass_ok(const uint8_t* d_luma, const FrameGeom& g, int n) {
@@ -227,7 +313,7 @@ static void launch_small_t(const SmallParams& P, int shape, unsigned blocks, hip
 
 void launch_small_pass(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, bool resi, const Workspace& ws,
                        const DeviceWeights& w, float* fc1_out, float qn, float thr1, float thr2, float* d_probs, int nchunks,
-                       int* d_sync, hipStream_t s) {
+                       int* d_sync, int epoch, hipStream_t s) {
     SmallParams P;
     P.src.luma = d_luma;
     P.src.width = g.width;
@@ -273,6 +359,9 @@ void launch_small_pass(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int
     P.raw = ws.raw;
     P.probs = d_probs;
     P.exp = 0;
+    P.epoch = epoch;
+    static const int steal_test = [] { const char* e = getenv("ETHCNN_SMALL_STEAL_TEST"); return e ? atoi(e) : 0; }();  // tests
+    P.steal_test = steal_test > 1 ? steal_test : 0;
     unsigned blocks = (unsigned)(P.bS + P.bM + P.bL) + P.fc1_blocks + P.heads_blocks;
 #ifdef ETHCNN_EXPERIMENTS  // A/B builds only (scripts/build_variant.sh NAME -DETHCNN_EXPERIMENTS): these produce WRONG results
     static const int exp_mode = [] { const char* e = getenv("ETHCNN_SMALL_EXP"); return e ? atoi(e) : 0; }();

@@ -200,9 +200,14 @@ struct Trunk {
     static __device__ __forceinline__ void run(const uint4* __restrict__ X, int ntasks, int wave, int nwaves,
                                                const float* __restrict__ wfrag, const float* __restrict__ bfrag,
                                                float* __restrict__ F, int N, float* wl, const DirectSrc* src = nullptr,
-                                               int* feat_done = nullptr) {
+                                               int* claim = nullptr, int tag = 0, int* s_owned = nullptr) {
         const int lane = threadIdx.x & 63;
         const int col = lane & 15, g = lane >> 4;
+        // single-launch pass: the block CLAIMS its work item (one exchange on the item's own word; `tag` = this launch's epoch).
+        // The answer is needed only after the weight-staging barrier below, so its round trip hides under the gather.  A block
+        // that finds the item already claimed (a waiting consumer executed it: ethcnn_small.hip, "claim or execute") leaves.
+        if (claim != nullptr && threadIdx.x == 0)
+            *s_owned = (__hip_atomic_exchange(claim, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag);
         // DIRECT (latency path): the pixel gather is requested FIRST, so that its memory round trip overlaps the weight staging
         // below.  (L blocks: all four waves take part in the gather's LDS exchange; waves 1..3 leave after the barriers.)
         uint4 raw[NJ];
@@ -216,6 +221,7 @@ struct Trunk {
             for (int i = threadIdx.x; i < kTrunkWFrags * 64; i += 256) wl[i] = wf[i];
         }
         __syncthreads();
+        if (claim != nullptr && !*s_owned) return;  // (block-uniform)
         if (!active) return;
         const float* wA2 = wl + 4 * 64 + lane;   // A2[t][s] = wA2[(t * 16 + s) * 64]
         const float* wA3 = wl + 36 * 64 + lane;  // A3[t][s] = wA3[(t * 24 + s) * 64]
@@ -366,10 +372,6 @@ struct Trunk {
                     *reinterpret_cast<f32x4*>(p_) = lrelu4(c3[0]);
                     *reinterpret_cast<f32x4*>(p_ + 1024) = lrelu4(c3[1]);
                 }
-            }
-            if (feat_done != nullptr) {  // single-launch pass: this task's features (agent-scope stores) have completed
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // before its group's completion counter moves (21 tasks per group)
-                if (lane == 0) __hip_atomic_fetch_add(feat_done + grp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }

@@ -199,7 +199,8 @@ int ethcnn_reset_stage_times(ethcnn_ctx* ctx);
  *   0 (default)  FC1 launch, heads launch, k5_gate launch;
  *   1            passes of >= 73,728 CTUs run FC1, the three heads and the gates as ONE launch (heads blocks appended to FC1's
  *                grid behind per-tile completion counters, gates applied per sub-batch by the block that completes it; time
- *                booked under ETHCNN_STAGE_FC1); env ETHCNN_FUSED=1 starts contexts in it;
+ *                booked under ETHCNN_STAGE_FC1); env ETHCNN_FUSED=1 starts contexts in it.  Its waiting blocks have no
+ *                claim-or-execute path (the single-launch small pass has): do NOT use it when several processes share the GPU;
  *   2            FC1 launch + heads launch that applies the gates itself (ETHCNN_STAGE_GATE counts no launches); env
  *                ETHCNN_GATE_FOLD=1.
  * Plans 1 and 2 were built in round 3 to remove launch boundaries and to fill FC1's draining rounds; measured on MI355X they

@@ -135,3 +135,41 @@ def test_long_sequences_of_single_launch_passes(pkg, oracle):
             case[5].free()
     finally:
         c.close()
+
+
+def test_claim_or_execute_when_producer_blocks_never_run(pkg, oracle):
+    """FORWARD PROGRESS of the dataflow launch when the GPU is shared: a consumer that has waited too long executes
+    the unclaimed work items it depends on itself.  ETHCNN_SMALL_STEAL_TEST=k makes every k-th producer block (trunk and FC1
+    alike) leave WITHOUT claiming its item -- as if it had never been given a slot -- and gives consumers no patience, so FC1
+    blocks must run trunk items and heads blocks must run FC1 items (which run trunk items).  Results stay bit-exact.  Run in
+    a subprocess (the knob is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    code = textwrap.dedent("""
+        import importlib, os, sys
+        import numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "oracle"))
+        import ethcnn_np as oracle
+        pkg = importlib.import_module("hevc-complexity-reduction_amd")
+        rng = np.random.default_rng(5)
+        blob = oracle.synth_blob(6, 4.0)
+        c = pkg.EthCnn(0)
+        c.load_blob(blob)
+        for (w, h, frames) in ((1920, 1080, 1), (768, 512, 1), (416, 240, 3), (3840, 2160, 1), (64, 64, 1)):
+            luma = rng.integers(0, 256, size=(frames, h, w), dtype=np.uint8)
+            for thr in ((0.5, 0.5), (0.9, 0.5), (2.0, -0.5)):
+                c.set_thresholds(*thr)
+                want = oracle.predict_frames(blob, luma, w, h, frames, 30, thr[0], thr[1], mode=0)
+                for rep in range(3):
+                    got = c.predict_luma(luma, w, h, frames, 30)
+                    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (w, h, thr, rep)
+            want_vec = oracle.resi_vectors(blob, luma[0], w, h, mode=0)
+            assert np.array_equal(c.resi_vectors(luma[0], w, h).view(np.uint32), want_vec.view(np.uint32)), (w, h)
+        print("steal ok")
+    """ % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    for k in ("2", "3", "7"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, ETHCNN_SMALL_STEAL_TEST=k))
+        assert r.returncode == 0 and "steal ok" in r.stdout, (k, r.stdout[-800:], r.stderr[-1500:])
