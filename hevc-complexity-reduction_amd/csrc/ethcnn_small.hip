@@ -124,7 +124,11 @@ __device__ __forceinline__ bool wait_flag(int* p, int exp, unsigned long long bu
     put(p, 0);
     return true;
 }
+#ifdef SMALL_NO_STEAL  // A/B builds only: the first form of the launch (wait for ever) -- to show what the shared-GPU test catches
+constexpr unsigned long long kPatience = 0;
+#else
 constexpr unsigned long long kPatience = 10000;  // 100 us
+#endif
 
 #ifdef SMALL_STAMPS
 // development probe (scripts/ubench/small_probe.hip): device-wide 100 MHz stamps per block: entry, woken, computed, exit

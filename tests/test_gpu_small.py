@@ -173,3 +173,65 @@ def test_claim_or_execute_when_producer_blocks_never_run(pkg, oracle):
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
                            env=dict(os.environ, ETHCNN_SMALL_STEAL_TEST=k))
         assert r.returncode == 0 and "steal ok" in r.stdout, (k, r.stdout[-800:], r.stderr[-1500:])
+
+
+def test_four_processes_share_the_gpu(pkg, oracle, tmp_path):
+    """The scenario that broke the first form of the dataflow launch: several PROCESSES issuing single-picture passes on one GPU
+    at the same time (their launches' waiting blocks can starve each other's producers; claim-or-execute keeps them moving).
+    Four processes that start together (file barrier) and each issue single-picture passes of three geometries back to back for
+    3 s (plus a 12,240-CTU pass now and then, whose long-running blocks skew the XCDs' dispatch progress), every 8th result
+    checked bit for bit; none may trap, hang, stall or fall silent."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import importlib, os, sys, time
+        import numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "oracle"))
+        import ethcnn_np as oracle
+        pkg = importlib.import_module("hevc-complexity-reduction_amd")
+        seed, gate = int(sys.argv[1]), sys.argv[2]
+        rng = np.random.default_rng(seed)
+        blob = oracle.synth_blob(6, 4.0)
+        c = pkg.EthCnn(0)
+        c.load_blob(blob)
+        cases = []
+        for (w, h) in ((1920, 1080), (768, 512), (3840, 2160)):
+            luma = rng.integers(0, 256, size=(h, w), dtype=np.uint8)
+            nctu = pkg.ethcnn.ctus_per_frame(w, h)
+            d_in, d_out = c.alloc(luma.nbytes), c.alloc(nctu * 84)
+            d_in.upload(luma)
+            cases.append((w, h, nctu, d_in, d_out, oracle.predict_frames(blob, luma, w, h, 1, 30, 0.5, 0.5, mode=0)))
+        open(os.path.join(gate, "ready%%d" %% seed), "w").close()
+        while len(os.listdir(gate)) < 4:
+            time.sleep(0.001)
+        t0, k = time.time(), 0
+        big_in, big_out = c.alloc(24 * 1080 * 1920), c.alloc(24 * 510 * 84)   # a many-CTU pass now and then: its long-running
+        big_in.upload(rng.integers(0, 256, size=24 * 1080 * 1920, dtype=np.uint8))  # blocks skew the XCDs' dispatch progress
+        while time.time() - t0 < float(os.environ.get('ETHCNN_SHARED_SECONDS', '3')) or k %% 8:
+            if k %% 32 == 8 * seed:
+                c.predict_luma_device(big_in, 1920, 1080, 24, 30, big_out)
+            w, h, nctu, d_in, d_out, want = cases[(k // 8 + seed) %% 3]
+            c.predict_luma_device(d_in, w, h, 1, 30, d_out)
+            if k %% 8 == 7:
+                c.synchronize()
+                got = d_out.download(np.float32, nctu * 21).reshape(-1, 21)
+                assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (seed, k)
+            k += 1
+        c.synchronize()
+        print("ok %%d %%d calls %%.2f s" %% (seed, k, time.time() - t0))
+    """ % (root, root))
+    gate = tmp_path / "gate"
+    gate.mkdir()
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(s), str(gate)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for s in range(4)]
+    for s, p in enumerate(procs):
+        out, err = p.communicate(timeout=300)
+        assert p.returncode == 0 and ("ok %d" % s) in out, (s, out[-500:], err[-1500:])
+        print(out.strip())
+        assert int(out.split()[2]) >= 400, out      # sharing the GPU four ways still leaves > 250 calls a second each
+        # the launch without claim-or-execute (A/B build -DSMALL_NO_STEAL) passes the value checks but in 4 of 6 runs STALLS here for
+        # 4-17 s (until the driver's queue preemption unties the processes) or traps (profiles/r03_shared_gpu_ab.txt)
+        assert float(out.split()[4]) < 2.0 + float(os.environ.get('ETHCNN_SHARED_SECONDS', '3')), out
