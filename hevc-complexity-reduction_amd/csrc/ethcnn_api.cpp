@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -187,6 +188,12 @@ struct ethcnn_ctx {
     int small_epoch = 0;     // claim tag of the last single-launch pass (1 .. 2^30, wraps: the area is re-zeroed then)
     int fused = 0;           // 1 = big passes run FC1 + heads + gates as ONE launch (ethcnn_set_fused_launch, env ETHCNN_FUSED=1).
                              // Off by default: measured equal-to-1 % slower than the separate launches
+    // completion word (page-locked host memory): the last block of a latency-path launch stores the launch's sequence number
+    // there and the host spins on it instead of calling hipStreamSynchronize (~5 us sooner, scripts/ubench/launch_rtt.hip)
+    unsigned* h_done = nullptr;
+    unsigned done_seq = 0;     // last number handed out
+    unsigned done_armed = 0;   // != 0: the LAST operation enqueued on the main stream stores this number when all its outputs are final
+    int done_sync = 1;         // env ETHCNN_DONE_WORD=0: always hipStreamSynchronize (A/B runs)
     int gate_fold = 0;       // 1 = the heads launch applies the gates itself (sub-batch arrival counters); 0 = k5_gate launch behind it.
                              // Off by default: measured equal (single pictures) to 0.4 % slower (C3) than the separate launch (env ETHCNN_GATE_FOLD=1)
     bool main_dirty = false; // main-stream work since e_main was last recorded (single-picture passes, LDP steps): the event is
@@ -343,6 +350,12 @@ extern "C" int ethcnn_create(ethcnn_ctx** out, const ethcnn_options* opt) {
     if (const char* e = std::getenv("ETHCNN_SMALL")) c->small_launch = std::atoi(e) != 0;  // development knob (A/B runs)
     if (const char* e = std::getenv("ETHCNN_FUSED")) c->fused = std::atoi(e) != 0;      // development knob (A/B runs)
     if (const char* e = std::getenv("ETHCNN_GATE_FOLD")) c->gate_fold = std::atoi(e) != 0;  // development knob (A/B runs)
+    if (const char* e = std::getenv("ETHCNN_DONE_WORD")) c->done_sync = std::atoi(e) != 0;  // development knob (A/B runs)
+    if (hipHostMalloc((void**)&c->h_done, 64, hipHostMallocDefault) != hipSuccess) {
+        ethcnn_destroy(c);
+        return set_err(nullptr, ETHCNN_ERR_DEVICE, "cannot allocate the completion word on device %d", dev);
+    }
+    *c->h_done = 0;
     c->tile_blocks = prop.multiProcessorCount;
     {   // the GPU's NUMA node -> its CPU list (/sys/devices/system/node/nodeN/cpulist: "64-127,192-255"); ETHCNN_NUMA_BIND=0 opts out
         int node = -1;
@@ -415,6 +428,7 @@ static void free_staging(ethcnn_ctx* c) {
 }
 
 extern "C" void ethcnn_destroy(ethcnn_ctx* c) {
+    if (c && c->h_done) { (void)hipDeviceSynchronize(); (void)hipHostFree(c->h_done); c->h_done = nullptr; }
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
@@ -673,6 +687,29 @@ static int make_geom(ethcnn_ctx* c, int w, int h, ptrdiff_t pitch, ptrdiff_t fst
 // Everything a pass leaves in flight ends on the main stream (its tile stage is always followed by its own trunk there), so
 // "after all passes enqueued so far" is simply main-stream order.  Main-stream users of the workspace outside run_pass (LDP
 // front-end, LSTM step) only have to tell the NEXT pipelined tile stage, which runs on the side stream, to wait for them:
+// ---- completion word.  done_arm: number for a launch whose last block will store it; the caller sets c->done_armed once the
+// launch is enqueued.  Every other enqueue on the main stream clears done_armed first (the word would not cover it).
+static unsigned done_arm(ethcnn_ctx* c) {
+    if (!c->done_sync || !c->h_done) return 0;
+    if (++c->done_seq == 0) ++c->done_seq;
+    return c->done_seq;
+}
+// wait for everything enqueued on the main stream: through the completion word when the last enqueued launch carries one
+// (bounded: a launch that never reports -- a device fault -- falls through to hipStreamSynchronize, which returns the error)
+static hipError_t stream_sync(ethcnn_ctx* c) {
+    const unsigned seq = c->done_armed;
+    c->done_armed = 0;
+    if (seq) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 1;; ++spins) {
+            if (__atomic_load_n(c->h_done, __ATOMIC_ACQUIRE) == seq) return hipSuccess;
+            _mm_pause();
+            if ((spins & 4095u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
+        }
+    }
+    return hipStreamSynchronize(c->stream);
+}
+
 static int serial_end(ethcnn_ctx* c) {
     c->main_dirty = true;  // the next pipelined tile stage records e_main behind this work and waits for it
     return 0;
@@ -683,6 +720,7 @@ static int serial_end(ethcnn_ctx* c) {
 static int run_small_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, bool resi, const Workspace& w,
                           float* fc1_out, float qn, float* d_probs, int nchunks) {
     const int words = small_pass_sync_words(n, nchunks);
+    c->done_armed = 0;
     if (c->small_epoch >= (1 << 30)) c->ssync_clean = false;  // tags start over on a freshly zeroed area
     if (words > c->ssync_cap || !c->ssync_clean) {
         if (words > c->ssync_cap) {
@@ -700,10 +738,12 @@ static int run_small_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom&
     ++c->small_epoch;
     c->ssync_clean = false;  // until this launch has been enqueued without an error
     (void)hipGetLastError();
-    { StageTimer t(c, ETHCNN_STAGE_FC1, n); launch_small_pass(d_luma, g, ctu0, n, resi, w, c->dw, fc1_out, qn, c->thr1, c->thr2, d_probs, nchunks, c->d_ssync, c->small_epoch, c->stream); }
+    const unsigned seq = resi ? 0u : done_arm(c);
+    { StageTimer t(c, ETHCNN_STAGE_FC1, n); launch_small_pass(d_luma, g, ctu0, n, resi, w, c->dw, fc1_out, qn, c->thr1, c->thr2, d_probs, nchunks, c->d_ssync, c->small_epoch, seq ? c->h_done : nullptr, seq, c->stream); }
     const hipError_t le = hipGetLastError();
     if (le != hipSuccess) return set_err(c, ETHCNN_ERR_DEVICE, "launch of the single-launch small pass failed: %s", hipGetErrorString(le));
     c->ssync_clean = true;
+    c->done_armed = seq;
     return 0;
 }
 
@@ -714,6 +754,7 @@ static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, lo
     const int cpf = chunks_per_frame(g.nctu);
     const long nchunks = (ctu0 + n - 1) / g.nctu * cpf + ((ctu0 + n - 1) % g.nctu) / kSubBatch + 1 -
                          (ctu0 / g.nctu * cpf + (ctu0 % g.nctu) / kSubBatch);
+    c->done_armed = 0;
     int rc = ensure_workspace(c, n, (int)nchunks);
     if (rc) return rc;
     const float qn = (float)qp * (1.0f / 51.0f);  // net_CNN.py:106
@@ -1052,7 +1093,11 @@ static int predict_luma_latency(ethcnn_ctx* c, const uint8_t* luma, int w, int h
         if (rc) break;
     }
     if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
+    // (letting the single-launch pass write the probabilities straight into page-locked host memory and report through the
+    // completion word was measured 3 us SLOWER than this copy + hipStreamSynchronize: 96 heads blocks storing 4-byte words
+    // over PCIe; profiles/r03_completion_word.txt)
     float* dst = in_pinned(c, probs, out_bytes) ? probs : c->h_out[0];
+    c->done_armed = 0;
     HIPCHK(c, hipMemcpyAsync(dst, c->d_out[0], out_bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (dst != probs) std::memcpy(probs, dst, out_bytes);
@@ -1177,6 +1222,7 @@ extern "C" int ethcnn_predict_yuv_shard(ethcnn_ctx* c, const char* yuv, int w, i
 
 // -------------------------------------------------------------- config #5 -----------
 extern "C" int ethcnn_resi_vectors_device(ethcnn_ctx* c, const uint8_t* d_luma, int w, int h, ptrdiff_t pitch, float* d_vec) {
+    if (c) c->done_armed = 0;
     if (!c || !d_luma || !d_vec) return c ? set_err(c, ETHCNN_ERR_ARG, "null pointer") : ETHCNN_ERR_ARG;
     if (!c->have_weights) return set_err(c, ETHCNN_ERR_NOWEIGHTS, "no weights loaded");
     FrameGeom g;
@@ -1290,6 +1336,7 @@ static int ensure_lstm_buffers(ethcnn_ctx* c, int n) {
 extern "C" int ethcnn_lstm_step_device(ethcnn_ctx* c, const float* d_vec, const float* d_state_in, int n, int qp,
                                        int i_frame, float* d_state_out, float* d_probs) {
     if (!c || !d_vec || !d_state_out || !d_probs) return c ? set_err(c, ETHCNN_ERR_ARG, "null pointer") : ETHCNN_ERR_ARG;
+    c->done_armed = 0;
     if (n <= 0) return set_err(c, ETHCNN_ERR_ARG, "n must be positive");
     if (!c->have_lstm) return set_err(c, ETHCNN_ERR_NOWEIGHTS, "no LSTM weights loaded");
     HIPCHK(c, hipSetDevice(c->device));
@@ -1312,13 +1359,15 @@ extern "C" int ethcnn_lstm_step_device(ethcnn_ctx* c, const float* d_vec, const 
         HIPCHK(c, hipMemsetAsync(c->d_lgate, 0, (size_t)c->lgate_chunks * sizeof(int), c->stream));  // stream-ordered
     }
     c->lgate_clean = false;  // until this launch has been enqueued without an error
+    const unsigned seq = done_arm(c);
     {
         StageTimer t(c, ETHCNN_STAGE_HEADS);
         launch_lstm(d_vec, d_state_in, d_state_out, c->d_lstm, n, qp, i_frame, c->thr1, c->thr2, c->debug_capture ? c->ws.raw : nullptr,
-                    d_probs, c->d_lgate, c->stream);
+                    d_probs, c->d_lgate, seq ? c->h_done : nullptr, seq, c->stream);
     }
     HIPCHK(c, hipGetLastError());
     c->lgate_clean = true;
+    c->done_armed = seq;
     c->last_n = n;
     return serial_end(c);
 }
@@ -1370,15 +1419,21 @@ static int ldp_step_impl(ethcnn_ctx* c, const uint8_t* luma, int w, int h, ptrdi
     if (in_place) d_luma = luma;
     else HIPCHK(c, hipMemcpyAsync(c->d_in[0], luma, lbytes, hipMemcpyHostToDevice, c->stream));
     const size_t pbytes = (size_t)nctu * kNOut * 4;
-    float* d_probs = in_pinned(c, probs, pbytes) ? probs : c->d_lprobs;
+    // probabilities: straight into page-locked host memory (the caller's, else the staging buffer + one memcpy), the launch's
+    // last block reports through the completion word
+    float* d_probs = in_pinned(c, probs, pbytes) ? probs : (c->done_sync ? c->h_out[0] : c->d_lprobs);
     c->luma_over_pcie = (d_luma == luma);
     rc = ethcnn_resi_vectors_device(c, d_luma, w, h, pitch, c->d_vec);
     c->luma_over_pcie = false;
     if (rc) return rc;
     rc = ethcnn_lstm_step_device(c, c->d_vec, in >= 0 ? c->d_state[in] : nullptr, nctu, qp, i_frame, c->d_state[out], d_probs);
     if (rc) return rc;
-    if (d_probs != probs) HIPCHK(c, hipMemcpyAsync(probs, c->d_lprobs, pbytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (d_probs == c->d_lprobs) {
+        c->done_armed = 0;
+        HIPCHK(c, hipMemcpyAsync(probs, c->d_lprobs, pbytes, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, stream_sync(c));
+    if (d_probs == c->h_out[0]) std::memcpy(probs, d_probs, pbytes);
     c->state_cur = out;
     c->state_nctu = nctu;
     return ETHCNN_OK;
@@ -1455,7 +1510,7 @@ extern "C" int ethcnn_memcpy_d2h(ethcnn_ctx* c, void* dst, const void* src, size
 extern "C" int ethcnn_synchronize(ethcnn_ctx* c) {
     if (!c) return ETHCNN_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_sync(c));
     return ETHCNN_OK;
 }
 

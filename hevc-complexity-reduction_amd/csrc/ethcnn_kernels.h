@@ -58,7 +58,7 @@ bool small_pass_ok(const uint8_t* d_luma, const FrameGeom& g, int n);
 int small_pass_sync_words(int n, int nchunks);
 void launch_small_pass(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, bool resi, const Workspace& ws,
                        const DeviceWeights& w, float* fc1_out, float qn, float thr1, float thr2, float* d_probs, int nchunks,
-                       int* d_sync, int epoch, hipStream_t s);
+                       int* d_sync, int epoch, unsigned* done, unsigned done_seq, hipStream_t s);
 // k5: apply the batch gates in place on d_probs
 void launch_gate(const Workspace& ws, int n, int nctu_per_frame, long ctu0, float thr2, float* d_probs,
                  hipStream_t s);
@@ -69,7 +69,8 @@ void launch_gate(const Workspace& ws, int n, int nctu_per_frame, long ctu0, floa
 unsigned lstm_heads_blocks(int n);
 int lstm_gate_words(int n);
 void launch_lstm(const float* d_vec, const float* d_state_in, float* d_state_out, const float* d_lstm_blob, int n, int qp,
-                 int i_frame, float thr1, float thr2, float* d_raw, float* d_probs, int* d_gate, hipStream_t s);
+                 int i_frame, float thr1, float thr2, float* d_raw, float* d_probs, int* d_gate, unsigned* done, unsigned done_seq,
+                 hipStream_t s);  // done: completion word in page-locked host memory (null: none), stored by the heads launch's last block
 
 int chunks_per_frame(int nctu);
 

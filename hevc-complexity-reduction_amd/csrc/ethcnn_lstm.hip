@@ -271,7 +271,7 @@ __device__ __forceinline__ void lstm_heads(const LstmParams& lp, const float* __
 // launch instead of three (memset of the predicates, heads, gate) in a latency-bound chain.
 __global__ __launch_bounds__(768) void k_lstm_heads(const float* __restrict__ state_out, LstmParams lp, int N, float thr1,
                                                     float thr2, float* __restrict__ raw, float* __restrict__ probs,
-                                                    int* __restrict__ gate) {
+                                                    int* __restrict__ gate, unsigned* done, unsigned done_seq) {
     __shared__ f32x4 h2T[12 * 64];
     __shared__ int s_last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -328,6 +328,13 @@ __global__ __launch_bounds__(768) void k_lstm_heads(const float* __restrict__ st
     }
     __syncthreads();  // every thread has read the predicates
     for (int i = threadIdx.x; i < 2 * chunks; i += 768) __hip_atomic_store(pred + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // completion word (page-locked host memory): every block's probabilities had completed before its ticket, this block's
+    // zero-fills complete here; the host thread spinning on the word sees the frame ~5 us before hipStreamSynchronize returns
+    if (done) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(done, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 unsigned lstm_heads_blocks(int n) { return (unsigned)((n + 15) / 16) * 3u; }
@@ -335,7 +342,8 @@ unsigned lstm_heads_blocks(int n) { return (unsigned)((n + 15) / 16) * 3u; }
 int lstm_gate_words(int n) { return 2 * ((n + kSubBatch - 1) / kSubBatch) + 32 + 32 * (1 + ((int)lstm_heads_blocks(n) + 7) / 8); }
 
 void launch_lstm(const float* d_vec, const float* d_state_in, float* d_state_out, const float* d_lstm_blob, int n, int qp,
-                 int i_frame, float thr1, float thr2, float* d_raw, float* d_probs, int* d_gate, hipStream_t s) {
+                 int i_frame, float thr1, float thr2, float* d_raw, float* d_probs, int* d_gate, unsigned* done, unsigned done_seq,
+                 hipStream_t s) {
     LstmParams lp;
     lp.blob = d_lstm_blob;
     lp.efs[0] = ((float)qp / 51.0f) * 0.18f;  // net():283  qp / 51.0 * 0.18
@@ -344,7 +352,7 @@ void launch_lstm(const float* d_vec, const float* d_state_in, float* d_state_out
     const unsigned groups = (unsigned)((n + 15) / 16);
     if (groups >= 12) hipLaunchKernelGGL(k_lstm_cell<2>, dim3((groups + 1) / 2, 28), dim3(256), 0, s, d_vec, d_state_in, d_state_out, lp, n);
     else hipLaunchKernelGGL(k_lstm_cell<1>, dim3(groups, 28), dim3(256), 0, s, d_vec, d_state_in, d_state_out, lp, n);
-    hipLaunchKernelGGL(k_lstm_heads, dim3(groups, 3), dim3(768), 0, s, d_state_out, lp, n, thr1, thr2, d_raw, d_probs, d_gate);
+    hipLaunchKernelGGL(k_lstm_heads, dim3(groups, 3), dim3(768), 0, s, d_state_out, lp, n, thr1, thr2, d_raw, d_probs, d_gate, done, done_seq);
 }
 
 }  // namespace ethcnn

@@ -51,6 +51,8 @@ struct SmallParams {
     float *h2, *logits, *raw, *probs;
     int exp;  // 0 in production; timing experiments of -DETHCNN_EXPERIMENTS builds: 1 = consumers do not wait (WRONG results)
     int epoch;      // this launch's claim tag (never 0; claim words hold the tag of the last launch that claimed them)
+    unsigned* done;      // completion word in page-locked HOST memory (null: none) ...
+    unsigned done_seq;   // ... the launch's last finishing block stores this value there, after every output of the launch
     int steal_test; // 0 in production; k > 0: role blocks with id % k == 1 leave WITHOUT claiming and consumers have no patience,
                     // so the items must be executed by the consumers that depend on them (tests; results stay correct)
 };
@@ -76,6 +78,7 @@ struct SmallSync {
     int* fc1_flag;     // [fc1_blocks] x kPad  "your tile's features have landed", one per FC1 block
     int* fc1_done;     // [ntiles] x kPad      FC1 column blocks finished per tile
     int* heads_flag;   // [3 ngroups] x kPad   "your tile's h1 has landed", one per heads block (16 CTUs x head)
+    int* done_cnt;     // [1] x kPad           gate sub-batches completed (nchunks = the launch's outputs are final)
     int words;         // of the part above: every word of it is zero between launches (reset by its last user)
     // claim words (epoch tags, NEVER reset: a stale tag simply differs from the current one) live at FIXED offsets behind the
     // largest possible self-cleaning part, because the layout above moves with the geometry and a stale tag must never be
@@ -85,7 +88,7 @@ struct SmallSync {
 };
 constexpr int kMaxGroups = (kSmallPassMaxCtus + 15) / 16, kMaxTiles = (kSmallPassMaxCtus + 63) / 64, kMaxFc1Blocks = kMaxTiles * 28;
 constexpr int kClaimBase = 2 * kSmallPassMaxCtus + (kSmallPassMaxCtus + kPad - 1) / kPad * kPad + kPad +
-                           (kMaxGroups + kMaxTiles + kMaxFc1Blocks + kMaxTiles + 3 * kMaxGroups) * kPad;  // >= words for any n, nchunks <= n
+                           (kMaxGroups + kMaxTiles + kMaxFc1Blocks + kMaxTiles + 3 * kMaxGroups + 1) * kPad;  // >= words for any n, nchunks <= n
 constexpr int kSyncTotalWords = kClaimBase + (6 * kMaxGroups + kMaxFc1Blocks) * kPad;
 __host__ __device__ inline SmallSync small_sync(int* base, int nchunks, int ngroups, int ntiles, int fc1_blocks) {  // (heads blocks = 3 ngroups)
     SmallSync s;
@@ -96,7 +99,8 @@ __host__ __device__ inline SmallSync small_sync(int* base, int nchunks, int ngro
     s.fc1_flag = s.tile_groups + ntiles * kPad;
     s.fc1_done = s.fc1_flag + fc1_blocks * kPad;
     s.heads_flag = s.fc1_done + ntiles * kPad;
-    s.words = (int)(s.heads_flag + 3 * ngroups * kPad - base);
+    s.done_cnt = s.heads_flag + 3 * ngroups * kPad;
+    s.words = (int)(s.done_cnt + kPad - base);
     s.claim_t = base + kClaimBase;
     s.claim_f = s.claim_t + 6 * kMaxGroups * kPad;  // trunk blocks: 4 S + 1 M + 1 L per group
     return s;
@@ -291,6 +295,18 @@ __global__ __launch_bounds__(256, 2) void k_small_pass(SmallParams P) {  // <= 2
     // gates per sub-batch, applied by the block that completes it, which also hands its words back as zeros
     SMALL_STAMP(2);
     heads_gates_arrive<true, 16>(Y.pred, Y.arrive, P.gi, N, grp * 16, P.thr2, P.probs, &sh.ga);
+    // completion word: a host thread spinning on a word in page-locked memory sees the end of the launch ~5 us before
+    // hipStreamSynchronize returns (scripts/ubench/launch_rtt.hip).  Every sub-batch is completed by exactly one block; the
+    // block that completes the last one has seen, through the arrival counters, every probability of the launch stored
+    // (s_waitcnt vmcnt(0) before each arrival) -- its own zero-fills included once it has waited for them here.
+    if (P.done && sh.ga.n > 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0 && add_ret(Y.done_cnt, sh.ga.n) + sh.ga.n == P.nchunks) {
+            put(Y.done_cnt, 0);
+            __hip_atomic_store(P.done, P.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
     SMALL_STAMP(3);
 }
 
@@ -317,8 +333,10 @@ static void launch_small_t(const SmallParams& P, int shape, unsigned blocks, hip
 
 void launch_small_pass(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, bool resi, const Workspace& ws,
                        const DeviceWeights& w, float* fc1_out, float qn, float thr1, float thr2, float* d_probs, int nchunks,
-                       int* d_sync, int epoch, hipStream_t s) {
+                       int* d_sync, int epoch, unsigned* done, unsigned done_seq, hipStream_t s) {
     SmallParams P;
+    P.done = resi ? nullptr : done;  // (the LDP front-end is not the end of its call)
+    P.done_seq = done_seq;
     P.src.luma = d_luma;
     P.src.width = g.width;
     P.src.height = g.height;

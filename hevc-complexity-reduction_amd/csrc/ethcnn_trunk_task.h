@@ -213,6 +213,21 @@ struct Trunk {
         uint4 raw[NJ];
         bool active = wave < ntasks;
         if (DIRECT && active) active = load_direct(*src, wave, lane, raw, reinterpret_cast<uint4*>(wl + kTrunkWFrags * 64));
+        // bias fragments: requested BEFORE the staging barrier (loads cannot be moved across it by the compiler, and behind it
+        // they are one more exposed memory round trip of a block that has nothing else to do yet: single-launch pass)
+        f32x4 B1, B2[2], B3[2];
+        {
+            const float* bf = bfrag + (size_t)BR * kTrunkBFrags * 64 + lane;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) B1[r] = bf[r * 64];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    B2[t][r] = bf[(4 + t * 4 + r) * 64];
+                    B3[t][r] = bf[(12 + t * 4 + r) * 64];
+                }
+        }
         // conv2 / conv3 A-operand fragments of this branch -> LDS, once per block (80 of the 84
         // fragments; every MFMA fetches its A operand with one conflict-free ds_read_b32, which costs
         // the matrix pipe nothing, and frees 80 VGPRs: three waves per SIMD instead of two)
@@ -227,21 +242,8 @@ struct Trunk {
         const float* wA3 = wl + 36 * 64 + lane;  // A3[t][s] = wA3[(t * 24 + s) * 64]
 
         float A1[4];
-        f32x4 B1, B2[2], B3[2];
-        {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) A1[s] = wl[s * 64 + lane];
-            const float* bf = bfrag + (size_t)BR * kTrunkBFrags * 64 + lane;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) B1[r] = bf[r * 64];
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    B2[t][r] = bf[(4 + t * 4 + r) * 64];
-                    B3[t][r] = bf[(12 + t * 4 + r) * 64];
-                }
-        }
+        for (int s = 0; s < 4; ++s) A1[s] = wl[s * 64 + lane];
 
         // buffer addressing: SGPR resource + SGPR task / slot offset + ONE VGPR lane offset per instruction.
         // The 128-bit STORES keep their whole offset in the VGPR (one v_add each) and soffset = 0: with an SGPR soffset

@@ -352,6 +352,11 @@ class EthCnn(object):
         self._chk(self.lib.ethcnn_resi_vectors(self.h, luma.ctypes.data, width, height, pitch, out.ctypes.data_as(_fp)))
         return out
 
+    def resi_vectors_device(self, d_luma, width, height, d_vec, pitch=None):
+        """asynchronous: LDP front-end on device buffers (ethcnn_resi_vectors_device)"""
+        pitch = width if pitch is None else pitch
+        self._chk(self.lib.ethcnn_resi_vectors_device(self.h, d_luma.ptr, width, height, pitch, d_vec.ptr))
+
     # -- config #5 back-end: ETH-LSTM one step (resi_to_cu_depth_LDP.py:108-129)
     def load_lstm_checkpoint(self, prefix):
         self._chk(self.lib.ethcnn_load_lstm_checkpoint(self.h, os.fsencode(prefix)))

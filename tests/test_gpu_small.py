@@ -235,3 +235,55 @@ def test_four_processes_share_the_gpu(pkg, oracle, tmp_path):
         # the launch without claim-or-execute (A/B build -DSMALL_NO_STEAL) passes the value checks but in 4 of 6 runs STALLS here for
         # 4-17 s (until the driver's queue preemption unties the processes) or traps (profiles/r03_shared_gpu_ab.txt)
         assert float(out.split()[4]) < 2.0 + float(os.environ.get('ETHCNN_SHARED_SECONDS', '3')), out
+
+
+def test_completion_word_only_covers_the_last_launch(pkg, oracle):
+    """ethcnn_synchronize returns through the completion word of a single-launch pass (a word in page-locked memory stored by the
+    launch's last block, ~5 us sooner than hipStreamSynchronize) ONLY when that pass is the last thing enqueued: a long
+    pipelined call or an LDP front-end enqueued behind it must be waited for the ordinary way.  Outputs are poisoned before
+    every round, so a synchronize that returned early would be seen."""
+    rng = np.random.default_rng(31)
+    blob = oracle.synth_blob(4, 4.0)
+    c = pkg.EthCnn(device=0)
+    c.load_blob(blob)
+    try:
+        w, h = 1920, 1080
+        small = _luma(rng, 1, h, w, w)
+        big = _luma(rng, 24, h, w, w)
+        n1 = pkg.ethcnn.ctus_per_frame(w, h)
+        want_small = oracle.predict_frames(blob, small, w, h, 1, 30, 0.5, 0.5, mode=0)
+        want_big = oracle.predict_frames(blob, big, w, h, 24, 30, 0.5, 0.5, mode=0)
+        want_vec = oracle.resi_vectors(blob, small[0], w, h, mode=0)
+        d_s, d_b = c.alloc(small.nbytes), c.alloc(big.nbytes)
+        o_s, o_b, o_v = c.alloc(want_small.nbytes), c.alloc(want_big.nbytes), c.alloc(want_vec.nbytes)
+        d_s.upload(small)
+        d_b.upload(big)
+        poison_b = np.full(want_big.size, 7.0, np.float32)
+        poison_v = np.full(want_vec.size, 7.0, np.float32)
+        for rep in range(6):
+            o_b.upload(poison_b)
+            o_v.upload(poison_v)
+            c.predict_luma_device(d_s, w, h, 1, 30, o_s)            # carries the completion word ...
+            if rep % 2 == 0:
+                c.predict_luma_device(d_b, w, h, 24, 30, o_b)       # ... but 12,240 CTUs of five-launch passes follow
+            else:
+                c.resi_vectors_device(d_s, w, h, o_v)               # ... but an LDP front-end (no word) follows
+            c.synchronize()
+            if rep % 2 == 0:
+                got = o_b.download(np.float32, want_big.size).reshape(want_big.shape)
+                assert np.array_equal(_bits(got), _bits(want_big)), rep
+            else:
+                got = o_v.download(np.float32, want_vec.size).reshape(want_vec.shape)
+                assert np.array_equal(_bits(got), _bits(want_vec)), rep
+            got = o_s.download(np.float32, want_small.size).reshape(want_small.shape)
+            assert np.array_equal(_bits(got), _bits(want_small)), rep
+            # and the plain case: the pass alone, many times (the word's sequence number moves on every launch)
+            for _ in range(20):
+                c.predict_luma_device(d_s, w, h, 1, 30, o_s)
+                c.synchronize()
+            got = o_s.download(np.float32, want_small.size).reshape(want_small.shape)
+            assert np.array_equal(_bits(got), _bits(want_small)), rep
+        for b in (d_s, d_b, o_s, o_b, o_v):
+            b.free()
+    finally:
+        c.close()
