@@ -10,6 +10,7 @@ for wl in c2 c3; do
 done
 [ -s gpurun_out/latency.txt ] && cp gpurun_out/latency.txt profiles/${R}_latency.txt
 [ -s gpurun_out/latency_ldp.txt ] && cp gpurun_out/latency_ldp.txt profiles/${R}_latency_ldp.txt
+[ -s gpurun_out/latency_host.txt ] && cp gpurun_out/latency_host.txt profiles/${R}_latency_host.txt
 [ -s gpurun_out/latency_five_launches.txt ] && cp gpurun_out/latency_five_launches.txt profiles/${R}_latency_five_launches.txt
 [ -s gpurun_out/small_pass_timeline.txt ] && cp gpurun_out/small_pass_timeline.txt profiles/${R}_small_pass_timeline.txt
 [ -s gpurun_out/launch_plans.txt ] && cp gpurun_out/launch_plans.txt profiles/${R}_launch_plans.txt

@@ -33,9 +33,15 @@ for rep in 1 2; do for plan in "0:" "1:ETHCNN_FUSED=1" "2:ETHCNN_GATE_FOLD=1"; d
 done; done
 python scripts/summarize.py "gpurun_out/plan*.json" | tee gpurun_out/launch_plans.txt
 python scripts/latency_ldp.py --cpu > gpurun_out/latency_ldp.txt 2>&1; cat gpurun_out/latency_ldp.txt
+python scripts/latency_host.py > gpurun_out/latency_host.txt 2>&1; cat gpurun_out/latency_host.txt
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_$WL -o $WL -- python $REPO/bench.py --workload $WL --no-cpu-baseline --no-host-scopes > $REPO/gpurun_out/prof_$WL.log 2>&1
-for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+cd $REPO
+# HBM traffic of FC1 (and, for the default workload, the MFMA-busy pass): c3, then the FETCH / WRITE passes of c2 as well, so that
+# profiles/fc1_traffic.json carries a current stamp for both
+pmc_passes() {
+cd /tmp
+for pmc in "${PMCS[@]}"; do
   tag=$(echo $pmc | tr ' ' '_' | cut -c1-30)
   rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d $REPO/gpurun_out/pmc_${WL}_$tag -o p -- python $REPO/bench.py --workload $WL --no-cpu-baseline --no-host-scopes --steps 5 --warmup 1 > $REPO/gpurun_out/pmc_${WL}_$tag.log 2>&1
 done
@@ -65,6 +71,9 @@ if fe is not None and wr is not None:
                 "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of `python bench.py --workload %s --no-cpu-baseline --no-host-scopes --steps 5 --warmup 1` (scripts/gpu_round.sh), summed over the FC1 dispatches of a step; FETCH_SIZE x2 (gfx950 correction)" % wl}}
     json.dump(out, open("gpurun_out/fc1_traffic_%s.json" % wl,"w"), indent=1); print("fc1 traffic:", out)
 PY
+}
+PMCS=("FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"); pmc_passes
+if [ "$WL" = c3 ]; then WL=c2; PMCS=("FETCH_SIZE" "WRITE_SIZE"); pmc_passes; WL=c3; fi
 head -12 gpurun_out/prof_$WL/${WL}_kernel_stats.csv
 python - <<'PY'
 import csv, glob, collections
