@@ -44,7 +44,7 @@ int main(int argc, char** argv) {
     float best = 1e9;
     for (int it = 0; it < 20; ++it) {
         hipEventRecord(e0, 0);
-        launch_small_pass(luma, g, 0, n, resi, ws, dw, ws.h1, 0.6f, 0.5f, 0.5f, probs, 1, sync, 0);
+        launch_small_pass(luma, g, 0, n, resi, ws, dw, ws.h1, 0.6f, 0.5f, 0.5f, probs, 1, sync, it + 1, nullptr, 0u, 0);  // (epoch = it + 1: a fresh claim tag per launch)
         hipEventRecord(e1, 0);
         CK(hipEventSynchronize(e1));
         float ms;
