@@ -473,6 +473,7 @@ static int upload_weights(ethcnn_ctx* c) {
     sizes.push_back((size_t)kNFeat * kNVec);  // [16] fc1 image BN 64
     sizes.push_back((size_t)kNFeat * kNVec);  // [17] fc1 image BN 32
     sizes.push_back((size_t)kNFeat * kNVec);  // [18] fc1 image BN 16
+    sizes.push_back((size_t)kNFeat * kNVec);  // [19] fc1 in MFMA-operand (lane) order
     std::vector<size_t> offs;
     size_t total = 0;
     for (size_t s : sizes) { offs.push_back(total); total += (s + 63) / 64 * 64; }
@@ -486,6 +487,7 @@ static int upload_weights(ethcnn_ctx* c) {
         pack_fc1_image(wcat.data(), 64, 32, host.data() + offs[16]);
         pack_fc1_image(wcat.data(), 32, 32, host.data() + offs[17]);
         pack_fc1_image(wcat.data(), 16, 32, host.data() + offs[18]);
+        pack_fc1_lane_image(wcat.data(), host.data() + offs[19]);
     }
     for (int h = 0; h < 3; ++h) {
         std::memcpy(host.data() + offs[4 + 2 * h], blob + kOffFc2W[h], sizes[4 + 2 * h] * 4);
@@ -503,6 +505,7 @@ static int upload_weights(ethcnn_ctx* c) {
     d.fc1_img64 = c->dw_arena + offs[16];
     d.fc1_img32 = c->dw_arena + offs[17];
     d.fc1_img16 = c->dw_arena + offs[18];
+    d.fc1_lane16 = c->dw_arena + offs[19];
     d.fc1_b = c->dw_arena + offs[3];
     for (int h = 0; h < 3; ++h) {
         d.fc2_w[h] = c->dw_arena + offs[4 + 2 * h];

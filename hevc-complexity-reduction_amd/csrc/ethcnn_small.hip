@@ -39,7 +39,8 @@ struct SmallParams {
     float* feat;
     int n, ngroups, ntiles, nchunks;
     int bS, bM, bL;               // trunk blocks per branch (S / M: 4 waves = 4 tasks; L: one task per block)
-    const float* wimg;
+    const float* wimg;            // FC1 weights as the LDS image of the launch's tile shape ...
+    const float* wlane;           // ... and in MFMA-operand order per 16-column tile (fc1_tile_regs)
     const float* fc1_b;
     float* h1;                    // FC1 output: the pass's h1 (AI) or the caller's 448-vectors (LDP front-end)
     unsigned fc1_blocks, heads_blocks;
@@ -200,6 +201,87 @@ __device__ __forceinline__ bool block_wait(int* flag, const SmallParams& P, Smal
 
 // ---- an FC1 work item: column block nb of 64-CTU tile mt.  Claims it, waits for the tile's features (executing the tile's
 // unclaimed trunk items itself when that takes too long), computes, signals the tile; the tile's finisher wakes its heads.
+// ---- FC1 tile of the single-launch pass, REGISTER-FED: 64 CTUs x 16 NS columns, one wave per 16 CTUs, NS accumulators per wave
+// = NS dependent chains of 672 MFMAs (the canonical order: sub-chunk u ascending, inside it e = 0..3 -- exactly fc1_tile_at's).
+// One picture's FC1 blocks are alone on their SIMDs, so their time is the chain's: 45 cycles per link (scripts/ubench/
+// chain_probe.hip), 12.9 us for 672 links -- IF nothing else is exposed.  The LDS-staged tile (fc1_tile_at, built for
+// throughput) adds a barrier + an LDS round trip per K chunk and cannot look further ahead than its ring (17 us measured,
+// whatever the ring depth).  Here both operands of a sub-chunk are ONE dwordx4 load per lane each, straight from memory
+// into a ring of D register slots (features: the trunk's [k/4][16][4] group image, agent-scope; weights: the same order per
+// 16-column tile, DeviceWeights::fc1_lane16, shared by the block's four waves through the CU's vector cache): no LDS, no
+// barrier, no address arithmetic, look-ahead D sub-chunks = D x 4 NS MFMAs.
+template <int NS, int D>
+__device__ __forceinline__ void fc1_tile_regs(const float* __restrict__ feat, const float* __restrict__ wlane, const float* __restrict__ bias,
+                                              float* __restrict__ out, int M, const int mt, const int nb) {
+    constexpr int NU = kNFeat / 16;  // 168 sub-chunks
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int col = lane & 15, g = lane >> 4;
+    const int m0 = mt * 64 + wv * 16, n0 = nb * 16 * NS;
+    const int grp = min(m0 >> 4, ((M + 15) >> 4) - 1);  // (a ragged tile's idle waves recompute the last group; never stored)
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(feat) + (size_t)grp * (kNFeat / 4) * 64, 0, kNFeat * 16 * 4, 0x00020000);
+    __amdgpu_buffer_rsrc_t rB[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j)
+        rB[j] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wlane) + (size_t)(nb * NS + j) * NU * 256, 0, NU * 1024, 0x00020000);
+    const int voff = lane * 16;
+    float bv[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) bv[j] = bias[n0 + j * 16 + col];
+    f32x4 ra[D], rb[D][NS];
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+        ra[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, voff, u * 1024, kAuxSc1));
+#pragma unroll
+        for (int j = 0; j < NS; ++j) rb[u][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rB[j], voff, u * 1024, 0));
+    }
+    f32x4 acc[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int slot = u % D;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int j = 0; j < NS; ++j) acc[j] = MFMA16(ra[slot][e], rb[slot][j][e], acc[j]);
+        if (u + D < NU) {
+            ra[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, voff, (u + D) * 1024, kAuxSc1));
+#pragma unroll
+            for (int j = 0; j < NS; ++j)
+                rb[slot][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rB[j], voff, (u + D) * 1024, 0));
+        }
+        // the order above IS the schedule: left alone, the machine scheduler sinks every load to just before its use (fewest
+        // live registers) and the look-ahead is gone
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // epilogue as fc1_tile_at's: bias + leaky-ReLU, agent-scope stores, rows beyond M dropped by the range check
+    const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc(out, 0, M * kNVec * 4, 0x00020000);
+    const int lane_out = ((m0 + 4 * g) * kNVec + col) * 4;
+#pragma unroll
+    for (int j = 0; j < NS; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float h = acc[j][r] + bv[j];
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(0.2f * h, h)), rO, lane_out + r * kNVec * 4, (n0 + j * 16) * 4, kAuxSc1);
+        }
+}
+#ifndef SMALL_D2
+#define SMALL_D2 10  // ring depth (sub-chunks) of the 32-column shape
+#endif
+#ifndef SMALL_D4
+#define SMALL_D4 6   // ... of the 64-column shape
+#endif
+#ifndef SMALL_FC1_REGS
+#define SMALL_FC1_REGS 1  // 0: the LDS-staged tile everywhere (A/B builds)
+#endif
+// Which tile a launch uses (measured, profiles/r03_fc1_regs.txt): register-fed for the 16-column shape (<= 576 CTUs: 1080p
+// 51.7 -> 46.5 us, 768x512 49.7 -> 43.6) and for the LDP front-end at every size (2160p 85.7 -> 80.0); a 2160p All-Intra
+// picture (1600 blocks on 512 slots, the heads blocks among them) keeps the LDS-staged 32-column tile (101 vs 106 us).
+template <int NS, bool RESI>
+__device__ __host__ constexpr bool fc1_regs() { return SMALL_FC1_REGS != 0 && (NS == 1 || RESI); }
+
 template <int NS, int NSUB, bool RESI>
 __device__ __forceinline__ void do_fc1_item(const SmallParams& P, const SmallSync& Y, int fb, float* smem, SmallShared* sh) {
     constexpr int NSPLIT = kNVec / (16 * NS);
@@ -229,7 +311,8 @@ __device__ __forceinline__ void do_fc1_item(const SmallParams& P, const SmallSyn
         (void)block_wait(Y.fc1_flag + fb * kPad, P, sh, 0);  // every item of the tile is claimed by a resident block now
     }
     SMALL_STAMP(1);
-    fc1_tile_at<1, NS, 4, NSUB, 3, true, true>(smem, P.feat, P.wimg, P.fc1_b, P.h1, P.n, mt, nb);
+    if (fc1_regs<NS, RESI>()) fc1_tile_regs<NS, (NS == 1 ? 16 : (NS == 2 ? SMALL_D2 : SMALL_D4))>(P.feat, P.wlane, P.fc1_b, P.h1, P.n, mt, nb);
+    else fc1_tile_at<1, NS, 4, NSUB, 3, true, true>(smem, P.feat, P.wimg, P.fc1_b, P.h1, P.n, mt, nb);
     SMALL_STAMP(2);
     if (!RESI) {  // (LDP front-end: the vectors are the launch's output, nothing waits for them inside it)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -246,7 +329,7 @@ __device__ __forceinline__ void do_fc1_item(const SmallParams& P, const SmallSyn
 template <int NS, int NSUB, bool RESI>
 __global__ __launch_bounds__(256, 2) void k_small_pass(SmallParams P) {  // <= 256 registers: two blocks per CU
     constexpr int NSPLIT = kNVec / (16 * NS);
-    constexpr int LDS_FLOATS = MaxOf<MaxOf<Fc1Shape<1, NS, 4, NSUB, 3>::LDS_FLOATS, kTrunkWFrags * 64 + 8 * 64 * 4>::value, kHeadsLatStages * kHeadsStage + 12 * 256>::value;
+    constexpr int LDS_FLOATS = MaxOf<MaxOf<(fc1_regs<NS, RESI>() ? 0 : Fc1Shape<1, NS, 4, NSUB, 3>::LDS_FLOATS), kTrunkWFrags * 64 + 8 * 64 * 4>::value, kHeadsLatStages * kHeadsStage + 12 * 256>::value;
     __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
     __shared__ SmallShared sh;
     const int bid = (int)blockIdx.x;
@@ -361,6 +444,7 @@ void launch_small_pass(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int
     if (force >= 0 && force <= 2) shape = force;
     const int nsplit = shape == 0 ? 28 : (shape == 1 ? 14 : 7);
     P.wimg = shape == 0 ? w.fc1_img16 : (shape == 1 ? w.fc1_img32 : w.fc1_img64);
+    P.wlane = w.fc1_lane16;
     P.fc1_b = w.fc1_b;
     P.h1 = fc1_out;
     P.fc1_blocks = (unsigned)(P.ntiles * nsplit);

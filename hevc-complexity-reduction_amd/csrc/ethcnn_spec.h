@@ -97,6 +97,9 @@ struct DeviceWeights {
     float* fc1_img64 = nullptr;   // BN 64,  BK 32
     float* fc1_img32 = nullptr;   // BN 32 and BN 16: low-latency shapes for short row ranges (the image
     float* fc1_img16 = nullptr;   // depends on BN only: chunk rows are consecutive)
+    // the same weights in MFMA-operand order per 16-column tile: [28 tiles][168 sub-chunks of 16 k][64 lanes][4]: lane (col, g)
+    // holds W1[16 u + 4 g + e][16 t + col], e = 0..3 -- one dwordx4 load per lane per sub-chunk, no LDS (single-launch pass)
+    float* fc1_lane16 = nullptr;
     float* fc1_b = nullptr;    // [448]
     float* fc2_w[3] = {nullptr, nullptr, nullptr};  // [n1+1][n2] (last row = qp row)
     float* fc2_b[3] = {nullptr, nullptr, nullptr};
@@ -108,6 +111,7 @@ struct DeviceWeights {
 void pack_trunk_fragments(const float* blob, float* w_out /*[3][84][64]*/, float* b_out /*[3][20][64]*/);
 void pack_fc1(const float* blob, float* w_out /*[2688][448]*/, float* b_out /*[448]*/);
 void pack_fc1_image(const float* w_cat /*[2688][448]*/, int bn, int bk, float* img_out /*[2688*448]*/);
+void pack_fc1_lane_image(const float* w_cat /*[2688][448]*/, float* img_out /*[2688*448]*/);
 void synth_blob(uint64_t seed, double head_gain, float* blob_out /*[kBlobFloats]*/);
 void synth_lstm_blob(uint64_t seed, double head_gain, float* blob_out /*[kLstmBlobFloats]*/);
 void pack_lstm_kernels(const float* blob, float* out /*[kLstmPackFloats]*/);

@@ -202,6 +202,18 @@ void pack_fc1_image(const float* w_cat, int bn, int bk, float* img) {
             }
 }
 
+// W1 in MFMA B-operand order per 16-column tile (DeviceWeights::fc1_lane16): what lane (col, g) feeds the four MFMA steps of
+// sub-chunk u is one float4
+void pack_fc1_lane_image(const float* w_cat, float* img) {
+    for (int t = 0; t < kNVec / 16; ++t)
+        for (int u = 0; u < kNFeat / 16; ++u)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 4; ++e) {
+                    const int col = lane & 15, g = lane >> 4;
+                    *img++ = w_cat[(size_t)(16 * u + 4 * g + e) * kNVec + 16 * t + col];
+                }
+}
+
 void pack_lstm_kernels(const float* blob, float* out) {
     for (int lv = 0; lv < 3; ++lv) {
         const int N = 64 << lv, NC = 2 * N / 16;
