@@ -474,6 +474,7 @@ static int upload_weights(ethcnn_ctx* c) {
     sizes.push_back((size_t)kNFeat * kNVec);  // [17] fc1 image BN 32
     sizes.push_back((size_t)kNFeat * kNVec);  // [18] fc1 image BN 16
     sizes.push_back((size_t)kNFeat * kNVec);  // [19] fc1 in MFMA-operand (lane) order
+    for (int h = 0; h < 3; ++h) sizes.push_back((size_t)kN1[h] * kN2[h]);  // [20..22] fc2 in MFMA-operand order
     std::vector<size_t> offs;
     size_t total = 0;
     for (size_t s : sizes) { offs.push_back(total); total += (s + 63) / 64 * 64; }
@@ -494,6 +495,7 @@ static int upload_weights(ethcnn_ctx* c) {
         std::memcpy(host.data() + offs[5 + 2 * h], blob + kOffFc2B[h], sizes[5 + 2 * h] * 4);
         std::memcpy(host.data() + offs[10 + 2 * h], blob + kOffFc3W[h], sizes[10 + 2 * h] * 4);
         std::memcpy(host.data() + offs[11 + 2 * h], blob + kOffFc3B[h], sizes[11 + 2 * h] * 4);
+        pack_fc2_lane_image(blob + kOffFc2W[h], kN1[h], kN2[h], host.data() + offs[20 + h]);
     }
     if (!c->dw_arena) HIPCHK(c, hipMalloc((void**)&c->dw_arena, total * 4));
     HIPCHK(c, hipDeviceSynchronize());  // no pass in flight (on any of the streams) may still read the old arena
@@ -506,6 +508,7 @@ static int upload_weights(ethcnn_ctx* c) {
     d.fc1_img32 = c->dw_arena + offs[17];
     d.fc1_img16 = c->dw_arena + offs[18];
     d.fc1_lane16 = c->dw_arena + offs[19];
+    for (int h = 0; h < 3; ++h) d.fc2_lane[h] = c->dw_arena + offs[20 + h];
     d.fc1_b = c->dw_arena + offs[3];
     for (int h = 0; h < 3; ++h) {
         d.fc2_w[h] = c->dw_arena + offs[4 + 2 * h];

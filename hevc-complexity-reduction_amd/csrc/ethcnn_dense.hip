@@ -25,6 +25,7 @@
 #include <cstdlib>
 
 #include "ethcnn_kernels.h"
+#include "ethcnn_fc1_regs.h"
 #include "ethcnn_fc1_tile.h"
 
 namespace ethcnn {
@@ -79,6 +80,24 @@ static void launch_fc1_p3(const float* feat, const float* wimg, const float* bia
     hipLaunchKernelGGL((k_fc1_p3<MS, NS, WM, NSUB, GROUP, NST>), dim3(blocks), dim3(64 * WM), 0, s, feat, wimg, bias, out, M);
 }
 
+// Short row ranges, register-fed (ethcnn_fc1_regs.h): 64 CTUs x 16 NS columns per block, no LDS, one wave per 16 CTUs with NS
+// dependent chains.  A block's time is its chain's -- 672 links x max(45 cycles, 32 x the chains sharing its SIMD) -- not a
+// per-chunk barrier + LDS round trip: few rows finish in one chain time (~13 us), many rows run at the matrix pipe's rate.
+template <int NS, int D>
+__global__ __launch_bounds__(256) void k_fc1_regs(const float* __restrict__ feat, const float* __restrict__ wlane,
+                                                  const float* __restrict__ bias, float* __restrict__ out, int M) {
+    int mt, nb;
+    fc1_block_to_tile<kNVec / (16 * NS), true>(blockIdx.x, mt, nb);
+    if (mt * 64 >= M) return;
+    fc1_tile_regs<NS, D, false>(feat, wlane, bias, out, M, mt, nb);
+}
+template <int NS, int D>
+static void launch_fc1_regs(const float* feat, const float* wlane, const float* bias, float* out, int M, hipStream_t s) {
+    constexpr int NSPLIT = kNVec / (16 * NS);
+    const int mtiles = (M + 63) / 64;
+    hipLaunchKernelGGL((k_fc1_regs<NS, D>), dim3(((mtiles + 7) / 8) * 8 * NSPLIT), dim3(256), 0, s, feat, wlane, bias, out, M);
+}
+
 static int fc1_variant() {
     static int v = -2;
     if (v == -2) {
@@ -98,6 +117,12 @@ static int fc1_short_variant(int n) {
     // a, b refitted in round 2 (gpurun_out/fc1_rows.txt after the SGPR-base addressing; r01: profiles/r01_fc1_rows.txt)
     static const Shape shapes[] = {{0, 128, 4, 15.0, 150.0}, {1, 64, 4, 30.0, 70.0},  {2, 64, 7, 9.0, 45.0},
                                    {3, 64, 14, 10.0, 22.5},  {4, 64, 28, 8.0, 14.4}, {5, 64, 14, 9.5, 22.6}};
+    // register-fed shapes (k_fc1_regs; round 3, profiles/r03_fc1_rows.txt): 256-510 rows 15.9 us (LDS-staged best: 21.9), 924 rows
+    // 26.6 (34.1), 1536 46.7 (48.2), 2040 48.5 (59.3), 3696 89.0 (98.2), 6000 138 (142); from 8000 rows the staged shapes win again
+    if (n <= 576) return 7;
+    if (n <= 1152) return 8;
+    if (n <= 1792) return 7;   // (672 blocks: one round at three blocks per CU, 40 us at 1536 rows against 46-47)
+    if (n <= 6400) return 9;
     int best = 2;
     double tbest = 1e30;
     for (const Shape& sh : shapes) {
@@ -135,6 +160,9 @@ static void launch_fc1_rows(int variant, const Workspace& ws, const DeviceWeight
         case 6:  // 32 CTUs (2 waves) x 32 columns, BK 64
             launch_fc1_p3<1, 2, 2, 4, true>(feat, w.fc1_img32, w.fc1_b, o, rows, s);
             break;
+        case 7: launch_fc1_regs<1, 16>(feat, w.fc1_lane16, w.fc1_b, o, rows, s); break;  // register-fed, 64 x 16
+        case 8: launch_fc1_regs<2, 10>(feat, w.fc1_lane16, w.fc1_b, o, rows, s); break;  // register-fed, 64 x 32
+        case 9: launch_fc1_regs<4, 6>(feat, w.fc1_lane16, w.fc1_b, o, rows, s); break;   // register-fed, 64 x 64
         case 10: launch_fc1_p3<2, 7, 4, 1, false>(feat, w.fc1_img112, w.fc1_b, o, rows, s); break;
         case 11: launch_fc1_p3<1, 7, 4, 1, false>(feat, w.fc1_img112, w.fc1_b, o, rows, s); break;
         case 12: launch_fc1_p3<1, 4, 4, 2, false>(feat, w.fc1_img64, w.fc1_b, o, rows, s); break;

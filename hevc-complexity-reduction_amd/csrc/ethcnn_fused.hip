@@ -154,6 +154,7 @@ void launch_fc1_heads(const Workspace& ws, const DeviceWeights& w, int n, float 
     P.nchunks = nchunks;
     for (int h = 0; h < 3; ++h) {
         P.hp.w2[h] = w.fc2_w[h];
+        P.hp.w2lane[h] = w.fc2_lane[h];
         P.hp.b2[h] = w.fc2_b[h];
         P.hp.w3[h] = w.fc3_w[h];
         P.hp.b3[h] = w.fc3_b[h];

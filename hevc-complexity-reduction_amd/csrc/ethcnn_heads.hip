@@ -62,6 +62,7 @@ void launch_heads(const Workspace& ws, const DeviceWeights& w, int n, float qn, 
     HeadsParams hp;
     for (int h = 0; h < 3; ++h) {
         hp.w2[h] = w.fc2_w[h];
+        hp.w2lane[h] = w.fc2_lane[h];
         hp.b2[h] = w.fc2_b[h];
         hp.w3[h] = w.fc3_w[h];
         hp.b3[h] = w.fc3_b[h];

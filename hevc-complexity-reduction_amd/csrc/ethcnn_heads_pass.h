@@ -50,6 +50,7 @@ __device__ __forceinline__ void heads_stamp(int slot) {
 
 struct HeadsParams {
     const float* w2[3];
+    const float* w2lane[3];  // DeviceWeights::fc2_lane (single-launch pass only)
     const float* b2[3];
     const float* w3[3];
     const float* b3[3];
@@ -291,6 +292,135 @@ __device__ __forceinline__ void head_pass(float* smem, const float* __restrict__
 
 
 // ---- latency form for ONE group of 16 CTUs (the single-launch small pass, ethcnn_small.hip): the block's waves SPLIT the FC2
+// output tiles of the head (head 16: 12 tiles -> 3 per wave; 32: 2, 2, 2, -; 64: 1, 1, 1, -) instead of each taking 16
+// CTUs with all tiles: a wave's K loop is a quarter as long (head 16: 192 MFMAs instead of 768 -- the 64-CTU form keeps one
+// SIMD busy for 10 us, and a picture's heads blocks have the GPU to themselves).
+// REGISTER-FED like the pass's FC1 tile: a wave's W2 operands are its OWN (its tiles' columns), so they need neither LDS nor
+// barriers -- one dwordx4 load per lane per (tile, 16-k chunk) from the MFMA-operand-ordered copy of W2 (HeadsParams::w2lane).
+// Heads 64 and 32 request everything -- all h1 quads (agent-scope), all W2 pieces, epilogue operands -- in ONE round trip; head
+// 16 (48 pieces per wave) runs its pieces through a ring of D chunks.  The first form (W2 chunks through a 3-stage LDS ring
+// shared by the block, barrier per chunk) paid half a DMA round trip per chunk: 16 x ~0.5 us for head 16, the launch's
+// critical path.  h2 crosses waves through LDS in [tile][lane] order (the writer's C-layout quad of lane (ctu, g) is the
+// reader's B-operand quad, as in k_lstm_heads); wave 0 runs FC3 + sigmoid + gate predicates, its W3 operands requested while the
+// ring drains.  Same chains per accumulator: same results.  smem: NT * 256 floats (the h2 exchange).
+template <int H>
+__device__ __forceinline__ void head_pass_regs(float* smem, const float* __restrict__ H1, const HeadsParams& hp, float qn, int lane,
+                                               unsigned wvu, bool valid, int ctu, float* __restrict__ h2row,
+                                               float* __restrict__ logits, float* __restrict__ raw, float* __restrict__ probs,
+                                               int* flag32, int* flag16, float thr1, float thr2) {
+    using D = Hd<H>;
+    constexpr int TPW = (D::NT + 3) / 4;                     // tiles per wave
+    constexpr int RING = (D::NK <= 8) ? D::NK : 6;           // chunks of W2 pieces in registers (heads 64 / 32: all of them)
+    const int col = lane & 15, g = lane >> 4;
+    const float* W3 = hp.w3[H];
+    f32x4* const h2T = reinterpret_cast<f32x4*>(smem);
+    const int j0 = (int)wvu * TPW;  // this wave's tiles j0 .. j0 + TPW - 1 (those < NT; idle slots recompute the last tile, never stored)
+    const unsigned a_off = 4u * (unsigned)(ctu * kNVec + D::O1 + 4 * g);
+    const __amdgpu_buffer_rsrc_t rH1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(H1), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rWl = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hp.w2lane[H]), 0, D::N1 * D::N2 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rW2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hp.w2[H]), 0, (D::N1 + 1) * D::N2 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hp.b2[H]), 0, D::N2 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rW3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W3), 0, (D::N2 + 1) * D::N3 * 4, 0x00020000);
+    const int voff = lane * 16;
+    int tile_off[TPW];  // byte offset of tile (j0 + jj)'s pieces: [tile][chunk][64 lanes][4]
+#pragma unroll
+    for (int jj = 0; jj < TPW; ++jj) tile_off[jj] = __builtin_amdgcn_readfirstlane(min(j0 + jj, D::NT - 1) * D::NK * 1024);
+
+    // ---- one round trip: h1 quads, the first RING chunks of W2 pieces, the FC2 epilogue operands (qp row of W2, bias)
+    f32x4 hq[D::NK];
+#pragma unroll
+    for (int kc = 0; kc < D::NK; ++kc) hq[kc] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rH1, a_off, kc * 64, kAuxSc1));
+    f32x4 wr[RING][TPW];
+#pragma unroll
+    for (int kc = 0; kc < RING; ++kc)
+#pragma unroll
+        for (int jj = 0; jj < TPW; ++jj) wr[kc][jj] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rWl, voff, tile_off[jj] + kc * 1024, 0));
+    f32x4 wq[TPW], bv[TPW];
+#pragma unroll
+    for (int jj = 0; jj < TPW; ++jj) {
+        const int j = min(j0 + jj, D::NT - 1);
+        wq[jj] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW2, 16 * g, (D::N1 * D::N2 + 16 * j) * 4, 0));
+        bv[jj] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rB2, 16 * g, 64 * j, 0));
+    }
+    float w3q[D::NT][4], w3p[4], b3v[4];
+    f32x4 acc[TPW];
+#pragma unroll
+    for (int jj = 0; jj < TPW; ++jj) acc[jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kc = 0; kc < D::NK; ++kc) {
+        const int slot = kc % RING;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int jj = 0; jj < TPW; ++jj) acc[jj] = MFMA16(wr[slot][jj][e], hq[kc][e], acc[jj]);
+        if (kc + RING < D::NK) {
+#pragma unroll
+            for (int jj = 0; jj < TPW; ++jj)
+                wr[slot][jj] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rWl, voff, tile_off[jj] + (kc + RING) * 1024, 0));
+        }
+        // wave 0 runs FC3 at the end: ALL of its W3 operands are requested as soon as the ring stops refilling (registers free
+        // up from there on), so that they are there when the K loop ends; columns >= N3 read as 0
+        if (kc == D::NK - RING && wvu == 0) {
+            const int w3off = (4 * g * D::N3 + col) * 4;  // lane part of W3[(16 j + 4 g + r) * N3 + col]
+#pragma unroll
+            for (int j = 0; j < D::NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    w3q[j][r] = (col < D::N3) ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rW3, w3off, (16 * j + r) * D::N3 * 4, 0)) : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {  // FC3 epilogue: the qp row of W3 and the bias of output o = 4 g + r
+                const int o = min(4 * g + r, D::N3 - 1);
+                w3p[r] = W3[D::N2 * D::N3 + o];
+                b3v[r] = hp.b3[H][o];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // (the order above is the schedule: see fc1_tile_regs)
+    }
+    // FC2 epilogue of this wave's tiles, then hand them to wave 0
+#pragma unroll
+    for (int jj = 0; jj < TPW; ++jj) {
+        const int j = j0 + jj;
+        if (j < D::NT) {  // wave-uniform
+            f32x4 a = acc[jj];
+            a[0] = lrelu_h(fmaf(qn, wq[jj].x, a[0]) + bv[jj].x);
+            a[1] = lrelu_h(fmaf(qn, wq[jj].y, a[1]) + bv[jj].y);
+            a[2] = lrelu_h(fmaf(qn, wq[jj].z, a[2]) + bv[jj].z);
+            a[3] = lrelu_h(fmaf(qn, wq[jj].w, a[3]) + bv[jj].w);
+            if (valid && h2row) *reinterpret_cast<f32x4*>(h2row + D::O2 + 16 * j + 4 * g) = a;
+            h2T[j * 64 + lane] = a;
+        }
+    }
+    __syncthreads();
+    if (wvu != 0) return;
+    f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < D::NT; ++j) {
+        const f32x4 hv = h2T[j * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) z = MFMA16(w3q[j][r], hv[r], z);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int o = 4 * g + r;
+        if (o < D::N3 && valid) {
+            const float zz = fmaf(qn, w3p[r], z[r]) + b3v[r];
+            const float p = 1.0f / (1.0f + expf_canonical_h(-zz));
+            const size_t idx = (size_t)ctu * kNOut + D::O3 + o;
+            if (logits) logits[idx] = zz;
+            if (raw) raw[idx] = p;
+            __hip_atomic_store(&probs[idx], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (H == 0 && p > thr1 && __hip_atomic_load(flag32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+                __hip_atomic_store(flag32, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (H == 1 && p > thr2 && __hip_atomic_load(flag16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+                __hip_atomic_store(flag16, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+
+// ---- the same split with the W2 chunks through a 3-stage LDS ring shared by the block (the first form; kept for pictures of more
+// than 576 CTUs, where 1600 blocks share 512 slots and it measures 7 us faster at 2160p than the register-fed form above): the block's waves SPLIT the FC2
 // output tiles of the head (head 16: 12 tiles -> 3 per wave; 32: 2, 2, 2, -; 64: 1, 1, 1, -) instead of each taking 16
 // CTUs with all tiles: a wave's K loop is a quarter as long (head 16: 192 MFMAs instead of 768 -- the 64-CTU form keeps one
 // SIMD busy for 10 us, and a picture's heads blocks have the GPU to themselves).  Every wave requests all h1 quads of the

@@ -10,7 +10,7 @@
 //   blocks [0, nT)          trunk: one wave = one unit position of 16 CTUs, pixels gathered STRAIGHT from the luma frame
 //                           (Trunk<.., DIRECT>: the CTU-load stage folded into its consumer; no record buffers, no tile launch)
 //   blocks [nT, +nF)        FC1 64 x (16 NS) tiles; a block starts when the 4 x 21 trunk tasks of its 64 CTUs have landed
-//   blocks [.., +3 groups)  one head of a group of 16 CTUs (its waves split the head's FC2 tiles: head_pass_split); starts when
+//   blocks [.., +3 groups)  one head of a group of 16 CTUs (its waves split the head's FC2 tiles: head_pass_regs); starts when
 //                           the NSPLIT FC1 column blocks of its 64-CTU tile have landed; applies the gates per sub-batch
 //
 // Every consumer block has a higher block id than its producers and workgroups are dispatched in id order, so a waiting block
@@ -25,6 +25,7 @@
 
 #include <cstdlib>
 
+#include "ethcnn_fc1_regs.h"
 #include "ethcnn_fc1_tile.h"
 #include "ethcnn_heads_pass.h"
 #include "ethcnn_kernels.h"
@@ -201,72 +202,6 @@ __device__ __forceinline__ bool block_wait(int* flag, const SmallParams& P, Smal
 
 // ---- an FC1 work item: column block nb of 64-CTU tile mt.  Claims it, waits for the tile's features (executing the tile's
 // unclaimed trunk items itself when that takes too long), computes, signals the tile; the tile's finisher wakes its heads.
-// ---- FC1 tile of the single-launch pass, REGISTER-FED: 64 CTUs x 16 NS columns, one wave per 16 CTUs, NS accumulators per wave
-// = NS dependent chains of 672 MFMAs (the canonical order: sub-chunk u ascending, inside it e = 0..3 -- exactly fc1_tile_at's).
-// One picture's FC1 blocks are alone on their SIMDs, so their time is the chain's: 45 cycles per link (scripts/ubench/
-// chain_probe.hip), 12.9 us for 672 links -- IF nothing else is exposed.  The LDS-staged tile (fc1_tile_at, built for
-// throughput) adds a barrier + an LDS round trip per K chunk and cannot look further ahead than its ring (17 us measured,
-// whatever the ring depth).  Here both operands of a sub-chunk are ONE dwordx4 load per lane each, straight from memory
-// into a ring of D register slots (features: the trunk's [k/4][16][4] group image, agent-scope; weights: the same order per
-// 16-column tile, DeviceWeights::fc1_lane16, shared by the block's four waves through the CU's vector cache): no LDS, no
-// barrier, no address arithmetic, look-ahead D sub-chunks = D x 4 NS MFMAs.
-template <int NS, int D>
-__device__ __forceinline__ void fc1_tile_regs(const float* __restrict__ feat, const float* __restrict__ wlane, const float* __restrict__ bias,
-                                              float* __restrict__ out, int M, const int mt, const int nb) {
-    constexpr int NU = kNFeat / 16;  // 168 sub-chunks
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int col = lane & 15, g = lane >> 4;
-    const int m0 = mt * 64 + wv * 16, n0 = nb * 16 * NS;
-    const int grp = min(m0 >> 4, ((M + 15) >> 4) - 1);  // (a ragged tile's idle waves recompute the last group; never stored)
-    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(feat) + (size_t)grp * (kNFeat / 4) * 64, 0, kNFeat * 16 * 4, 0x00020000);
-    __amdgpu_buffer_rsrc_t rB[NS];
-#pragma unroll
-    for (int j = 0; j < NS; ++j)
-        rB[j] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wlane) + (size_t)(nb * NS + j) * NU * 256, 0, NU * 1024, 0x00020000);
-    const int voff = lane * 16;
-    float bv[NS];
-#pragma unroll
-    for (int j = 0; j < NS; ++j) bv[j] = bias[n0 + j * 16 + col];
-    f32x4 ra[D], rb[D][NS];
-#pragma unroll
-    for (int u = 0; u < D; ++u) {
-        ra[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, voff, u * 1024, kAuxSc1));
-#pragma unroll
-        for (int j = 0; j < NS; ++j) rb[u][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rB[j], voff, u * 1024, 0));
-    }
-    f32x4 acc[NS];
-#pragma unroll
-    for (int j = 0; j < NS; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-        const int slot = u % D;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int j = 0; j < NS; ++j) acc[j] = MFMA16(ra[slot][e], rb[slot][j][e], acc[j]);
-        if (u + D < NU) {
-            ra[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, voff, (u + D) * 1024, kAuxSc1));
-#pragma unroll
-            for (int j = 0; j < NS; ++j)
-                rb[slot][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rB[j], voff, (u + D) * 1024, 0));
-        }
-        // the order above IS the schedule: left alone, the machine scheduler sinks every load to just before its use (fewest
-        // live registers) and the look-ahead is gone
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    // epilogue as fc1_tile_at's: bias + leaky-ReLU, agent-scope stores, rows beyond M dropped by the range check
-    const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc(out, 0, M * kNVec * 4, 0x00020000);
-    const int lane_out = ((m0 + 4 * g) * kNVec + col) * 4;
-#pragma unroll
-    for (int j = 0; j < NS; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float h = acc[j][r] + bv[j];
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(0.2f * h, h)), rO, lane_out + r * kNVec * 4, (n0 + j * 16) * 4, kAuxSc1);
-        }
-}
 #ifndef SMALL_D2
 #define SMALL_D2 10  // ring depth (sub-chunks) of the 32-column shape
 #endif
@@ -311,7 +246,7 @@ __device__ __forceinline__ void do_fc1_item(const SmallParams& P, const SmallSyn
         (void)block_wait(Y.fc1_flag + fb * kPad, P, sh, 0);  // every item of the tile is claimed by a resident block now
     }
     SMALL_STAMP(1);
-    if (fc1_regs<NS, RESI>()) fc1_tile_regs<NS, (NS == 1 ? 16 : (NS == 2 ? SMALL_D2 : SMALL_D4))>(P.feat, P.wlane, P.fc1_b, P.h1, P.n, mt, nb);
+    if (fc1_regs<NS, RESI>()) fc1_tile_regs<NS, (NS == 1 ? 16 : (NS == 2 ? SMALL_D2 : SMALL_D4)), true>(P.feat, P.wlane, P.fc1_b, P.h1, P.n, mt, nb);
     else fc1_tile_at<1, NS, 4, NSUB, 3, true, true>(smem, P.feat, P.wimg, P.fc1_b, P.h1, P.n, mt, nb);
     SMALL_STAMP(2);
     if (!RESI) {  // (LDP front-end: the vectors are the launch's output, nothing waits for them inside it)
@@ -329,7 +264,7 @@ __device__ __forceinline__ void do_fc1_item(const SmallParams& P, const SmallSyn
 template <int NS, int NSUB, bool RESI>
 __global__ __launch_bounds__(256, 2) void k_small_pass(SmallParams P) {  // <= 256 registers: two blocks per CU
     constexpr int NSPLIT = kNVec / (16 * NS);
-    constexpr int LDS_FLOATS = MaxOf<MaxOf<(fc1_regs<NS, RESI>() ? 0 : Fc1Shape<1, NS, 4, NSUB, 3>::LDS_FLOATS), kTrunkWFrags * 64 + 8 * 64 * 4>::value, kHeadsLatStages * kHeadsStage + 12 * 256>::value;
+    constexpr int LDS_FLOATS = MaxOf<MaxOf<(fc1_regs<NS, RESI>() ? 0 : Fc1Shape<1, NS, 4, NSUB, 3>::LDS_FLOATS), kTrunkWFrags * 64 + 8 * 64 * 4>::value, (RESI ? 0 : (NS == 1 ? 12 * 256 : kHeadsLatStages * kHeadsStage + 12 * 256))>::value;
     __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
     __shared__ SmallShared sh;
     const int bid = (int)blockIdx.x;
@@ -352,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void k_small_pass(SmallParams P) {  // <= 2
         return;
     }
     if (RESI) return;  // (no heads blocks are launched for the LDP front-end)
-    // ---- one head of one group of 16 CTUs (the block's waves split the head's FC2 tiles: head_pass_split)
+    // ---- one head of one group of 16 CTUs (the block's waves split the head's FC2 tiles: head_pass_regs)
     const int hb = bid - nT - (int)P.fc1_blocks;
     const int grp = hb / 3, head_ = hb % 3;
     if (!block_wait(Y.heads_flag + hb * kPad, P, &sh, P.steal_test ? 1 : kPatience)) {
@@ -372,9 +307,15 @@ __global__ __launch_bounds__(256, 2) void k_small_pass(SmallParams P) {  // <= 2
     float* h2row = P.h2 ? P.h2 + (size_t)ctu * kNFc2 : nullptr;
     int* fl = Y.pred;
     if (head_ != 0) fl += 2 * gate_chunk(P.gi, ctu);
-    if (head_ == 0) head_pass_split<2>(smem, P.h1, P.hp, P.qn, lane, wvu, valid, ctu, h2row, P.logits, P.raw, P.probs, fl, fl + 1, P.thr1, P.thr2);
-    else if (head_ == 1) head_pass_split<1>(smem, P.h1, P.hp, P.qn, lane, wvu, valid, ctu, h2row, P.logits, P.raw, P.probs, fl, fl + 1, P.thr1, P.thr2);
-    else head_pass_split<0>(smem, P.h1, P.hp, P.qn, lane, wvu, valid, ctu, h2row, P.logits, P.raw, P.probs, fl, fl + 1, P.thr1, P.thr2);
+    if (NS == 1) {  // up to 576 CTUs: register-fed heads (1080p 45.7 -> 43.6 us); bigger pictures: the LDS-ring form (2160p 103 vs 110 us)
+        if (head_ == 0) head_pass_regs<2>(smem, P.h1, P.hp, P.qn, lane, wvu, valid, ctu, h2row, P.logits, P.raw, P.probs, fl, fl + 1, P.thr1, P.thr2);
+        else if (head_ == 1) head_pass_regs<1>(smem, P.h1, P.hp, P.qn, lane, wvu, valid, ctu, h2row, P.logits, P.raw, P.probs, fl, fl + 1, P.thr1, P.thr2);
+        else head_pass_regs<0>(smem, P.h1, P.hp, P.qn, lane, wvu, valid, ctu, h2row, P.logits, P.raw, P.probs, fl, fl + 1, P.thr1, P.thr2);
+    } else {
+        if (head_ == 0) head_pass_split<2>(smem, P.h1, P.hp, P.qn, lane, wvu, valid, ctu, h2row, P.logits, P.raw, P.probs, fl, fl + 1, P.thr1, P.thr2);
+        else if (head_ == 1) head_pass_split<1>(smem, P.h1, P.hp, P.qn, lane, wvu, valid, ctu, h2row, P.logits, P.raw, P.probs, fl, fl + 1, P.thr1, P.thr2);
+        else head_pass_split<0>(smem, P.h1, P.hp, P.qn, lane, wvu, valid, ctu, h2row, P.logits, P.raw, P.probs, fl, fl + 1, P.thr1, P.thr2);
+    }
     // gates per sub-batch, applied by the block that completes it, which also hands its words back as zeros
     SMALL_STAMP(2);
     heads_gates_arrive<true, 16>(Y.pred, Y.arrive, P.gi, N, grp * 16, P.thr2, P.probs, &sh.ga);
@@ -452,6 +393,7 @@ void launch_small_pass(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int
     P.sync = d_sync;
     for (int h = 0; h < 3; ++h) {
         P.hp.w2[h] = w.fc2_w[h];
+        P.hp.w2lane[h] = w.fc2_lane[h];
         P.hp.b2[h] = w.fc2_b[h];
         P.hp.w3[h] = w.fc3_w[h];
         P.hp.b3[h] = w.fc3_b[h];

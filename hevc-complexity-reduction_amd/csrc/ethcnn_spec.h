@@ -103,6 +103,9 @@ struct DeviceWeights {
     float* fc1_b = nullptr;    // [448]
     float* fc2_w[3] = {nullptr, nullptr, nullptr};  // [n1+1][n2] (last row = qp row)
     float* fc2_b[3] = {nullptr, nullptr, nullptr};
+    // rows 0 .. n1-1 of fc2_w in MFMA-operand order: [n2/16 tiles][n1/16 chunks][64 lanes][4]: lane (col, g) holds
+    // W2[16 kc + 4 g + e][16 j + col] (single-launch pass: one dwordx4 load per lane per tile and chunk, no LDS)
+    float* fc2_lane[3] = {nullptr, nullptr, nullptr};
     float* fc3_w[3] = {nullptr, nullptr, nullptr};  // [n2+1][n3]
     float* fc3_b[3] = {nullptr, nullptr, nullptr};
 };
@@ -112,6 +115,7 @@ void pack_trunk_fragments(const float* blob, float* w_out /*[3][84][64]*/, float
 void pack_fc1(const float* blob, float* w_out /*[2688][448]*/, float* b_out /*[448]*/);
 void pack_fc1_image(const float* w_cat /*[2688][448]*/, int bn, int bk, float* img_out /*[2688*448]*/);
 void pack_fc1_lane_image(const float* w_cat /*[2688][448]*/, float* img_out /*[2688*448]*/);
+void pack_fc2_lane_image(const float* w2 /*[n1+1][n2]*/, int n1, int n2, float* img_out /*[n1*n2]*/);
 void synth_blob(uint64_t seed, double head_gain, float* blob_out /*[kBlobFloats]*/);
 void synth_lstm_blob(uint64_t seed, double head_gain, float* blob_out /*[kLstmBlobFloats]*/);
 void pack_lstm_kernels(const float* blob, float* out /*[kLstmPackFloats]*/);

@@ -214,6 +214,16 @@ void pack_fc1_lane_image(const float* w_cat, float* img) {
                 }
 }
 
+void pack_fc2_lane_image(const float* w2, int n1, int n2, float* img) {
+    for (int j = 0; j < n2 / 16; ++j)
+        for (int kc = 0; kc < n1 / 16; ++kc)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 4; ++e) {
+                    const int col = lane & 15, g = lane >> 4;
+                    *img++ = w2[(size_t)(16 * kc + 4 * g + e) * n2 + 16 * j + col];
+                }
+}
+
 void pack_lstm_kernels(const float* blob, float* out) {
     for (int lv = 0; lv < 3; ++lv) {
         const int N = 64 << lv, NC = 2 * N / 16;

@@ -33,8 +33,8 @@ int main(int argc, char** argv) {
     CK(hipMemset(arena, 0x3c, (wfloats + 65536) * 4));  // small positive floats everywhere
     dw.trunk_w = dw.trunk_b = arena;
     dw.fc1_img112 = dw.fc1_img64 = dw.fc1_img32 = dw.fc1_img16 = arena;
-    dw.fc1_b = arena;
-    for (int h = 0; h < 3; ++h) dw.fc2_w[h] = dw.fc2_b[h] = dw.fc3_w[h] = dw.fc3_b[h] = arena;
+    dw.fc1_b = dw.fc1_lane16 = arena;
+    for (int h = 0; h < 3; ++h) dw.fc2_w[h] = dw.fc2_b[h] = dw.fc3_w[h] = dw.fc3_b[h] = dw.fc2_lane[h] = arena;
     const int words = small_pass_sync_words(n, 1);
     CK(hipMalloc(&sync, (size_t)words * 4));
     CK(hipMemset(sync, 0, (size_t)words * 4));
