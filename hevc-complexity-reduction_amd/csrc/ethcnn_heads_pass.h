@@ -88,12 +88,7 @@ constexpr int kHeadsStages = 2;  // prefetch distance 1: 24 KB of LDS, < 80 VGPR
 // every h1 read is an agent-scope load (sc1).  P_SC1 (gates applied inside the launch): the probabilities are agent-scope
 // stores -- the block that applies the gates at the end of the launch may run on another XCD and overwrites them.
 // Results are identical in every combination.
-// LAT (the single-launch small pass, ethcnn_small.hip): latency form of the K loop.  A picture's heads blocks are alone on
-// their CUs, so nothing hides a memory round trip per K chunk (16 chunks x ~2.5 us for agent-scope h1 loads that bypass the
-// L2): ALL h1 quads of the wave are requested up front into registers (one round trip), the W2 chunks run through a 3-stage
-// ring (prefetch distance 2) and the loop is fully unrolled.  Same chains: same results.
-constexpr int kHeadsLatStages = 3;
-template <int H, bool H1_SC1 = false, bool P_SC1 = false, bool LAT = false>
+template <int H, bool H1_SC1 = false, bool P_SC1 = false>
 __device__ __forceinline__ void head_pass(float* smem, const float* __restrict__ H1, const HeadsParams& hp, float qn,
                                           int lane, unsigned wvu, bool valid, int ctu, float* __restrict__ h2row,
                                           float* __restrict__ logits, float* __restrict__ raw, float* __restrict__ probs,
@@ -148,7 +143,7 @@ __device__ __forceinline__ void head_pass(float* smem, const float* __restrict__
         _Pragma("unroll") for (int i = 0; i < D::B_PER; ++i)                                             \
             HP_DMA(b_off[i], W2 + (size_t)(kc) * 16 * D::N2,                                             \
                    4u * ((st) * kHeadsStage + min(wvu + i * 4, (unsigned)(D::B_INST - 1)) * 256));       \
-        if (!D::H1REG && !LAT) {                                                                         \
+        if (!D::H1REG) {                                                                                 \
             if (H1_SC1) HP_DMA_SC1(a_off, H1 + (kc) * 16, 4u * ((st) * kHeadsStage + D::H1_AT + wvu * 256))  \
             else HP_DMA(a_off, H1 + (kc) * 16, 4u * ((st) * kHeadsStage + D::H1_AT + wvu * 256))         \
         }                                                                                                \
@@ -161,35 +156,6 @@ __device__ __forceinline__ void head_pass(float* smem, const float* __restrict__
 
     const __amdgpu_buffer_rsrc_t rH1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(H1), 0, -1, 0x00020000);
     constexpr int kH1Aux = H1_SC1 ? kAuxSc1 : 0;
-    if constexpr (LAT) {
-        f32x4 hq[D::NK];
-#pragma unroll
-        for (int kc = 0; kc < D::NK; ++kc) hq[kc] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rH1, a_off, kc * 64, kH1Aux));
-        __builtin_amdgcn_s_barrier();  // (block entry: nothing of a previous user of the LDS is still being read)
-        HP_ISSUE(0, 0);
-        if (D::NK > 1) { HP_ISSUE(1, 1); }
-        if (D::NK > 1) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D::B_PER) : "memory"); }  // all but the newest group: h1 + chunk 0
-        else { HP_WAIT(0); }
-        __builtin_amdgcn_s_barrier();
-#pragma unroll
-        for (int kc = 0; kc < D::NK; ++kc) {
-            const int st = kc % kHeadsLatStages;
-            if (kc + 2 < D::NK) { HP_ISSUE(kc + 2, (kc + 2) % kHeadsLatStages); }  // the stage every wave left at the last barrier
-            const float* bsE = smem + st * kHeadsStage + a_base[0];
-            const float* bsO = smem + st * kHeadsStage + a_base[1];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float hv = hq[kc][e];
-#pragma unroll
-                for (int j = 0; j < D::NT; ++j)
-                    acc[j] = MFMA16((((D::COLSWZ ? j : e) & 1) ? bsO : bsE)[e * D::N2 + 16 * j], hv, acc[j]);  // rows = W2 columns
-            }
-            if (kc + 2 < D::NK) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D::B_PER) : "memory"); }  // chunk kc + 1 has landed
-            else { HP_WAIT(0); }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
-    } else {
     f32x4 avr = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (D::H1REG) avr = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rH1, a_off, 0, kH1Aux));
     __builtin_amdgcn_s_barrier();  // the previous head's last stage has been consumed by every wave
@@ -226,7 +192,6 @@ __device__ __forceinline__ void head_pass(float* smem, const float* __restrict__
         st = st2;
         avr = avn;
     }
-    }  // !LAT
 #undef HP_DMA
 #undef HP_DMA_SC1
 #undef HP_ISSUE
@@ -428,6 +393,7 @@ __device__ __forceinline__ void head_pass_regs(float* smem, const float* __restr
 // through LDS in [tile][lane] order (the writer's C-layout quad of lane (ctu, g) is the reader's B-operand quad, as in
 // k_lstm_heads) and wave 0 runs FC3 + sigmoid + gate predicates.  Same chains per accumulator: same results.
 // smem: kHeadsLatStages * kHeadsStage floats of W2 stages + NT * 256 floats of h2.
+constexpr int kHeadsLatStages = 3;
 template <int H>
 __device__ __forceinline__ void head_pass_split(float* smem, const float* __restrict__ H1, const HeadsParams& hp, float qn, int lane,
                                                 unsigned wvu, bool valid, int ctu, float* __restrict__ h2row,
