@@ -11,3 +11,16 @@ python scripts/latency_ldp.py | tail -6
 python - <<'PY'
 import json; d=json.load(open("gpurun_out/bench_c5.json")); print(d["value"], d["ms_per_step"], d["stages_ms_per_step"])
 PY
+python - <<'PY'
+# gaps between the three kernels of a frame (kernel trace of the same run): end -> next start
+import csv, glob
+rows = []
+for f in glob.glob("gpurun_out/prof_c5/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"][:28]))
+rows.sort()
+rows = rows[len(rows) // 2: len(rows) // 2 + 9]
+for i, (s, e, n) in enumerate(rows):
+    gap = s - rows[i - 1][1] if i else 0
+    print("%-30s start +%7.1f us  dur %6.1f us  gap before %5.1f us" % (n, (s - rows[0][0]) / 1e3, (e - s) / 1e3, gap / 1e3))
+PY

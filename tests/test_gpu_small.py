@@ -1,5 +1,6 @@
 """GPU: the single-launch small pass (csrc/ethcnn_small.hip: CTU load + trunk -> FC1 -> heads -> gates as a dataflow inside one
-grid) against the oracle and against the five-launch path (ethcnn_set_small_pass_launch off): bit-identical probabilities,
+grid; register-fed FC1 / heads up to 576 CTUs, LDS-staged above) against the oracle and against the five-launch path
+(ethcnn_set_small_pass_launch off; its FC1 is one of the register-fed k_fc1_regs shapes at these sizes): bit-identical probabilities,
 features, FC1 outputs, LDP vectors and LDP recurrences over aligned geometries of every FC1 shape, zero-padded edges, pitched
 planes, several frames per pass, closed / mixed gates, and long call sequences (the launch's last block must leave its sync
 area zero for the next one)."""
@@ -22,7 +23,8 @@ def _luma(rng, frames, h, pitch, w):
 
 GEOMS = [  # (width, height, frames, pitch): every FC1 shape of the launch (<= 576, <= 2304, more rows), ragged right / bottom CTUs
     (768, 512, 1, 768), (1920, 1080, 1, 1920), (416, 240, 1, 416), (400, 136, 3, 448), (832, 480, 2, 832),
-    (3840, 2160, 1, 3840), (4928, 3264, 1, 4928), (1920, 1080, 3, 2048), (64, 64, 1, 64), (16, 16, 5, 16), (1280, 720, 8, 1280)]
+    (3840, 2160, 1, 3840), (4928, 3264, 1, 4928), (1920, 1080, 3, 2048), (64, 64, 1, 64), (16, 16, 5, 16), (1280, 720, 8, 1280),
+    (2560, 1440, 1, 2560)]  # (920 CTUs: the 64 x 32 register-fed FC1 kernel of the multi-launch path)
 
 
 @pytest.mark.parametrize("geom", GEOMS)
