@@ -111,6 +111,7 @@ __device__ __forceinline__ void lstm_cell(const LstmParams& lp, const float* __r
     float4 a[NC];
 #pragma unroll
     for (int kc = 0; kc < NC; ++kc) a[kc] = *reinterpret_cast<const float4*>(kpk + (size_t)kc * 256);
+
 #pragma unroll
     for (int i = 0; i < NC / 4; ++i) {
         const int kc = 4 * i + q;
@@ -123,6 +124,14 @@ __device__ __forceinline__ void lstm_cell(const LstmParams& lp, const float* __r
             xh[(c * NC + kc) * 64 + lane] = (f32x4){v.x, v.y, v.z, v.w};
         }
     }
+    // ... and what the cell update needs behind the chain (the unit's four biases, its previous cell state): requested here (behind the
+    // [x, h_prev] loads, which the staging barrier below waits for), not
+    // behind the gate exchange's barrier, where they were one more exposed round trip
+    const int u = 16 * t + 4 * g + q;
+    const float b_i = bk[u], b_j = bk[N + u], b_f = bk[2 * N + u], b_o = bk[3 * N + u];
+    float cprev[CG];
+#pragma unroll
+    for (int c = 0; c < CG; ++c) cprev[c] = state_in ? state_in[row[c] * 2 * kNVec + O1 + u] : 0.0f;
     __syncthreads();
     f32x4 acc[CG];
 #pragma unroll
@@ -144,13 +153,11 @@ __device__ __forceinline__ void lstm_cell(const LstmParams& lp, const float* __r
 #pragma unroll
     for (int c = 0; c < CG; ++c) xch[(c * 4 + q) * 64 + lane] = acc[c];
     __syncthreads();
-    const int u = 16 * t + 4 * g + q;
-    const float b_i = bk[u], b_j = bk[N + u], b_f = bk[2 * N + u], b_o = bk[3 * N + u];
 #pragma unroll
     for (int c = 0; c < CG; ++c) {
         const float* xf = reinterpret_cast<const float*>(xch + c * 256) + lane * 4 + q;
         const float gi = xf[0] + b_i, gj = xf[256] + b_j, gf = xf[512] + b_f, go = xf[768] + b_o;
-        const float cp = state_in ? state_in[row[c] * 2 * kNVec + O1 + u] : 0.0f;
+        const float cp = cprev[c];
         float cc = sigmoid_l(gf + 1.0f) * cp + sigmoid_l(gi) * tanh_l(gj);
         cc = fminf(fmaxf(cc, -5.0f), 5.0f);
         const float hn = sigmoid_l(go) * tanh_l(cc);
@@ -192,6 +199,7 @@ __device__ __forceinline__ void lstm_heads(const LstmParams& lp, const float* __
     // fc2^T: wave j owns output tile j; step (t, r) consumes k = 16 t + 4 g + r.  Latency form: ALL operands of the tile (64 W2
     // values and 16 h quads per lane at level 16) are requested before the first MFMA -- fetched a step ahead, the loop paid
     // one L2 round trip per step with the GPU otherwise idle (round 3: 1080p LSTM heads 17 -> see profiles/r03_latency_ldp.txt)
+    float w3v[NT2][4], w3e[4][5], b3v[4];  // wave 0: fc3 operands (requested behind its fc2 chain, used behind the exchange)
     if (wave < NT2) {
         const int j = wave;
         f32x4 a2 = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -205,11 +213,13 @@ __device__ __forceinline__ void lstm_heads(const LstmParams& lp, const float* __
 #pragma unroll
             for (int r = 0; r < 4; ++r) wv[t][r] = wcol[(size_t)(16 * t + r) * N2];
         }
-        float we[4][5];  // the efs rows + bias of this lane's four outputs
+        float we[4][5], b2v[4];  // the efs rows + bias of this lane's four outputs
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < 4; ++r) {
 #pragma unroll
             for (int e = 0; e < 5; ++e) we[r][e] = W2[(N + e) * N2 + 16 * j + 4 * g + r];
+            b2v[r] = b2[16 * j + 4 * g + r];
+        }
         asm volatile("" ::: "memory");  // every request above is issued before the first MFMA below waits for its operands
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -217,25 +227,35 @@ __device__ __forceinline__ void lstm_heads(const LstmParams& lp, const float* __
 #pragma unroll
             for (int r = 0; r < 4; ++r) a2 = MFMA16(wv[t][r], hv[r], a2);
         }
+        // wave 0 runs fc3^T behind the exchange: its operands (and the efs rows / bias of the fc3 epilogue) are requested HERE,
+        // where the registers of the fc2 operands have just become free, so that their round trip passes under the fc2
+        // epilogue and the wait for the other waves instead of standing behind the barrier
+        if (wave == 0) {
+#pragma unroll
+            for (int jj = 0; jj < NT2; ++jj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) w3v[jj][r] = (col < N3) ? W3[(16 * jj + 4 * g + r) * N3 + col] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = min(4 * g + r, N3 - 1);
+#pragma unroll
+                for (int e = 0; e < 5; ++e) w3e[r][e] = W3[(N2 + e) * N3 + o];
+                b3v[r] = b3[o];
+            }
+            asm volatile("" ::: "memory");
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int idx = 16 * j + 4 * g + r;
             float v = a2[r];
 #pragma unroll
             for (int e = 0; e < 5; ++e) v = fmaf(lp.efs[e], we[r][e], v);
-            a2[r] = lrelu_l(v + b2[idx]);
+            a2[r] = lrelu_l(v + b2v[r]);
         }
         h2T[(j * 4 + g) * 16 + col] = a2;
     }
     __syncthreads();
-    if (wave == 0) {  // fc3^T (operands requested up front, as above)
+    if (wave == 0) {  // fc3^T
         f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
-        float w3v[NT2][4];
-#pragma unroll
-        for (int j = 0; j < NT2; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) w3v[j][r] = (col < N3) ? W3[(16 * j + 4 * g + r) * N3 + col] : 0.0f;
-        asm volatile("" ::: "memory");
 #pragma unroll
         for (int j = 0; j < NT2; ++j) {
             const f32x4 hv = h2T[(j * 4 + g) * 16 + col];
@@ -248,8 +268,8 @@ __device__ __forceinline__ void lstm_heads(const LstmParams& lp, const float* __
             if (o < N3 && valid) {
                 float zz = z[r];
 #pragma unroll
-                for (int e = 0; e < 5; ++e) zz = fmaf(lp.efs[e], W3[(N2 + e) * N3 + o], zz);
-                const float p = sigmoid_l(zz + b3[o]);
+                for (int e = 0; e < 5; ++e) zz = fmaf(lp.efs[e], w3e[r][e], zz);
+                const float p = sigmoid_l(zz + b3v[r]);
                 const size_t idx = (size_t)ctu * kNOut + O3 + o;
                 if (raw) raw[idx] = p;
                 // agent-scope store (written through the XCD's L2): the block that applies the gates may run on another XCD
