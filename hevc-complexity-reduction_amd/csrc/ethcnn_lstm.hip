@@ -24,6 +24,19 @@ namespace ethcnn {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
+#ifdef LSTM_STAMPS
+// development probe (scripts/ubench/lstm_probe.hip): device-wide 100 MHz stamps per block: entry, operands staged, chain done, exit
+__device__ unsigned long long g_lstm_stamps[2][1 << 11][4];
+__device__ __forceinline__ void lstm_stamp(int kernel, int slot) {
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    if (threadIdx.x == 0) g_lstm_stamps[kernel][(blockIdx.y * gridDim.x + blockIdx.x) & 0x7ff][slot] = t;
+}
+#define LSTM_STAMP(k, i) lstm_stamp(k, i)
+#else
+#define LSTM_STAMP(k, i)
+#endif
+
 __device__ __forceinline__ float lrelu_l(float h) { return fmaxf(0.2f * h, h); }
 __device__ __forceinline__ float expf_l(float x) {  // the canonical exp of DESIGN.md
     x = fminf(x, 80.0f);
@@ -133,6 +146,7 @@ __device__ __forceinline__ void lstm_cell(const LstmParams& lp, const float* __r
 #pragma unroll
     for (int c = 0; c < CG; ++c) cprev[c] = state_in ? state_in[row[c] * 2 * kNVec + O1 + u] : 0.0f;
     __syncthreads();
+    LSTM_STAMP(0, 1);
     f32x4 acc[CG];
 #pragma unroll
     for (int c = 0; c < CG; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -153,6 +167,7 @@ __device__ __forceinline__ void lstm_cell(const LstmParams& lp, const float* __r
 #pragma unroll
     for (int c = 0; c < CG; ++c) xch[(c * 4 + q) * 64 + lane] = acc[c];
     __syncthreads();
+    LSTM_STAMP(0, 2);
 #pragma unroll
     for (int c = 0; c < CG; ++c) {
         const float* xf = reinterpret_cast<const float*>(xch + c * 256) + lane * 4 + q;
@@ -180,9 +195,11 @@ __global__ __launch_bounds__(256) void k_lstm_cell(const float* __restrict__ vec
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int group0 = blockIdx.x * CG;
     const int ti = blockIdx.y;
+    LSTM_STAMP(0, 0);
     if (ti < 16) lstm_cell<2, CG>(lp, vec, state_in, state_out, N, group0, lane, q, ti, xch, xh);
     else if (ti < 24) lstm_cell<1, CG>(lp, vec, state_in, state_out, N, group0, lane, q, ti - 16, xch, xh);
     else lstm_cell<0, CG>(lp, vec, state_in, state_out, N, group0, lane, q, ti - 24, xch, xh);
+    LSTM_STAMP(0, 3);
 }
 
 template <int LV>
@@ -220,7 +237,14 @@ __device__ __forceinline__ void lstm_heads(const LstmParams& lp, const float* __
             for (int e = 0; e < 5; ++e) we[r][e] = W2[(N + e) * N2 + 16 * j + 4 * g + r];
             b2v[r] = b2[16 * j + 4 * g + r];
         }
-        asm volatile("" ::: "memory");  // every request above is issued before the first MFMA below waits for its operands
+        // every request above is issued before the first MFMA below waits for its operands: the ORDER is pinned -- left alone,
+        // hipcc's scheduler sinks each load to just before its use (fewest live registers), i.e. one exposed round trip per
+        // handful of MFMAs (lstm_probe: 7.8 us between "operands landed" and the h2 exchange for a 64-link chain)
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef LSTM_STAMPS_FINE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        LSTM_STAMP(1, 1);
+#endif
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const float hv[4] = {hq[t].x, hq[t].y, hq[t].z, hq[t].w};
@@ -231,10 +255,11 @@ __device__ __forceinline__ void lstm_heads(const LstmParams& lp, const float* __
         // where the registers of the fc2 operands have just become free, so that their round trip passes under the fc2
         // epilogue and the wait for the other waves instead of standing behind the barrier
         if (wave == 0) {
+            const int c3 = min(col, N3 - 1);  // (columns >= N3 feed zeros: loaded from a valid address, then dropped -- no branch per load)
 #pragma unroll
             for (int jj = 0; jj < NT2; ++jj)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) w3v[jj][r] = (col < N3) ? W3[(16 * jj + 4 * g + r) * N3 + col] : 0.0f;
+                for (int r = 0; r < 4; ++r) w3v[jj][r] = W3[(16 * jj + 4 * g + r) * N3 + c3];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int o = min(4 * g + r, N3 - 1);
@@ -242,8 +267,8 @@ __device__ __forceinline__ void lstm_heads(const LstmParams& lp, const float* __
                 for (int e = 0; e < 5; ++e) w3e[r][e] = W3[(N2 + e) * N3 + o];
                 b3v[r] = b3[o];
             }
-            asm volatile("" ::: "memory");
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float v = a2[r];
@@ -254,13 +279,18 @@ __device__ __forceinline__ void lstm_heads(const LstmParams& lp, const float* __
         h2T[(j * 4 + g) * 16 + col] = a2;
     }
     __syncthreads();
+#ifdef LSTM_STAMPS_FINE
+    LSTM_STAMP(1, 2);
+#else
+    LSTM_STAMP(1, 1);
+#endif
     if (wave == 0) {  // fc3^T
         f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < NT2; ++j) {
             const f32x4 hv = h2T[(j * 4 + g) * 16 + col];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) z = MFMA16(w3v[j][r], hv[r], z);
+            for (int r = 0; r < 4; ++r) z = MFMA16(col < N3 ? w3v[j][r] : 0.0f, hv[r], z);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -303,6 +333,7 @@ __global__ __launch_bounds__(768) void k_lstm_heads(const float* __restrict__ st
     int* const pred = gate;                   // two predicate words per mini-batch, then the ticket tree (lstm_gate_words)
     int* fl = pred + 2 * (ctu / kSubBatch);  // one frame: mini-batches of 1024 in raster order
     const int lv = 2 - (int)blockIdx.y;
+    LSTM_STAMP(1, 0);
     if (lv == 0) lstm_heads<0>(lp, hrow, valid, ctu, lane, wave, h2T, raw, probs, fl, fl + 1, thr1, thr2);
     else if (lv == 1) lstm_heads<1>(lp, hrow, valid, ctu, lane, wave, h2T, raw, probs, fl, fl + 1, thr1, thr2);
     else lstm_heads<2>(lp, hrow, valid, ctu, lane, wave, h2T, raw, probs, fl, fl + 1, thr1, thr2);
@@ -315,6 +346,9 @@ __global__ __launch_bounds__(768) void k_lstm_heads(const float* __restrict__ st
     // atomics on one word are served one at a time (~150 ns each: 96 blocks on a single ticket word kept the 1080p launch
     // open for ~14 us after its last MFMA).  Eight blocks share a first-level word (own 128-byte line), its finisher moves the
     // root; every word is reset by its finisher, so the tree is zero again when the launch ends.
+#ifndef LSTM_STAMPS_FINE
+    LSTM_STAMP(1, 2);
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -333,6 +367,7 @@ __global__ __launch_bounds__(768) void k_lstm_heads(const float* __restrict__ st
         s_last = last;
     }
     __syncthreads();
+    LSTM_STAMP(1, 3);
     if (!s_last) return;
     for (int ch = 0; ch < chunks; ++ch) {
         const bool open32 = __hip_atomic_load(pred + 2 * ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
