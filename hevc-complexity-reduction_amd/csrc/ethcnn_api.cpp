@@ -709,7 +709,9 @@ static hipError_t stream_sync(ethcnn_ctx* c) {
         const auto t0 = std::chrono::steady_clock::now();
         for (unsigned spins = 1;; ++spins) {
             if (__atomic_load_n(c->h_done, __ATOMIC_ACQUIRE) == seq) return hipSuccess;
+#if defined(__SSE2__)
             _mm_pause();
+#endif
             if ((spins & 4095u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
         }
     }

@@ -385,7 +385,7 @@ __device__ __forceinline__ void head_pass_regs(float* smem, const float* __restr
 
 
 // ---- the same split with the W2 chunks through a 3-stage LDS ring shared by the block (the first form; kept for pictures of more
-// than 576 CTUs, where 1600 blocks share 512 slots and it measures 7 us faster at 2160p than the register-fed form above): the block's waves SPLIT the FC2
+// than 1536 CTUs, where up to 1600 blocks share 512 slots and it measures 7 us faster at 2160p than the register-fed form above): the block's waves SPLIT the FC2
 // output tiles of the head (head 16: 12 tiles -> 3 per wave; 32: 2, 2, 2, -; 64: 1, 1, 1, -) instead of each taking 16
 // CTUs with all tiles: a wave's K loop is a quarter as long (head 16: 192 MFMAs instead of 768 -- the 64-CTU form keeps one
 // SIMD busy for 10 us, and a picture's heads blocks have the GPU to themselves).  Every wave requests all h1 quads of the

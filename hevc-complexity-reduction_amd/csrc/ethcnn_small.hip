@@ -211,7 +211,7 @@ __device__ __forceinline__ bool block_wait(int* flag, const SmallParams& P, Smal
 #ifndef SMALL_FC1_REGS
 #define SMALL_FC1_REGS 1  // 0: the LDS-staged tile everywhere (A/B builds)
 #endif
-// Which tile a launch uses (measured, profiles/r03_fc1_regs.txt): register-fed for the 16-column shape (<= 576 CTUs: 1080p
+// Which tile a launch uses (measured, profiles/r03_fc1_regs.txt): register-fed for the 16-column shape (<= 1536 CTUs: 1080p
 // 51.7 -> 46.5 us, 768x512 49.7 -> 43.6) and for the LDP front-end at every size (2160p 85.7 -> 80.0); a 2160p All-Intra
 // picture (1600 blocks on 512 slots, the heads blocks among them) keeps the LDS-staged 32-column tile (101 vs 106 us).
 template <int NS, bool RESI>
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void k_small_pass(SmallParams P) {  // <= 2
     float* h2row = P.h2 ? P.h2 + (size_t)ctu * kNFc2 : nullptr;
     int* fl = Y.pred;
     if (head_ != 0) fl += 2 * gate_chunk(P.gi, ctu);
-    if (NS == 1) {  // up to 576 CTUs: register-fed heads (1080p 45.7 -> 43.6 us); bigger pictures: the LDS-ring form (2160p 103 vs 110 us)
+    if (NS == 1) {  // up to 1536 CTUs: register-fed heads (1080p 45.7 -> 43.6 us); bigger pictures: the LDS-ring form (2160p 103 vs 110 us)
         if (head_ == 0) head_pass_regs<2>(smem, P.h1, P.hp, P.qn, lane, wvu, valid, ctu, h2row, P.logits, P.raw, P.probs, fl, fl + 1, P.thr1, P.thr2);
         else if (head_ == 1) head_pass_regs<1>(smem, P.h1, P.hp, P.qn, lane, wvu, valid, ctu, h2row, P.logits, P.raw, P.probs, fl, fl + 1, P.thr1, P.thr2);
         else head_pass_regs<0>(smem, P.h1, P.hp, P.qn, lane, wvu, valid, ctu, h2row, P.logits, P.raw, P.probs, fl, fl + 1, P.thr1, P.thr2);
@@ -381,7 +381,9 @@ void launch_small_pass(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int
     P.bM = (P.ngroups * 4 + 3) / 4;
     P.bL = P.ngroups;  // one L task per block
     static const int force = [] { const char* e = getenv("ETHCNN_SMALL_SHAPE"); return e ? atoi(e) : -1; }();  // development knob
-    int shape = n <= 576 ? 0 : (n <= 2304 ? 1 : 2);
+    // 64 x 16 tiles (register-fed FC1 and heads) up to 1536 CTUs, 64 x 32 above (scripts/latency_mid.py, profiles/r03_latency_mid.txt:
+    // 920 CTUs 61.8 vs 81.5 us, 1536 CTUs 82.9 vs 89.9, 1800 CTUs 101.2 vs 99.6)
+    int shape = n <= 1536 ? 0 : (n <= 2304 ? 1 : 2);
     if (force >= 0 && force <= 2) shape = force;
     const int nsplit = shape == 0 ? 28 : (shape == 1 ? 14 : 7);
     P.wimg = shape == 0 ? w.fc1_img16 : (shape == 1 ? w.fc1_img32 : w.fc1_img64);

@@ -53,7 +53,7 @@ int main(int argc, char** argv) {
     }
     const int ngroups = (n + 15) / 16, ntiles = (n + 63) / 64;
     const int nT = ngroups * 4 + ngroups + ngroups;
-    const int nsplit = n <= 576 ? 28 : (n <= 2304 ? 14 : 7);
+    const int nsplit = n <= 1536 ? 28 : (n <= 2304 ? 14 : 7);
     const int nF = ntiles * nsplit, nH = resi ? 0 : ngroups * 3, nb = nT + nF + nH;
     std::vector<unsigned long long> st((size_t)(1 << 13) * 4);
     CK(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_small_stamps), st.size() * 8));
