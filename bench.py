@@ -235,6 +235,18 @@ def main():
                                "unit": "GB/s", "frac": tile_gbps / PEAK_HBM_GBPS, "avg_launch_ms": tile_ms,
                                "algorithmic_bytes_per_ctu": 4096},
         }
+        # box calibration, right behind the timed region (same clocks, same temperature): what THIS GPU sustains in pure
+        # exact-fp32 MFMAs.  Boxes of one pool differ by several per cent (round 3 saw 39.4 - 42.0 M CTU/s from the same code);
+        # frac_of_box_mfma_rate is the fraction that does not move with the box
+        try:
+            box = ctx.measure_mfma_rate(0.05)
+            result["roofline"]["box_mfma_tflops"] = box
+            result["roofline"]["frac_of_box_mfma_rate"] = fc1_tflops / box if box > 0 else None
+            result["roofline"]["box_note"] = ("pure v_mfma_f32_16x16x4_f32 for 50 ms on this GPU right after the timed region "
+                                              "(ethcnn_measure_mfma_rate); 'peak' stays the data-sheet 157.3")
+        except Exception as exc:  # noqa: BLE001  (calibration only: never fail the bench line)
+            result["roofline"]["box_mfma_tflops"] = None
+            result["roofline"]["box_note"] = "calibration failed: %s" % exc
         # N > 1: the CPU baseline is the same single-box measurement, on a shorter sample (the other ranks wait at the
         # final barrier meanwhile); the per-GPU side measurements that need the GPU to themselves are N = 1 only
         cpu_seconds = args.cpu_seconds if world == 1 else min(args.cpu_seconds, 8.0)

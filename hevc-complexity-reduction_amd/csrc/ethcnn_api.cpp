@@ -194,6 +194,7 @@ struct ethcnn_ctx {
     unsigned done_seq = 0;     // last number handed out
     unsigned done_armed = 0;   // != 0: the LAST operation enqueued on the main stream stores this number when all its outputs are final
     int done_sync = 1;         // env ETHCNN_DONE_WORD=0: always hipStreamSynchronize (A/B runs)
+    int cus = 0;             // compute units of the device
     int gate_fold = 0;       // 1 = the heads launch applies the gates itself (sub-batch arrival counters); 0 = k5_gate launch behind it.
                              // Off by default: measured equal (single pictures) to 0.4 % slower (C3) than the separate launch (env ETHCNN_GATE_FOLD=1)
     bool main_dirty = false; // main-stream work since e_main was last recorded (single-picture passes, LDP steps): the event is
@@ -356,7 +357,7 @@ extern "C" int ethcnn_create(ethcnn_ctx** out, const ethcnn_options* opt) {
         return set_err(nullptr, ETHCNN_ERR_DEVICE, "cannot allocate the completion word on device %d", dev);
     }
     *c->h_done = 0;
-    c->tile_blocks = prop.multiProcessorCount;
+    c->tile_blocks = c->cus = prop.multiProcessorCount;
     {   // the GPU's NUMA node -> its CPU list (/sys/devices/system/node/nodeN/cpulist: "64-127,192-255"); ETHCNN_NUMA_BIND=0 opts out
         int node = -1;
         const char* off = std::getenv("ETHCNN_NUMA_BIND");
@@ -1519,6 +1520,38 @@ extern "C" int ethcnn_synchronize(ethcnn_ctx* c) {
     if (!c) return ETHCNN_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, stream_sync(c));
+    return ETHCNN_OK;
+}
+
+// What this GPU sustains in exact-fp32 MFMAs with nothing else issued, over about `seconds` of pure matrix work (three waves per
+// SIMD, four independent accumulators each).  A calibration for reading roofline fractions: the data-sheet peak is 157.3.
+extern "C" int ethcnn_measure_mfma_rate(ethcnn_ctx* c, double seconds, double* tflops) {
+    if (!c || !tflops || !(seconds > 0.0) || seconds > 5.0) return c ? set_err(c, ETHCNN_ERR_ARG, "seconds must be in (0, 5]") : ETHCNN_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    c->done_armed = 0;
+    float* sink = nullptr;
+    HIPCHK(c, hipMalloc((void**)&sink, 4));
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipFree(sink); return set_err(c, ETHCNN_ERR_DEVICE, "cannot create HIP events"); }
+    const int blocks = c->cus * 3;   // three 4-wave blocks per CU = three waves per SIMD
+    auto run = [&](int iters, float* ms) -> hipError_t {
+        hipError_t e = hipEventRecord(e0, c->stream);
+        launch_mfma_rate(blocks, iters, sink, c->stream);
+        if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        if (e == hipSuccess) e = hipEventElapsedTime(ms, e0, e1);
+        return e;
+    };
+    float ms = 0.0f;
+    hipError_t e = run(2000, &ms);                      // ~2 ms: sizes the real run (and ramps the clock)
+    int iters = 2000;
+    if (e == hipSuccess && ms > 0.0f) iters = (int)std::min(2.0e8, std::max(2000.0, 2000.0 * seconds * 1e3 / ms));
+    if (e == hipSuccess) e = run(iters, &ms);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(sink);
+    if (e != hipSuccess) return set_err(c, ETHCNN_ERR_DEVICE, "MFMA rate measurement failed: %s", hipGetErrorString(e));
+    *tflops = (double)blocks * 4.0 * (double)iters * 32.0 * 2048.0 / ((double)ms * 1e-3) * 1e-12;
     return ETHCNN_OK;
 }
 

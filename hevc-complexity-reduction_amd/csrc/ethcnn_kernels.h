@@ -72,6 +72,9 @@ void launch_lstm(const float* d_vec, const float* d_state_in, float* d_state_out
                  int i_frame, float thr1, float thr2, float* d_raw, float* d_probs, int* d_gate, unsigned* done, unsigned done_seq,
                  hipStream_t s);  // done: completion word in page-locked host memory (null: none), stored by the heads launch's last block
 
+// box calibration (ethcnn_kernels.hip): pure v_mfma_f32_16x16x4_f32, blocks x 4 waves x iters x 32 MFMAs
+void launch_mfma_rate(int blocks, int iters, float* d_sink, hipStream_t s);
+
 int chunks_per_frame(int nctu);
 
 // where the gate predicates of a pass live: chunk(c) = 1024-CTU sub-batch of the frame holding pass CTU c, counted from

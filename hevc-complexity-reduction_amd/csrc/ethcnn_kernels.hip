@@ -47,4 +47,26 @@ void launch_gate(const Workspace& ws, int n, int nctu, long ctu0, float thr2, fl
                        make_gate_index(nctu, ctu0), thr2);
 }
 
+// ============================================================ box calibration ======
+// What THIS GPU sustains in exact-fp32 MFMAs when nothing else is issued (ethcnn_measure_mfma_rate): three waves per SIMD, four
+// independent accumulators each, v_mfma_f32_16x16x4_f32 back to back.  bench.py prints it beside the roofline: boxes of one pool
+// differ by several per cent in sustained clock, and a fraction of the data-sheet peak says nothing about that.
+typedef float f32x4_cal __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_mfma_rate(int iters, float* sink) {
+    f32x4_cal acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const float a = 1.0f + threadIdx.x * 1e-7f, b = 0.999f;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[j], 0, 0, 0);
+    }
+    const float s = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3];
+    if (s == 123.456f) *sink = s;  // (never: keeps the chains alive)
+}
+// one launch: `blocks` blocks of 4 waves, `iters` x 32 MFMAs per wave; flops = blocks * 4 * iters * 32 * 2048
+void launch_mfma_rate(int blocks, int iters, float* d_sink, hipStream_t s) {
+    hipLaunchKernelGGL(k_mfma_rate, dim3(blocks), dim3(256), 0, s, iters, d_sink);
+}
+
 }  // namespace ethcnn

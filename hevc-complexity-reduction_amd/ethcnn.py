@@ -65,6 +65,7 @@ SIGNATURES = {
     "ethcnn_set_pass_pipeline": (_i, [_vp, _i]),
     "ethcnn_set_fused_launch": (_i, [_vp, _i]),
     "ethcnn_set_small_pass_launch": (_i, [_vp, _i]),
+    "ethcnn_measure_mfma_rate": (_i, [_vp, ctypes.c_double, ctypes.POINTER(ctypes.c_double)]),
     "ethcnn_ldp_step": (_i, [_vp, _vp, _i, _i, _pd, _i, _i, _vp, _fp]),
     "ethcnn_ldp_get_state": (_i, [_vp, _fp, _sz]),
     "ethcnn_host_alloc": (_i, [_vp, _sz, ctypes.POINTER(_vp)]),
@@ -463,6 +464,12 @@ class EthCnn(object):
         """launch plan of FC1 / heads / gates: 0 = three launches (default), 1 = one fused launch for big passes,
         2 = FC1 + a heads launch that applies the gates itself.  Same results in every mode."""
         self._chk(self.lib.ethcnn_set_fused_launch(self.h, int(mode)))
+
+    def measure_mfma_rate(self, seconds=0.05):
+        """TFLOP/s of pure exact-fp32 MFMAs this GPU sustains (box calibration for reading roofline fractions)"""
+        v = ctypes.c_double(0.0)
+        self._chk(self.lib.ethcnn_measure_mfma_rate(self.h, float(seconds), ctypes.byref(v)))
+        return v.value
 
     def set_small_pass_launch(self, on=True):
         """one picture (<= 8192 CTUs, 16-byte aligned rows) as ONE launch (default on); off = five launches.  Same results."""

@@ -215,6 +215,11 @@ int ethcnn_set_fused_launch(ethcnn_ctx* ctx, int mode);
  * geometries: the tile / trunk / FC1 / heads / gate launches.  Results do not depend on it.  Env: ETHCNN_SMALL=0. */
 int ethcnn_set_small_pass_launch(ethcnn_ctx* ctx, int on);
 
+/* Box calibration (no reference counterpart): what THIS GPU sustains in exact-fp32 MFMAs (v_mfma_f32_16x16x4_f32, nothing
+ * else issued) over about `seconds` (0 < seconds <= 5) of pure matrix work, in TFLOP/s.  bench.py prints it beside the
+ * roofline: boxes of one pool differ by several per cent in sustained clock, the data-sheet peak (157.3) does not. */
+int ethcnn_measure_mfma_rate(ethcnn_ctx* ctx, double seconds, double* tflops);
+
 /* ---- parity-test introspection: intermediates of the LAST pass, copied to host. */
 enum {
     ETHCNN_DBG_FEATURES = 0, /* [n][2688] h_conv_flat (net_CNN.py:150)          */

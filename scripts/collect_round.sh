@@ -11,6 +11,8 @@ done
 [ -s gpurun_out/latency.txt ] && cp gpurun_out/latency.txt profiles/${R}_latency.txt
 [ -s gpurun_out/latency_ldp.txt ] && cp gpurun_out/latency_ldp.txt profiles/${R}_latency_ldp.txt
 [ -s gpurun_out/latency_host.txt ] && cp gpurun_out/latency_host.txt profiles/${R}_latency_host.txt
+[ -s gpurun_out/lstm_timeline.txt ] && cp gpurun_out/lstm_timeline.txt profiles/${R}_lstm_timeline.txt
+if [ -s gpurun_out/latency_mid_now.txt ]; then { grep "^#" profiles/${R}_latency_mid.txt 2>/dev/null; echo "--- at the round's HEAD (shape 0 up to 1536 CTUs)"; cat gpurun_out/latency_mid_now.txt; echo "--- the measurement the rule came from:"; grep -v "^#" profiles/${R}_latency_mid.txt 2>/dev/null | grep -v "at the round's HEAD" ; } > /tmp/_mid.txt && cp /tmp/_mid.txt profiles/${R}_latency_mid.txt; fi
 [ -s gpurun_out/latency_five_launches.txt ] && cp gpurun_out/latency_five_launches.txt profiles/${R}_latency_five_launches.txt
 [ -s gpurun_out/small_pass_timeline.txt ] && cp gpurun_out/small_pass_timeline.txt profiles/${R}_small_pass_timeline.txt
 [ -s gpurun_out/launch_plans.txt ] && cp gpurun_out/launch_plans.txt profiles/${R}_launch_plans.txt

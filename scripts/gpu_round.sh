@@ -34,6 +34,8 @@ done; done
 python scripts/summarize.py "gpurun_out/plan*.json" | tee gpurun_out/launch_plans.txt
 python scripts/latency_ldp.py --cpu > gpurun_out/latency_ldp.txt 2>&1; cat gpurun_out/latency_ldp.txt
 python scripts/latency_host.py > gpurun_out/latency_host.txt 2>&1; cat gpurun_out/latency_host.txt
+python scripts/latency_mid.py > gpurun_out/latency_mid_now.txt 2>&1; cat gpurun_out/latency_mid_now.txt
+if [ -x scripts/ubench/lstm_probe ]; then (cd scripts/ubench && ./lstm_probe 1920 1080 && ./lstm_probe 832 480) > gpurun_out/lstm_timeline.txt 2>&1; cat gpurun_out/lstm_timeline.txt; fi
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_$WL -o $WL -- python $REPO/bench.py --workload $WL --no-cpu-baseline --no-host-scopes > $REPO/gpurun_out/prof_$WL.log 2>&1
 cd $REPO

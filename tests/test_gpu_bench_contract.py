@@ -56,3 +56,18 @@ def test_two_ranks_through_the_plain_command():
     pkg = importlib.import_module("hevc-complexity-reduction_amd")
     assert hs["fill_threads_per_rank"] == pkg.ethcnn.host_thread_budget(2)
     assert d["parity_first_frame_bit_exact"] is True
+
+
+def test_box_calibration_is_a_plausible_mfma_rate(pkg):
+    """ethcnn_measure_mfma_rate: pure exact-fp32 MFMAs for 20 ms -- between the rate every kernel of the path already reaches and
+    the data-sheet peak (157.3 TFLOP/s); bad arguments are refused"""
+    c = pkg.EthCnn(device=0)
+    try:
+        tf = c.measure_mfma_rate(0.02)
+        assert 120.0 < tf < 160.0, tf
+        with pytest.raises(Exception):
+            c.measure_mfma_rate(0.0)
+        with pytest.raises(Exception):
+            c.measure_mfma_rate(60.0)
+    finally:
+        c.close()
