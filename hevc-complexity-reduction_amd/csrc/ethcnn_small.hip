@@ -5,17 +5,20 @@
 // Why: a picture of a few hundred CTUs was five dependent launches (tile, trunk, FC1, heads, gate) of 10-20 us each with the
 // GPU < 10 % occupied -- every one pays its own dispatch, kernarg fetch, cold instruction cache, weight staging and drain, and
 // the stages cannot overlap (profiles/r02_latency.txt: 69 us for a 1080p picture whose longest dependent chain, FC1's 672 MFMA
-// steps, is 9 us of issue time).  Here the whole pass is a DATAFLOW inside one grid:
+// steps, is 12.9 us of dependent-issue latency, profiles/r03_chain_probe.txt).  Here the whole pass is a DATAFLOW inside one grid:
 //
 //   blocks [0, nT)          trunk: one wave = one unit position of 16 CTUs, pixels gathered STRAIGHT from the luma frame
 //                           (Trunk<.., DIRECT>: the CTU-load stage folded into its consumer; no record buffers, no tile launch)
-//   blocks [nT, +nF)        FC1 64 x (16 NS) tiles; a block starts when the 4 x 21 trunk tasks of its 64 CTUs have landed
+//   blocks [nT, +nF)        FC1 64 x (16 NS) tiles (register-fed up to 1536 CTUs and for the LDP front-end: ethcnn_fc1_regs.h);
+//                           a block starts when the 4 x 21 trunk tasks of its 64 CTUs have landed
 //   blocks [.., +3 groups)  one head of a group of 16 CTUs (its waves split the head's FC2 tiles: head_pass_regs); starts when
 //                           the NSPLIT FC1 column blocks of its 64-CTU tile have landed; applies the gates per sub-batch
 //
-// Every consumer block has a higher block id than its producers and workgroups are dispatched in id order, so a waiting block
-// can only wait for blocks that are resident or finished, and producers never wait: no deadlock whatever the grid size (all
-// blocks of a 1080p pass are co-resident anyway).  All hand-offs are agent-scope (sc1) stores / loads, completed
+// Every consumer block has a higher block id than its producers and workgroups are dispatched in id order, so ALONE on the GPU a
+// waiting block can only wait for blocks that are resident or finished, and producers never wait (all blocks of a 1080p pass
+// are co-resident anyway).  When several processes share the GPU that is not enough -- two such launches can fill each other's
+// XCDs with waiting blocks -- hence CLAIM OR EXECUTE (do_fc1_item / the heads role below): a consumer that has waited too long
+// executes the unclaimed items it depends on itself.  All hand-offs are agent-scope (sc1) stores / loads, completed
 // (s_waitcnt vmcnt(0)) before the producer's counter moves -- the fused big-pass launch's scheme (ethcnn_fused.hip, DESIGN.md
 // "hand-offs inside a launch") -- with the signalling shaped for LATENCY (see SmallSync below): finisher-notifies-private-flag
 // instead of polled counters.  The stages' launch overheads, weight staging and drains overlap instead of adding up.
