@@ -164,6 +164,10 @@ int ethcnn_device_alloc(ethcnn_ctx* ctx, size_t bytes, void** out);
 int ethcnn_device_free(ethcnn_ctx* ctx, void* p);
 int ethcnn_memcpy_h2d(ethcnn_ctx* ctx, void* dst, const void* src, size_t bytes);
 int ethcnn_memcpy_d2h(ethcnn_ctx* ctx, void* dst, const void* src, size_t bytes);
+/* Waits for everything enqueued on the context's main stream.  When the LAST thing enqueued is a single-launch pass or an LDP
+ * step, the wait is a spin on a completion word in page-locked memory that the launch's last block stores (about 5 us sooner
+ * than hipStreamSynchronize; bounded, with hipStreamSynchronize as the fallback, which also reports device faults); otherwise it
+ * is hipStreamSynchronize.  Env ETHCNN_DONE_WORD=0: always the latter. */
 int ethcnn_synchronize(ethcnn_ctx* ctx);
 int ethcnn_device_name(const ethcnn_ctx* ctx, char* out, size_t cap);
 
