@@ -174,6 +174,9 @@ struct ethcnn_ctx {
     int* d_lgate = nullptr;  // LSTM heads launch: gate predicates + ticket tree (lstm_gate_words)
     int lgate_chunks = 0;    // its capacity in ints
     bool lgate_clean = false;
+    int lgate_n = -1;        // frame size the area's layout was last zeroed for
+    int lstm_epoch = 0;      // claim tag of the one-launch frame kernel (ethcnn_lstm.hip)
+    int lstm_one_launch = 1; // cells + heads of an LDP frame as ONE dataflow launch (env ETHCNN_LSTM_ONE_LAUNCH=0: two launches)
     int tile_blocks = 256;   // blocks of the side-stream tile stage: one per CU (ETHCNN_TILE_BLOCKS)
     unsigned pass_idx = 0;   // parity selects the buffer set
     int last_parity = 0;     // of the last pass (debug_fetch reads its h1)
@@ -352,6 +355,7 @@ extern "C" int ethcnn_create(ethcnn_ctx** out, const ethcnn_options* opt) {
     if (const char* e = std::getenv("ETHCNN_FUSED")) c->fused = std::atoi(e) != 0;      // development knob (A/B runs)
     if (const char* e = std::getenv("ETHCNN_GATE_FOLD")) c->gate_fold = std::atoi(e) != 0;  // development knob (A/B runs)
     if (const char* e = std::getenv("ETHCNN_DONE_WORD")) c->done_sync = std::atoi(e) != 0;  // development knob (A/B runs)
+    if (const char* e = std::getenv("ETHCNN_LSTM_ONE_LAUNCH")) c->lstm_one_launch = std::atoi(e) != 0;  // development knob (A/B runs)
     if (hipHostMalloc((void**)&c->h_done, 64, hipHostMallocDefault) != hipSuccess) {
         ethcnn_destroy(c);
         return set_err(nullptr, ETHCNN_ERR_DEVICE, "cannot allocate the completion word on device %d", dev);
@@ -1355,7 +1359,11 @@ extern "C" int ethcnn_lstm_step_device(ethcnn_ctx* c, const float* d_vec, const 
     if (n > c->ws.cap) return set_err(c, ETHCNN_ERR_ARG, "frame of %d CTUs exceeds max_ctus_per_pass", n);
     // gate predicates + ticket tree of the LSTM heads launch: zero between launches by construction (every word is reset by its
     // last user); (re)established here after an allocation or after any failure on this path
-    const int gwords = lstm_gate_words(n);
+    // (the one-launch frame kernel keeps its counters, flags and claim words behind them; a claim word holds the tag of the last
+    // launch that claimed it, so the area is zeroed again whenever the frame size -- and with it the layout -- changes, and
+    // before the tags wrap)
+    const int gwords = lstm_frame_words(n);
+    if (c->lgate_n != n || c->lstm_epoch >= (1 << 30)) c->lgate_clean = false;
     if (gwords > c->lgate_chunks || !c->lgate_clean) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (gwords > c->lgate_chunks) {
@@ -1366,13 +1374,16 @@ extern "C" int ethcnn_lstm_step_device(ethcnn_ctx* c, const float* d_vec, const 
             c->lgate_chunks = gwords;
         }
         HIPCHK(c, hipMemsetAsync(c->d_lgate, 0, (size_t)c->lgate_chunks * sizeof(int), c->stream));  // stream-ordered
+        c->lstm_epoch = 0;
+        c->lgate_n = n;
     }
+    ++c->lstm_epoch;
     c->lgate_clean = false;  // until this launch has been enqueued without an error
     const unsigned seq = done_arm(c);
     {
         StageTimer t(c, ETHCNN_STAGE_HEADS);
         launch_lstm(d_vec, d_state_in, d_state_out, c->d_lstm, n, qp, i_frame, c->thr1, c->thr2, c->debug_capture ? c->ws.raw : nullptr,
-                    d_probs, c->d_lgate, seq ? c->h_done : nullptr, seq, c->stream);
+                    d_probs, c->d_lgate, seq ? c->h_done : nullptr, seq, (c->lstm_one_launch && n <= kLstmOneLaunchMaxCtus) ? 1 : 0, c->lstm_epoch, c->stream);
     }
     HIPCHK(c, hipGetLastError());
     c->lgate_clean = true;

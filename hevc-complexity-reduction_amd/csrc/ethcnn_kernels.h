@@ -70,7 +70,14 @@ unsigned lstm_heads_blocks(int n);
 int lstm_gate_words(int n);
 void launch_lstm(const float* d_vec, const float* d_state_in, float* d_state_out, const float* d_lstm_blob, int n, int qp,
                  int i_frame, float thr1, float thr2, float* d_raw, float* d_probs, int* d_gate, unsigned* done, unsigned done_seq,
-                 hipStream_t s);  // done: completion word in page-locked host memory (null: none), stored by the heads launch's last block
+                 int one_launch, int epoch, hipStream_t s);
+// done: completion word in page-locked host memory (null: none), stored by the frame's last heads block.  one_launch: cells and
+// heads as ONE dataflow launch (k_lstm_frame; d_gate = lstm_frame_words(n) ints, zero except claim words tagged with earlier
+// epochs; epoch = this launch's claim tag, never 0) instead of two launches (d_gate = lstm_gate_words(n) ints suffice)
+int lstm_frame_words(int n);
+// the one-launch form is used while (nearly) all of its blocks are resident at once: 28 cell blocks per 32 CTUs + 3 heads blocks
+// per 16 on 2 x 256 slots -- up to a 1080p frame (544 blocks); a 2160p frame measures 10 us slower than the two launches
+constexpr int kLstmOneLaunchMaxCtus = 640;
 
 // box calibration (ethcnn_kernels.hip): pure v_mfma_f32_16x16x4_f32, blocks x 4 waves x iters x 32 MFMAs
 void launch_mfma_rate(int blocks, int iters, float* d_sink, hipStream_t s);

@@ -52,7 +52,11 @@ constexpr size_t kLstmBlobFloats = 760078;  // 3,040,312-byte .data payload
 // lane = col + 16 g -- one contiguous 1 KB run per (tile, gate, chunk), a dwordx4 per lane
 constexpr int kLstmKernelOff[3] = {727310, 592568, 54496};    // float offsets of the three kernels inside the blob
 constexpr int kLstmPackOff[3] = {0, 32768, 163840};           // float offsets inside the packed area
-constexpr size_t kLstmPackFloats = 688128;
+// ... followed by the fc2 matrices' first N rows in MFMA-operand order (the one-launch LDP frame kernel's heads, ethcnn_lstm.hip):
+// level LV: [tile N2/16][chunk N/16][lane 64][r 4] = W2[16 chunk + 4 g + r][16 tile + col]
+constexpr int kLstmFc2Off[3] = {723688, 578880, 192};         // float offsets of the fc2 matrices [N + 5][N2] inside the blob
+constexpr int kLstmPackFc2Off[3] = {688128, 691200, 703488};  // 64 x 48, 128 x 96, 256 x 192 floats
+constexpr size_t kLstmPackFloats = 752640;
 
 // float offsets into the blob ------------------------------------------------------------
 // conv variables are unnamed: L = Variable.._5, M = _6.._11, S = _12.._17 (creation order,

@@ -237,6 +237,17 @@ void pack_lstm_kernels(const float* blob, float* out) {
                             const int col = lane & 15, g = lane >> 4;
                             *o++ = K[(size_t)(16 * kc + 4 * g + e) * (4 * N) + q * N + 16 * t + col];
                         }
+        // fc2, rows 0 .. N-1 (the 5 efs rows stay where they are)
+        const int N2 = 48 << lv;
+        const float* W2 = blob + kLstmFc2Off[lv];
+        float* o2 = out + kLstmPackFc2Off[lv];
+        for (int j = 0; j < N2 / 16; ++j)
+            for (int t = 0; t < N / 16; ++t)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int r = 0; r < 4; ++r) {
+                        const int col = lane & 15, g = lane >> 4;
+                        *o2++ = W2[(size_t)(16 * t + 4 * g + r) * N2 + 16 * j + col];
+                    }
     }
 }
 

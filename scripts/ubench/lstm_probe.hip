@@ -14,6 +14,7 @@ using namespace ethcnn;
 
 int main(int argc, char** argv) {
     const int W = argc > 1 ? atoi(argv[1]) : 1920, H = argc > 2 ? atoi(argv[2]) : 1080;
+    const int one = argc > 3 ? atoi(argv[3]) : 0;  // 1: the one-launch frame kernel (k_lstm_frame)
     const int n = ((W + 63) / 64) * ((H + 63) / 64);
     float *blob, *vec, *s0, *s1, *probs;
     int* gate;
@@ -26,7 +27,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&s1, (size_t)(n + 64) * 2 * kNVec * 4));
     CK(hipMemset(s0, 0x3c, (size_t)(n + 64) * 2 * kNVec * 4));
     CK(hipMalloc(&probs, (size_t)(n + 64) * kNOut * 4));
-    const int gw = lstm_gate_words(n);
+    const int gw = lstm_frame_words(n);
     CK(hipMalloc(&gate, gw * 4));
     CK(hipMemset(gate, 0, gw * 4));
     hipEvent_t e0, e1;
@@ -35,7 +36,7 @@ int main(int argc, char** argv) {
     float best = 1e9;
     for (int it = 0; it < 20; ++it) {
         hipEventRecord(e0, 0);
-        launch_lstm(vec, s0, s1, blob, n, 32, 3, 0.5f, 0.5f, nullptr, probs, gate, nullptr, 0u, 0);
+        launch_lstm(vec, s0, s1, blob, n, 32, 3, 0.5f, 0.5f, nullptr, probs, gate, nullptr, 0u, one, it + 1, 0);
         hipEventRecord(e1, 0);
         CK(hipEventSynchronize(e1));
         float ms;
@@ -45,12 +46,16 @@ int main(int argc, char** argv) {
     std::vector<unsigned long long> st((size_t)2 * (1 << 11) * 4);
     CK(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_lstm_stamps), st.size() * 8));
     const int groups = (n + 15) / 16, cg = groups >= 12 ? 2 : 1, gx = (groups + cg - 1) / cg;
-    printf("%dx%d: %d CTUs; k_lstm_cell<%d> %d x 28 blocks, k_lstm_heads %d x 3 blocks; both launches %.1f us by HIP events (best of 20)\n", W, H, n, cg, gx, groups, best * 1e3);
+    printf("%dx%d: %d CTUs; %s: cell<%d> %d x 28 blocks, heads %d x 3 blocks; %.1f us by HIP events (best of 20)\n", W, H, n,
+           one ? "ONE launch (k_lstm_frame)" : "two launches", cg, gx, groups, best * 1e3);
     unsigned long long t0 = ~0ull;
     for (int b = 0; b < gx * 28; ++b) t0 = std::min(t0, st[b * 4]);
     struct Role { const char* name; int k, b0, b1; } roles[] = {
         {"cell 16 (256 units)", 0, 0, gx * 16}, {"cell 32 (128)", 0, gx * 16, gx * 24}, {"cell 64 (64)", 0, gx * 24, gx * 28},
         {"heads 16", 1, 0, groups}, {"heads 32", 1, groups, 2 * groups}, {"heads 64", 1, 2 * groups, 3 * groups}};
+    if (one) {
+        for (int i = 3; i < 6; ++i) { roles[i].b0 += gx * 28; roles[i].b1 += gx * 28; }  // heads blocks follow the cell blocks in ONE grid
+    }
     printf("%-20s %6s | %-21s | %-21s | %-21s | %-21s\n", "role", "blocks", "entry  min/avg/max", "staged / exchanged", "chain / stored", "exit   min/avg/max");
     for (const Role& r : roles) {
         if (r.b1 > (1 << 11)) { printf("%s: more blocks than stamp slots\n", r.name); continue; }

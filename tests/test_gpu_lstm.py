@@ -245,3 +245,46 @@ def test_ldp_step_keeps_the_state_resident(pkg, oracle, lstm):
     finally:
         a.close()
         b.close()
+
+
+def test_one_launch_frame_kernel_both_forms_and_forced_claim_or_execute(pkg, oracle, lstm):
+    """An LDP frame's LSTM cells and heads run as ONE dataflow launch up to 640 CTUs (k_lstm_frame: heads blocks wait for the cells
+    of their group and level inside the grid) and as two launches above, or with ETHCNN_LSTM_ONE_LAUNCH=0.  Both forms, frame
+    sizes on both sides of the limit and of the CG = 1 / 2 switch, closed and open gates, six-frame recurrences on the resident
+    state: bit-exact vs the oracle.  ETHCNN_LSTM_STEAL_TEST=k makes every k-th cell block leave WITHOUT claiming its item and
+    gives the heads blocks no patience, so they must execute those cell items themselves (the forward-progress path of a
+    shared GPU).  One subprocess per setting (the knobs are read once per process)."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import importlib, os, sys
+        import numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "oracle"))
+        import ethcnn_np as oracle, ethcnn_lstm_np as ol
+        pkg = importlib.import_module("hevc-complexity-reduction_amd")
+        c = pkg.EthCnn(0)
+        bits = lambda a: np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+        rng = np.random.default_rng(5)
+        for n, gain in ((7, 1.0), (104, 3.0), (192, 2.0), (510, 4.0), (640, 2.0), (656, 2.0), (1064, 5.0)):
+            blob = ol.synth_lstm_blob(11 + n, gain)
+            c.load_lstm_blob(blob)
+            state = None
+            want_state = None
+            for i_frame in range(1, 7):
+                thr = (0.5, 0.5) if i_frame %% 2 else (0.97, 0.6)
+                c.set_thresholds(*thr)
+                vec = (np.abs(rng.standard_normal((n, 448))) * 0.5).astype(np.float32)
+                vec[:, ::5] *= -0.3
+                got_p, state = c.lstm_step(vec, state, 27, i_frame)
+                want_p, want_state = ol.lstm_step(blob, vec, want_state, 27, i_frame, thr[0], thr[1], mode=0)
+                assert np.array_equal(bits(got_p), bits(want_p)), (n, i_frame)
+                assert np.array_equal(bits(state), bits(want_state)), (n, i_frame)
+        print("ok")
+    """ % (root, root))
+    for env in ({}, {"ETHCNN_LSTM_ONE_LAUNCH": "0"}, {"ETHCNN_LSTM_STEAL_TEST": "2"}, {"ETHCNN_LSTM_STEAL_TEST": "3"},
+                {"ETHCNN_LSTM_STEAL_TEST": "7"}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "ok" in r.stdout, (env, r.stdout[-300:], r.stderr[-1500:])
