@@ -288,3 +288,51 @@ def test_one_launch_frame_kernel_both_forms_and_forced_claim_or_execute(pkg, ora
                 {"ETHCNN_LSTM_STEAL_TEST": "7"}):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and "ok" in r.stdout, (env, r.stdout[-300:], r.stderr[-1500:])
+
+
+def test_four_processes_run_ldp_frames_on_one_gpu(pkg, oracle, lstm, tmp_path):
+    """Several encoders sharing one GPU: four processes that start together and each run LDP frames (front-end as one launch, cells +
+    heads as one launch) for 2 s.  The dataflow launches' waiting blocks must not starve each other's producers (claim or
+    execute): every process keeps its rate, every checked frame is bit-exact, none traps."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import importlib, os, sys, time
+        import numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "oracle"))
+        import ethcnn_np as oracle, ethcnn_lstm_np as ol
+        pkg = importlib.import_module("hevc-complexity-reduction_amd")
+        seed, gate = int(sys.argv[1]), sys.argv[2]
+        rng = np.random.default_rng(seed)
+        blob, lblob = oracle.synth_blob(6, 1.0), ol.synth_lstm_blob(4 + seed, 3.0)
+        c = pkg.EthCnn(0)
+        c.load_blob(blob); c.load_lstm_blob(lblob); c.set_thresholds(0.6, 0.7)
+        w, h = (1920, 1080) if seed %% 2 else (832, 480)
+        frames = [np.clip(np.rint(128 + rng.laplace(0, 7, size=(h, w))), 0, 255).astype(np.uint8) for _ in range(4)]
+        vecs = [oracle.resi_vectors(blob, f, w, h) for f in frames]
+        open(os.path.join(gate, "ready%%d" %% seed), "w").close()
+        while len(os.listdir(gate)) < 4:
+            time.sleep(0.001)
+        t0, k, state, ostate = time.time(), 0, None, None
+        while time.time() - t0 < 2.0:
+            i = k %% 4
+            probs, state = c.ldp_predict_frame(frames[i], w, h, 32, k + 1, state)
+            if k < 12:   # the oracle recurrence is followed for the first frames (it is the slow side), then the GPU runs on
+                want, ostate = ol.lstm_step(lblob, vecs[i], ostate, 32, k + 1, 0.6, 0.7, mode=0)
+                assert np.array_equal(probs.view(np.uint32), want.view(np.uint32)), (seed, k)
+                assert np.array_equal(state.view(np.uint32), ostate.view(np.uint32)), (seed, k)
+            k += 1
+        print("ok %%d %%d frames %%.2f s" %% (seed, k, time.time() - t0))
+    """ % (root, root))
+    gate = tmp_path / "gate"
+    gate.mkdir()
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(s), str(gate)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for s in range(4)]
+    for s, p in enumerate(procs):
+        out, err = p.communicate(timeout=300)
+        assert p.returncode == 0 and ("ok %d" % s) in out, (s, out[-500:], err[-1500:])
+        print(out.strip())
+        assert int(out.split()[2]) >= 100 and float(out.split()[4]) < 6.0, out
