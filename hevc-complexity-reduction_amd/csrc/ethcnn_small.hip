@@ -267,7 +267,7 @@ __device__ __forceinline__ void do_fc1_item(const SmallParams& P, const SmallSyn
 template <int NS, int NSUB, bool RESI>
 __global__ __launch_bounds__(256, 2) void k_small_pass(SmallParams P) {  // <= 256 registers: two blocks per CU
     constexpr int NSPLIT = kNVec / (16 * NS);
-    constexpr int LDS_FLOATS = MaxOf<MaxOf<(fc1_regs<NS, RESI>() ? 0 : Fc1Shape<1, NS, 4, NSUB, 3>::LDS_FLOATS), kTrunkWFrags * 64 + 8 * 64 * 4>::value, (RESI ? 0 : (NS == 1 ? 12 * 256 : kHeadsLatStages * kHeadsStage + 12 * 256))>::value;
+    constexpr int LDS_FLOATS = MaxOf<MaxOf<(fc1_regs<NS, RESI>() ? 0 : Fc1Shape<1, NS, 4, NSUB, 3>::LDS_FLOATS), (RESI ? kTrunkResiLds : kTrunkWFrags * 64 + 8 * 64 * 4)>::value, (RESI ? 0 : (NS == 1 ? 12 * 256 : kHeadsLatStages * kHeadsStage + 12 * 256))>::value;
     __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
     __shared__ SmallShared sh;
     const int bid = (int)blockIdx.x;

@@ -91,6 +91,10 @@ constexpr int kNb[3] = {4, 2, 1};             // units per CTU side
 // with lane = col + 16 g.  Bias fragments (value for C-layout row 4g + r):
 //   [0..3] conv1, [4..11] conv2 [t][r] (0 for co >= 24), [12..19] conv3 [t][r]
 constexpr int kTrunkWFrags = 84, kTrunkBFrags = 20;
+// LDS of a trunk block (floats): [84 x 64 weight fragments][8 x 64 x 4: gather exchange of the single-launch pass's L blocks]
+// [resi only: the preprocessed values of the branch's 256 / 1021 / 4081 possible pixel sums, ethcnn_trunk_task.h]
+constexpr int kTrunkResiTabAt = kTrunkWFrags * 64 + 8 * 64 * 4;
+constexpr int kTrunkResiLds = kTrunkResiTabAt + 4096;
 
 struct DeviceWeights {
     float* trunk_w = nullptr;  // [3][84][64]

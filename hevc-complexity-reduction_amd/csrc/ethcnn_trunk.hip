@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void k1_trunk(const uint4* __restrict__ XS, co
                                                 const uint4* __restrict__ XL, int N, int bS, int bM,
                                                 const float* __restrict__ wfrag, const float* __restrict__ bfrag,
                                                 float* __restrict__ F) {
-    __shared__ float wl[kTrunkWFrags * 64];  // this block's branch: 84 A-operand fragments, 21 KB
+    __shared__ float wl[RESI ? kTrunkResiLds : kTrunkWFrags * 64];  // this block's branch: 84 A-operand fragments, 21 KB (+ resi: the table of preprocessed pixel sums)
     // wave-uniform on purpose (readfirstlane): task, group and unit indices then live in SGPRs, and every load / store
     // below is "SGPR base + one 32-bit VGPR lane offset" (saddr form) instead of a 64-bit per-lane address: a VMEM
     // instruction with VGPR addresses costs several times more matrix-pipe time (profiles/r02_fc1_variants.txt)

@@ -58,6 +58,11 @@ struct Trunk {
     static constexpr int OFF2 = (BR == 0) ? 672 : (BR == 1 ? 2208 : 2592);
     static constexpr int OFF3 = (BR == 0) ? 0 : (BR == 1 ? 512 : 640);
     static constexpr int NJ = (BR == 0) ? 4 : 8;  // uint4 records per lane per task
+    // resi: the preprocessed value of a pixel sum, (s - 128 cnt) / 255.0 * 10 (* SCALE), is a true fp32 DIVISION per value
+    // (~12 VALU instructions; 64 of them per lane and task: 1.5 us of a single-picture launch's trunk phase).  A pixel sum has
+    // only 255 cnt + 1 values, so the block tabulates them once -- with exactly that expression -- in LDS behind its weight
+    // fragments and the gather area, and the task loop looks them up: bit-identical by construction.
+    static constexpr int TAB = 255 * POOL * POOL + 1;  // 256 / 1021 / 4081 entries
 
     // exact integer sum of this lane's part of the record (the block mean needs it before conv1)
     static __device__ __forceinline__ int raw_sum(const uint4 (&raw)[NJ]) {
@@ -74,7 +79,7 @@ struct Trunk {
         return T;
     }
     // the 4 conv1 patches of position q2 -> x[q1][kx] (pixel sums as floats; resi: preprocessed values)
-    static __device__ __forceinline__ void decode_q2(const uint4 (&raw)[NJ], int q2, float (&x)[4][4]) {
+    static __device__ __forceinline__ void decode_q2(const uint4 (&raw)[NJ], int q2, float (&x)[4][4], const float* tab) {
         if (BR == 0) {
             const uint32_t w[4] = {raw[q2].x, raw[q2].y, raw[q2].z, raw[q2].w};
 #pragma unroll
@@ -82,7 +87,7 @@ struct Trunk {
 #pragma unroll
                 for (int kx = 0; kx < 4; ++kx) {
                     const int s = (int)((w[q1] >> (8 * kx)) & 0xff);
-                    x[q1][kx] = RESI ? px_value<true>(s, 1) : (float)s;
+                    x[q1][kx] = RESI ? tab[s] : (float)s;
                 }
         } else {
 #pragma unroll
@@ -94,7 +99,7 @@ struct Trunk {
 #pragma unroll
                     for (int kx = 0; kx < 4; ++kx) {
                         const int s = (int)((w[2 * hh + (kx >> 1)] >> (16 * (kx & 1))) & 0xffff);
-                        x[2 * jj + hh][kx] = RESI ? px_value<true>(s, POOL * POOL) * SCALE : (float)s;
+                        x[2 * jj + hh][kx] = RESI ? tab[s] : (float)s;
                     }
             }
         }
@@ -234,10 +239,13 @@ struct Trunk {
         {
             const float* wf = wfrag + (size_t)BR * kTrunkWFrags * 64;
             for (int i = threadIdx.x; i < kTrunkWFrags * 64; i += 256) wl[i] = wf[i];
+            if (RESI)  // (same expression as px_value's callers used per value: the table IS those values)
+                for (int i = threadIdx.x; i < TAB; i += 256) wl[kTrunkResiTabAt + i] = px_value<true>(i, POOL * POOL) * (BR == 0 ? 1.0f : SCALE);
         }
         __syncthreads();
         if (claim != nullptr && !*s_owned) return;  // (block-uniform)
         if (!active) return;
+        const float* tab = wl + kTrunkResiTabAt;  // (resi only)
         const float* wA2 = wl + 4 * 64 + lane;   // A2[t][s] = wA2[(t * 16 + s) * 64]
         const float* wA3 = wl + 36 * 64 + lane;  // A3[t][s] = wA3[(t * 24 + s) * 64]
 
@@ -324,7 +332,7 @@ struct Trunk {
             for (int q2 = 0; q2 < 4; ++q2) {
                 f32x4 c1[4], c2[2];
                 float x[4][4];
-                decode_q2(raw, q2, x);
+                decode_q2(raw, q2, x, tab);
                 CONV1(q2, c1);
                 LEAKY1(c1);
                 CONV2(c1, c2);
