@@ -287,3 +287,21 @@ def test_empty_and_degenerate_inputs(pkg, ctx, oracle, tmp_path):
         yuv.write_bytes(b"\0" * 1000)
         ctx.predict_yuv_file(str(yuv), 416, 240, 32, str(tmp_path / "x.dat"))
     assert not (tmp_path / "x.dat").exists()
+
+
+def test_fc1_shapes_over_short_row_ranges_are_bit_identical():
+    """The FC1 stage of the multi-launch path picks one of several tile shapes by row count (LDS-staged 64 x 64 / 32 / 16, register-fed
+    64 x 16 / 32 / 64: fc1_short_variant).  Every shape, forced through ETHCNN_FC1_VARIANT, over row counts on both sides of every
+    switch point and with ragged last groups / tiles, must give the same bits as the library's own choice (scripts/fc1_rows.py
+    compares a crc of the 448-vectors; the default choice is checked against the oracle by the other tests of this file)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ETHCNN_SMALL="0", ROWS="1,17,63,65,510,576,577,1152,1153,1792,1793,3000")
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fc1_rows.py"), "-1", "2", "3", "4", "7", "8", "9"],
+                       env=env, capture_output=True, text=True, timeout=280)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("v")]
+    assert r.returncode == 0 and len(lines) == 7, (r.stdout[-800:], r.stderr[-800:])
+    for l in lines:
+        assert l.rstrip().endswith("results identical"), l
