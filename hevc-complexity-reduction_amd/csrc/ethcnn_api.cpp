@@ -189,6 +189,10 @@ struct ethcnn_ctx {
     int ssync_cap = 0;       // in ints
     bool ssync_clean = false;
     int small_epoch = 0;     // claim tag of the last single-launch pass (1 .. 2^30, wraps: the area is re-zeroed then)
+    int fc1_plan = 0;        // 0 = exact fp32 FC1 (default; bit-identical to the oracle); 1 = "fast": FC1 of the multi-launch path as exact
+                             // three-way bf16 splits on the bf16 matrix pipe (ethcnn_fc1_fast.hip; ethcnn_set_fc1_plan, env ETHCNN_FC1_PLAN=1)
+    uint16_t* dw_fast = nullptr;  // W1 in plan 1's form (packed on first use), 7.2 MB
+    bool last_fast = false;  // the last pass ran plan 1 (debug_fetch reads its features from ws.featb)
     int fused = 0;           // 1 = big passes run FC1 + heads + gates as ONE launch (ethcnn_set_fused_launch, env ETHCNN_FUSED=1).
                              // Off by default: measured equal-to-1 % slower than the separate launches
     // completion word (page-locked host memory): the last block of a latency-path launch stores the launch's sequence number
@@ -256,7 +260,7 @@ extern "C" const char* ethcnn_last_error(const ethcnn_ctx* ctx) {
 // ------------------------------------------------------------------ workspace -------
 static void free_workspace(ethcnn_ctx* c) {
     Workspace& w = c->ws;
-    void* ptrs[] = {w.xs, w.xm, w.xl, w.feat, w.h1, w.h2, w.logits, w.raw, w.flags, c->xs1, c->xm1, c->xl1, c->h1_1, c->flags1};
+    void* ptrs[] = {w.featb, w.xs, w.xm, w.xl, w.feat, w.h1, w.h2, w.logits, w.raw, w.flags, c->xs1, c->xm1, c->xl1, c->h1_1, c->flags1};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     w = Workspace();
@@ -298,6 +302,8 @@ static int ensure_workspace(ethcnn_ctx* c, int n, int chunks) {
         HIPCHK(c, hipMalloc((void**)&c->h1_1, (size_t)cap * kNVec * 4));
         w.cap = cap;
     }
+    if (c->fc1_plan == 1 && !w.featb)  // plan 1: the features as bf16 x 3 pieces, 16,128 B per CTU (ethcnn_spec.h)
+        HIPCHK(c, hipMalloc((void**)&w.featb, (size_t)((w.cap + 31) / 32) * kFastPairBytes));
     const int words = sync_words(std::max(n, w.cap), chunks);
     if (words > w.flags_cap) {
         if (w.flags) (void)hipFree(w.flags);  // hipFree synchronises the device: no pass in flight still uses them
@@ -352,6 +358,7 @@ extern "C" int ethcnn_create(ethcnn_ctx** out, const ethcnn_options* opt) {
     }
     if (const char* e = std::getenv("ETHCNN_OVERLAP")) c->overlap = std::atoi(e) != 0;  // development knob (A/B runs)
     if (const char* e = std::getenv("ETHCNN_SMALL")) c->small_launch = std::atoi(e) != 0;  // development knob (A/B runs)
+    if (const char* e = std::getenv("ETHCNN_FC1_PLAN")) c->fc1_plan = std::atoi(e) == 1;  // user-facing: start contexts in FC1 plan 1
     if (const char* e = std::getenv("ETHCNN_FUSED")) c->fused = std::atoi(e) != 0;      // development knob (A/B runs)
     if (const char* e = std::getenv("ETHCNN_GATE_FOLD")) c->gate_fold = std::atoi(e) != 0;  // development knob (A/B runs)
     if (const char* e = std::getenv("ETHCNN_DONE_WORD")) c->done_sync = std::atoi(e) != 0;  // development knob (A/B runs)
@@ -433,10 +440,10 @@ static void free_staging(ethcnn_ctx* c) {
 }
 
 extern "C" void ethcnn_destroy(ethcnn_ctx* c) {
-    if (c && c->h_done) { (void)hipDeviceSynchronize(); (void)hipHostFree(c->h_done); c->h_done = nullptr; }
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipDeviceSynchronize();
+    (void)hipDeviceSynchronize();  // on THIS context's device: a launch still in flight may store the completion word
+    if (c->h_done) { (void)hipHostFree(c->h_done); c->h_done = nullptr; }
     for (auto& p : c->pending) { c->ev_pool.push_back(p.a); c->ev_pool.push_back(p.b); }
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     free_workspace(c);
@@ -444,6 +451,7 @@ extern "C" void ethcnn_destroy(ethcnn_ctx* c) {
     for (const auto& r : c->pinned) (void)hipHostFree(const_cast<char*>(r.first));  // ethcnn_host_alloc buffers die with the context
     delete c->pool;
     if (c->dw_arena) (void)hipFree(c->dw_arena);
+    if (c->dw_fast) (void)hipFree(c->dw_fast);
     {
         void* lp[] = {c->d_lstm, c->d_vec, c->d_state[0], c->d_state[1], c->d_lprobs, c->d_lgate, c->d_ssync};
         for (void* p : lp)
@@ -521,8 +529,33 @@ static int upload_weights(ethcnn_ctx* c) {
         d.fc3_w[h] = c->dw_arena + offs[10 + 2 * h];
         d.fc3_b[h] = c->dw_arena + offs[11 + 2 * h];
     }
+    d.fc1_fast = nullptr;  // plan 1's image of W1 belongs to the previous weights: repacked on the next plan-1 pass
     c->have_weights = true;
     return ETHCNN_OK;
+}
+
+// plan 1: W1 as three bf16 pieces in the bf16 MFMA's B-operand order (ethcnn_weights.cpp::pack_fc1_fast_image), once per weight load
+static int ensure_fast_weights(ethcnn_ctx* c) {
+    if (c->dw.fc1_fast) return 0;
+    const size_t n16 = (size_t)kNFeat * kNVec * 3;
+    std::vector<float> wcat((size_t)kNFeat * kNVec), b1(kNVec);
+    pack_fc1(c->blob.data(), wcat.data(), b1.data());
+    {   // the feature order of the plan is a table of the trunk's register order: it must be a permutation of 0 .. 2687
+        std::vector<char> seen(kNFeat, 0);
+        for (int ch = 0; ch < kFastChunks; ++ch)
+            for (int s8 = 0; s8 < 16; ++s8) {
+                const int k = fast_feature_k(ch, s8 >> 3, s8 & 7);
+                if (k < 0 || k >= kNFeat || seen[k]) return set_err(c, ETHCNN_ERR_ARG, "internal: FC1 plan 1 feature order is not a permutation (chunk %d)", ch);
+                seen[k] = 1;
+            }
+    }
+    std::vector<uint16_t> img(n16);
+    pack_fc1_fast_image(wcat.data(), img.data());
+    if (!c->dw_fast) HIPCHK(c, hipMalloc((void**)&c->dw_fast, n16 * 2));
+    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, hipMemcpy(c->dw_fast, img.data(), n16 * 2, hipMemcpyHostToDevice));
+    c->dw.fc1_fast = c->dw_fast;
+    return 0;
 }
 
 extern "C" int ethcnn_load_blob(ethcnn_ctx* c, const float* blob, size_t nfloats) {
@@ -661,6 +694,14 @@ extern "C" int ethcnn_set_fused_launch(ethcnn_ctx* c, int on) {
     return ETHCNN_OK;
 }
 
+extern "C" int ethcnn_set_fc1_plan(ethcnn_ctx* c, int plan) {
+    if (!c) return ETHCNN_ERR_ARG;
+    if (plan != 0 && plan != 1) return set_err(c, ETHCNN_ERR_ARG, "FC1 plan must be 0 (exact fp32, default) or 1 (bf16 x 3 split), got %d", plan);
+    c->fc1_plan = plan;  // takes effect with the next pass enqueued
+    return ETHCNN_OK;
+}
+extern "C" int ethcnn_get_fc1_plan(const ethcnn_ctx* c) { return c ? c->fc1_plan : ETHCNN_ERR_ARG; }
+
 extern "C" int ethcnn_set_small_pass_launch(ethcnn_ctx* c, int on) {
     if (!c) return ETHCNN_ERR_ARG;
     c->small_launch = on ? 1 : 0;  // takes effect with the next pass enqueued; results do not depend on it
@@ -789,6 +830,7 @@ static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, lo
         c->times.ctus += n;
         c->last_n = n;
         c->last_parity = p;
+        c->last_fast = false;  // (the single-launch pass always computes FC1 exactly)
         return 0;
     }
     if (side_tile) {
@@ -820,12 +862,20 @@ static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, lo
         HIPCHK(c, hipEventRecord(c->e_tile[p], s_tile));
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->e_tile[p], 0));
     }
-    { StageTimer t(c, ETHCNN_STAGE_TRUNK); launch_trunk(w, c->dw, n, false, c->stream); }
+    const bool fast = c->fc1_plan == 1;  // FC1 plan 1: trunk -> bf16 x 3 feature pieces -> FC1 on the bf16 matrix pipe
+    if (fast && (rc = ensure_fast_weights(c)) != 0) return rc;
+    { StageTimer t(c, ETHCNN_STAGE_TRUNK); launch_trunk(w, c->dw, n, false, c->stream, fast); }
     LAUNCH_OK("trunk");
     if (side_tile) HIPCHK(c, hipEventRecord(c->e_trunk[p], c->stream));
     Workspace wv = w;
     if (!c->debug_capture) wv.h2 = wv.logits = wv.raw = nullptr;
-    if (c->fused && fc1_heads_fusable(n)) {
+    if (fast) {
+        { StageTimer t(c, ETHCNN_STAGE_FC1, n); launch_fc1_fast(w, c->dw, n, w.h1, c->stream); }
+        LAUNCH_OK("FC1 (plan 1)");
+        { StageTimer t(c, ETHCNN_STAGE_HEADS); launch_heads(wv, c->dw, n, qn, g.nctu, ctu0, c->thr1, c->thr2, d_probs_pass, c->stream, c->gate_fold ? (int)nchunks : 0); }
+        if (!c->gate_fold) { StageTimer t(c, ETHCNN_STAGE_GATE); launch_gate(w, n, g.nctu, ctu0, c->thr2, d_probs_pass, c->stream); }
+        LAUNCH_OK("heads / gate");
+    } else if (c->fused && fc1_heads_fusable(n)) {
         // big pass: FC1, the heads and the gates are ONE launch (ethcnn_fused.hip); its time is booked under the FC1 stage
         { StageTimer t(c, ETHCNN_STAGE_FC1, n); launch_fc1_heads(wv, c->dw, n, qn, g.nctu, ctu0, c->thr1, c->thr2, d_probs_pass, (int)nchunks, c->stream); }
         LAUNCH_OK("fused FC1 + heads + gate");
@@ -841,6 +891,7 @@ static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, lo
     c->times.ctus += n;
     c->last_n = n;
     c->last_parity = p;
+    c->last_fast = fast;
     return 0;
 }
 
@@ -1076,7 +1127,7 @@ static int host_pipeline(ethcnn_ctx* c, int w, int h, int nframes, int qp, Fill 
 // [p, p + bytes) inside a buffer from ethcnn_host_alloc: page-locked, DMA-able (and device-addressable) as it is
 static bool in_pinned(const ethcnn_ctx* c, const void* p, size_t bytes);
 
-// One picture (or a few small ones): a single pass of <= 8192 CTUs.  The staging ring above is built for throughput -- a pool
+// One picture (or a few small ones): a single pass of < 8192 CTUs (kPipelineMinCtus; <= 2304 of them as ONE launch, above that five).  The staging ring above is built for throughput -- a pool
 // wake-up, three streams and two events per group -- which is most of the time of a one-frame call.  Here: (copy into pinned
 // staging unless the caller's buffer IS pinned) -> H2D -> the pass -> D2H, all on the main stream, one synchronisation.
 static int predict_luma_latency(ethcnn_ctx* c, const uint8_t* luma, int w, int h, ptrdiff_t pitch, ptrdiff_t fstride, int nframes,
@@ -1122,7 +1173,8 @@ extern "C" int ethcnn_predict_luma(ethcnn_ctx* c, const uint8_t* luma, int w, in
     if (!c || !luma || !probs || nframes < 0) return c ? set_err(c, ETHCNN_ERR_ARG, "null pointer / negative frame count") : ETHCNN_ERR_ARG;
     if (pitch < w) return set_err(c, ETHCNN_ERR_ARG, "pitch %td < width %d", pitch, w);
     const int nctu = ((w + 63) / 64) * ((h + 63) / 64);
-    if (w > 0 && h > 0 && nframes > 0 && (long)nframes * nctu <= kPipelineMinCtus)  // a picture, not a sequence
+    if (w > 0 && h > 0 && nframes > 0 && (long)nframes * nctu < kPipelineMinCtus)  // a picture, not a sequence (strictly below: a pass of
+        // exactly kPipelineMinCtus CTUs runs its tile stage on the side stream, which the latency path's H2D copy is not ordered with)
         return predict_luma_latency(c, luma, w, h, pitch, fstride, nframes, qp, probs);
     auto fill = [&](uint8_t* dst, int f0, int nf) -> int {
         return parallel_bands(c, nf, w, h, [&](int f, int r0, int rows) -> int {
@@ -1588,6 +1640,24 @@ extern "C" int ethcnn_debug_fetch(ethcnn_ctx* c, int which, float* out, size_t n
     }
     if (!src || nfloats > (size_t)c->last_n * per) return set_err(c, ETHCNN_ERR_ARG, "debug_fetch: last pass had %d CTUs", c->last_n);
     if (which != ETHCNN_DBG_FEATURES) return ethcnn_memcpy_d2h(c, out, src, nfloats * 4);
+    if (c->last_fast) {
+        // plan 1: the trunk left every feature as three bf16 pieces whose sum IS the feature (exact split): add them back
+        const size_t n = (nfloats + kNFeat - 1) / kNFeat, pairs = (n + 31) / 32;
+        std::vector<uint16_t> rawb(pairs * (kFastPairBytes / 2));
+        int rc = ethcnn_memcpy_d2h(c, rawb.data(), c->ws.featb, rawb.size() * 2);
+        if (rc) return rc;
+        auto f32 = [](uint16_t h) { const uint32_t u = (uint32_t)h << 16; float f; std::memcpy(&f, &u, 4); return f; };
+        for (size_t row = 0; row * kNFeat < nfloats; ++row)
+            for (int ch = 0; ch < kFastChunks; ++ch)
+                for (int kh = 0; kh < 2; ++kh)
+                    for (int idx = 0; idx < 8; ++idx) {
+                        const size_t o = row * kNFeat + (size_t)fast_feature_k(ch, kh, idx);
+                        if (o >= nfloats) continue;
+                        const uint16_t* rec = rawb.data() + ((row / 32) * kFastChunks + ch) * 3 * 512 + (kh * 32 + row % 32) * 8 + idx;
+                        out[o] = (f32(rec[0]) + f32(rec[512])) + f32(rec[1024]);
+                    }
+        return ETHCNN_OK;
+    }
     // features live as [group of 16 CTUs][k/4][16][4] (ethcnn_dense.hip); hand back [n][2688]
     const size_t n = (nfloats + kNFeat - 1) / kNFeat, groups = (n + 15) / 16;
     std::vector<float> rawf(groups * 16 * kNFeat);

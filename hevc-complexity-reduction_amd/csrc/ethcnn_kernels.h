@@ -13,6 +13,7 @@ struct Workspace {
     uint4* xm = nullptr;     // [cap/4][8][64]    u16 2x2 pooled sums (M branch)
     uint4* xl = nullptr;     // [cap/16][8][64]   u16 4x4 pooled sums (L branch)
     float* feat = nullptr;   // [cap][2688]
+    uint16_t* featb = nullptr; // FC1 plan 1 only: [cap/32][168][3][512] bf16 pieces of the features (ethcnn_spec.h, kFastPairBytes)
     float* h1 = nullptr;     // [cap][448]
     float* h2 = nullptr;     // [cap][336]
     float* logits = nullptr; // [cap][21]
@@ -32,10 +33,13 @@ struct FrameGeom {
 // max_blocks > 0: slab-staged persistent form with at most that many blocks (one per CU when it runs beside FC1)
 void launch_tile(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, const Workspace& ws, int n_flags,
                  hipStream_t s, int max_blocks = 0);
-// k1: xs/xm/xl -> feat
-void launch_trunk(const Workspace& ws, const DeviceWeights& w, int n, bool resi, hipStream_t s);
+// k1: xs/xm/xl -> feat (fast: -> featb, every feature as three bf16 pieces in the bf16 MFMA's operand order, FC1 plan 1)
+void launch_trunk(const Workspace& ws, const DeviceWeights& w, int n, bool resi, hipStream_t s, bool fast = false);
 // k2: feat -> h1 (bias + leaky-ReLU fused); out may be ws.h1 or a caller buffer (resi vectors)
 void launch_fc1(const Workspace& ws, const DeviceWeights& w, int n, float* out, hipStream_t s);
+// k2, plan 1 (ethcnn_fc1_fast.hip): featb -> h1 on the bf16 matrix pipe: six bf16 products per fp32 product (exact three-way
+// splits of both operands, terms i + j <= 2), fp32 accumulate; same bias + leaky-ReLU epilogue, same h1 layout
+void launch_fc1_fast(const Workspace& ws, const DeviceWeights& w, int n, float* out, hipStream_t s);
 // k3+k4 fused: h1 -> h2 -> logits, raw probs, probs and per-chunk gate flags.  gate_nchunks > 0: the batch gates are applied
 // inside the launch (ws.flags = sync area: arrival counters behind the 2 * gate_nchunks predicates, zero on
 // entry); 0: probs are left ungated for launch_gate

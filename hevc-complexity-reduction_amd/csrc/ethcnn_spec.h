@@ -27,6 +27,17 @@ static_assert((long long)kMaxCtusPerPass * kNVec * 4 < (1ll << 31), "FC1 / heads
 static_assert((long long)kMaxCtusPerPass * kNOut * 4 < (1ll << 31), "heads / gate: probability byte offsets must fit int32");
 static_assert(2 * kMaxCtusPerPass < (1 << 24), "gate_chunk: r0 + ctu must be exact in float");
 
+// ---- FC1 plan 1 ("fast": exact three-way bf16 split on the bf16 matrix pipe, ethcnn_fc1_fast.hip).
+// Features of the plan: every fp32 feature as three bf16 pieces (a = a0 + a1 + a2 exactly), in v_mfma_f32_32x32x16_bf16
+// A-operand order: featb[pair of groups = 32 CTUs][chunk of 16 k: 168][piece: 3][1 KiB = [k half: 2][row: 32][8 bf16]].
+// Which feature sits in (chunk, k half, slot) is fast_feature_k below: the order in which the trunk's registers hold them.
+constexpr int kFastChunks = kNFeat / 16;                     // 168 K chunks of 16
+constexpr int kFastPairBytes = kFastChunks * 3 * 1024;       // one pair of groups: 504 KiB (= 32 CTUs x 2688 x 6 B)
+static_assert((long long)(kMaxCtusPerPass / 32) * kFastPairBytes < (1ll << 31), "trunk / FC1 plan 1: pair image byte offset must fit int32");
+// feature index held by slot `idx` (0..7) of k half `kh` of chunk `c`: chunk = 8 T + 2 p + (g >> 1), kh = g & 1 for trunk task T
+// (unit position inside the group: 16 S, 4 M, 1 L), register pair p of the task and MFMA k-group g; slots 0..3 / 4..7 = the two quads of the pair
+int fast_feature_k(int chunk, int kh, int idx);
+
 // branches in feature order S, M, L (net_CNN.py:150 concat order)
 enum Branch { kS = 0, kM = 1, kL = 2 };
 
@@ -108,6 +119,9 @@ struct DeviceWeights {
     // the same weights in MFMA-operand order per 16-column tile: [28 tiles][168 sub-chunks of 16 k][64 lanes][4]: lane (col, g)
     // holds W1[16 u + 4 g + e][16 t + col], e = 0..3 -- one dwordx4 load per lane per sub-chunk, no LDS (single-launch pass)
     float* fc1_lane16 = nullptr;
+    // FC1 plan 1: W1 as three bf16 pieces in v_mfma_f32_32x32x16_bf16 B-operand order, [168 chunks][14 column tiles of 32][3 pieces]
+    // [1 KiB = [k half][32 columns][8 bf16]], k order = fast_feature_k (pack_fc1_fast_image)
+    uint16_t* fc1_fast = nullptr;
     float* fc1_b = nullptr;    // [448]
     float* fc2_w[3] = {nullptr, nullptr, nullptr};  // [n1+1][n2] (last row = qp row)
     float* fc2_b[3] = {nullptr, nullptr, nullptr};
@@ -123,6 +137,8 @@ void pack_trunk_fragments(const float* blob, float* w_out /*[3][84][64]*/, float
 void pack_fc1(const float* blob, float* w_out /*[2688][448]*/, float* b_out /*[448]*/);
 void pack_fc1_image(const float* w_cat /*[2688][448]*/, int bn, int bk, float* img_out /*[2688*448]*/);
 void pack_fc1_lane_image(const float* w_cat /*[2688][448]*/, float* img_out /*[2688*448]*/);
+void pack_fc1_fast_image(const float* w_cat /*[2688][448]*/, uint16_t* img_out /*[2688*448*3]*/);
+void split_bf16x3(float x, uint16_t* p0, uint16_t* p1, uint16_t* p2);  // exact: x = p0 + p1 + p2, round to nearest even at each step
 void pack_fc2_lane_image(const float* w2 /*[n1+1][n2]*/, int n1, int n2, float* img_out /*[n1*n2]*/);
 void synth_blob(uint64_t seed, double head_gain, float* blob_out /*[kBlobFloats]*/);
 void synth_lstm_blob(uint64_t seed, double head_gain, float* blob_out /*[kLstmBlobFloats]*/);

@@ -214,6 +214,64 @@ void pack_fc1_lane_image(const float* w_cat, float* img) {
                 }
 }
 
+// ---- FC1 plan 1 (ethcnn_fc1_fast.hip): feature order and weight image of the bf16 x 3 form.
+// The trunk wave of task T (ethcnn_trunk_task.h; lane = col + 16 g) ends up holding eight full quads of features in registers:
+//   n = 0..3  conv2 position q2 = n, channels 4 g + e           k = OFF2 + slot(q2) * 24 + 4 g + e
+//   n = 4, 5  conv2 channels 16..23 of positions 2 j, 2 j + 1   k = OFF2 + slot(2 j + (g >> 1)) * 24 + 16 + 4 (g & 1) + e   (j = n - 4)
+//   n = 6, 7  conv3 channels 16 t + 4 g + e                     k = OFF3 + unit * 32 + 16 t + 4 g + e                       (t = n - 6)
+// with slot(q2) = (2 by + (q2 >> 1)) * (2 NB) + 2 bx + (q2 & 1), unit = by * NB + bx.  Quads (2 p, 2 p + 1) form register pair p:
+// its lanes g = 0, 1 / 2, 3 fill the two k halves of chunks 8 T + 2 p / 8 T + 2 p + 1.
+int fast_feature_k(int chunk, int kh, int idx) {
+    const int T = chunk >> 3, p = (chunk >> 1) & 3, g = 2 * (chunk & 1) + kh;
+    const int n = 2 * p + (idx >> 2), e = idx & 3;
+    int br, by, bx;
+    if (T < 16) { br = 0; by = T >> 2; bx = T & 3; }
+    else if (T < 20) { br = 1; by = ((T - 16) >> 1) & 1; bx = (T - 16) & 1; }
+    else { br = 2; by = bx = 0; }
+    const int nb = kNb[br];
+    auto slot = [&](int q2) { return (2 * by + (q2 >> 1)) * (2 * nb) + 2 * bx + (q2 & 1); };
+    if (n < 4) return kOff2[br] + slot(n) * 24 + 4 * g + e;
+    if (n < 6) return kOff2[br] + slot(2 * (n - 4) + (g >> 1)) * 24 + 16 + 4 * (g & 1) + e;
+    return kOff3[br] + (by * nb + bx) * 32 + 16 * (n - 6) + 4 * g + e;
+}
+
+static inline uint16_t bf16_rne(float x) {  // fp32 -> bf16, round to nearest even (what v_cvt_pk_bf16_f32 does for finite values)
+    uint32_t u;
+    std::memcpy(&u, &x, 4);
+    if ((u & 0x7f800000u) == 0x7f800000u) return (uint16_t)(u >> 16);  // inf / nan: truncate (not produced by finite weights)
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float bf16_f32(uint16_t h) {
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+void split_bf16x3(float x, uint16_t* p0, uint16_t* p1, uint16_t* p2) {
+    *p0 = bf16_rne(x);
+    const float r1 = x - bf16_f32(*p0);  // exact (Sterbenz-like: the rounding error of an 8-bit rounding is representable)
+    *p1 = bf16_rne(r1);
+    const float r2 = r1 - bf16_f32(*p1);
+    *p2 = bf16_rne(r2);                  // exact: at most 8 significant bits are left
+}
+
+void pack_fc1_fast_image(const float* w_cat, uint16_t* img) {
+    for (int c = 0; c < kFastChunks; ++c)
+        for (int t = 0; t < kNVec / 32; ++t) {
+            uint16_t* rec = img + ((size_t)c * (kNVec / 32) + t) * 3 * 512;  // three 1 KiB pieces
+            for (int lane = 0; lane < 64; ++lane) {
+                const int n = lane & 31, kh = lane >> 5;
+                for (int idx = 0; idx < 8; ++idx) {
+                    const float w = w_cat[(size_t)fast_feature_k(c, kh, idx) * kNVec + 32 * t + n];
+                    uint16_t p[3];
+                    split_bf16x3(w, &p[0], &p[1], &p[2]);
+                    for (int q = 0; q < 3; ++q) rec[q * 512 + lane * 8 + idx] = p[q];
+                }
+            }
+        }
+}
+
 void pack_fc2_lane_image(const float* w2, int n1, int n2, float* img) {
     for (int j = 0; j < n2 / 16; ++j)
         for (int kc = 0; kc < n1 / 16; ++kc)

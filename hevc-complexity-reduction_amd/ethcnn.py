@@ -65,6 +65,8 @@ SIGNATURES = {
     "ethcnn_set_pass_pipeline": (_i, [_vp, _i]),
     "ethcnn_set_fused_launch": (_i, [_vp, _i]),
     "ethcnn_set_small_pass_launch": (_i, [_vp, _i]),
+    "ethcnn_set_fc1_plan": (_i, [_vp, _i]),
+    "ethcnn_get_fc1_plan": (_i, [_vp]),
     "ethcnn_measure_mfma_rate": (_i, [_vp, ctypes.c_double, ctypes.POINTER(ctypes.c_double)]),
     "ethcnn_ldp_step": (_i, [_vp, _vp, _i, _i, _pd, _i, _i, _vp, _fp]),
     "ethcnn_ldp_get_state": (_i, [_vp, _fp, _sz]),
@@ -471,8 +473,16 @@ class EthCnn(object):
         self._chk(self.lib.ethcnn_measure_mfma_rate(self.h, float(seconds), ctypes.byref(v)))
         return v.value
 
+    def set_fc1_plan(self, plan=1):
+        """FC1 plan: 0 = exact fp32 (default, bit-identical to the oracle); 1 = exact three-way bf16 splits on the bf16 matrix
+        pipe for passes that take the multi-launch path (as accurate against float64, NOT bit-identical; include/ethcnn.h)."""
+        self._chk(self.lib.ethcnn_set_fc1_plan(self.h, int(plan)))
+
+    def fc1_plan(self):
+        return int(self.lib.ethcnn_get_fc1_plan(self.h))
+
     def set_small_pass_launch(self, on=True):
-        """one picture (<= 8192 CTUs, 16-byte aligned rows) as ONE launch (default on); off = five launches.  Same results."""
+        """one picture (<= 2304 CTUs, 16-byte aligned rows) as ONE launch (default on); off = five launches.  Same results."""
         self._chk(self.lib.ethcnn_set_small_pass_launch(self.h, 1 if on else 0))
 
     def reset_stage_times(self):
