@@ -173,6 +173,34 @@ __global__ __launch_bounds__(64) void k_num(const float* A, const float* B, int 
     if (bad) atomicAdd(split_bad, bad);
 }
 
+// fp16 x 2: a = (a0 + a1) 2^-sa with a0 = fp16(a 2^sa), a1 = fp16(a 2^sa - a0) (an 11-bit significand each: 2^-24 relative when a1 is a
+// normal number); products a0 b0, a0 b1, a1 b0 (nprod 3) or also a1 b1 (nprod 4) on v_mfma_f32_32x32x16_f16; result scaled back by 2^-(sa + sb)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(64) void k_num_f16(const float* A, const float* B, int K, int nprod, float sa, float sb, float* out) {
+    const int lane = threadIdx.x;
+    f32x16 acc;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int rc = lane & 31, kh = lane >> 5;
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        f16x8 fa[2], fb[2];
+        for (int i = 0; i < 8; ++i) {
+            const float av = A[(size_t)rc * K + k0 + 8 * kh + i] * sa, bv = B[(size_t)(k0 + 8 * kh + i) * 32 + rc] * sb;
+            const _Float16 a0 = (_Float16)av, b0 = (_Float16)bv;
+            fa[0][i] = a0; fa[1][i] = (_Float16)(av - (float)a0);
+            fb[0][i] = b0; fb[1][i] = (_Float16)(bv - (float)b0);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0], fb[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[1], fb[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0], fb[1], acc, 0, 0, 0);
+        if (nprod == 4) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[1], fb[1], acc, 0, 0, 0);
+    }
+    const float inv = 1.0f / (sa * sb);
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = lane & 31;
+        out[row * 32 + col] = acc[r] * inv;
+    }
+}
+
 static uint64_t sm64(uint64_t& s) {
     uint64_t z = (s += 0x9E3779B97F4A7C15ull);
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -268,6 +296,21 @@ int main() {
                 hipMemcpy(&bad, dbad, 4, hipMemcpyDeviceToHost);
                 char name[96];
                 snprintf(name, sizeof name, "bf16x%d %s order %d (split bad %d)", order == 3 ? 2 : 3, shape == 0 ? "32x32x16" : "16x16x32", order, bad);
+                report(name, got.data());
+            }
+        // fp16 x 2 at several operand scales: amax * sa = 2^14 is "just below overflow"; each factor 2^-4 pushes more low pieces into fp16's
+        // subnormal range (absolute precision 2^-25 there)
+        float amax = 0.f, bmax = 0.f;
+        for (float v : A) amax = std::max(amax, std::fabs(v));
+        for (float v : B) bmax = std::max(bmax, std::fabs(v));
+        for (int down = 0; down <= 12; down += 4)
+            for (int nprod = 3; nprod <= 4; ++nprod) {
+                const float sa = std::exp2f(14 - down - std::ceil(std::log2(amax))), sb = std::exp2f(14 - down - std::ceil(std::log2(bmax)));
+                hipLaunchKernelGGL(k_num_f16, dim3(1), dim3(64), 0, 0, dA, dB, K, nprod, sa, sb, dO);
+                hipDeviceSynchronize();
+                hipMemcpy(got.data(), dO, 1024 * 4, hipMemcpyDeviceToHost);
+                char name[96];
+                snprintf(name, sizeof name, "fp16x2 %d products, max scaled to 2^%d", nprod, 14 - down);
                 report(name, got.data());
             }
         hipFree(dA);
