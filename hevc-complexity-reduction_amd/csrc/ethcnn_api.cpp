@@ -189,10 +189,10 @@ struct ethcnn_ctx {
     int ssync_cap = 0;       // in ints
     bool ssync_clean = false;
     int small_epoch = 0;     // claim tag of the last single-launch pass (1 .. 2^30, wraps: the area is re-zeroed then)
-    int fc1_plan = 0;        // 0 = exact fp32 FC1 (default; bit-identical to the oracle); 1 = "fast": FC1 of the multi-launch path as exact
-                             // three-way bf16 splits on the bf16 matrix pipe (ethcnn_fc1_fast.hip; ethcnn_set_fc1_plan, env ETHCNN_FC1_PLAN=1)
-    uint16_t* dw_fast = nullptr;  // W1 in plan 1's form (packed on first use), 7.2 MB
-    bool last_fast = false;  // the last pass ran plan 1 (debug_fetch reads its features from ws.featb)
+    int fc1_plan = 0;        // 0 = exact fp32 FC1 (default; bit-identical to the oracle); 1 / 2 = "fast": FC1 of the multi-launch path on the
+                             // 16-bit matrix pipe with split operands, bf16 x 3 / fp16 x 2 (ethcnn_fc1_fast.hip; ethcnn_set_fc1_plan, env ETHCNN_FC1_PLAN)
+    uint16_t* dw_fast[2] = {nullptr, nullptr};  // W1 in the form of plan 1 / 2 (packed on first use), 7.2 / 4.8 MB
+    int last_fast = 0;       // the FC1 plan of the last pass (debug_fetch reads the features of plans 1 / 2 from ws.featb)
     int fused = 0;           // 1 = big passes run FC1 + heads + gates as ONE launch (ethcnn_set_fused_launch, env ETHCNN_FUSED=1).
                              // Off by default: measured equal-to-1 % slower than the separate launches
     // completion word (page-locked host memory): the last block of a latency-path launch stores the launch's sequence number
@@ -302,7 +302,7 @@ static int ensure_workspace(ethcnn_ctx* c, int n, int chunks) {
         HIPCHK(c, hipMalloc((void**)&c->h1_1, (size_t)cap * kNVec * 4));
         w.cap = cap;
     }
-    if (c->fc1_plan == 1 && !w.featb)  // plan 1: the features as bf16 x 3 pieces, 16,128 B per CTU (ethcnn_spec.h)
+    if (c->fc1_plan != 0 && !w.featb)  // plans 1 / 2: the features as 16-bit pieces, up to 16,128 B per CTU (ethcnn_spec.h)
         HIPCHK(c, hipMalloc((void**)&w.featb, (size_t)((w.cap + 31) / 32) * kFastPairBytes));
     const int words = sync_words(std::max(n, w.cap), chunks);
     if (words > w.flags_cap) {
@@ -358,7 +358,10 @@ extern "C" int ethcnn_create(ethcnn_ctx** out, const ethcnn_options* opt) {
     }
     if (const char* e = std::getenv("ETHCNN_OVERLAP")) c->overlap = std::atoi(e) != 0;  // development knob (A/B runs)
     if (const char* e = std::getenv("ETHCNN_SMALL")) c->small_launch = std::atoi(e) != 0;  // development knob (A/B runs)
-    if (const char* e = std::getenv("ETHCNN_FC1_PLAN")) c->fc1_plan = std::atoi(e) == 1;  // user-facing: start contexts in FC1 plan 1
+    if (const char* e = std::getenv("ETHCNN_FC1_PLAN")) {  // user-facing: start contexts in FC1 plan 1 / 2
+        const int pl = std::atoi(e);
+        c->fc1_plan = (pl == 1 || pl == 2) ? pl : 0;
+    }
     if (const char* e = std::getenv("ETHCNN_FUSED")) c->fused = std::atoi(e) != 0;      // development knob (A/B runs)
     if (const char* e = std::getenv("ETHCNN_GATE_FOLD")) c->gate_fold = std::atoi(e) != 0;  // development knob (A/B runs)
     if (const char* e = std::getenv("ETHCNN_DONE_WORD")) c->done_sync = std::atoi(e) != 0;  // development knob (A/B runs)
@@ -451,7 +454,8 @@ extern "C" void ethcnn_destroy(ethcnn_ctx* c) {
     for (const auto& r : c->pinned) (void)hipHostFree(const_cast<char*>(r.first));  // ethcnn_host_alloc buffers die with the context
     delete c->pool;
     if (c->dw_arena) (void)hipFree(c->dw_arena);
-    if (c->dw_fast) (void)hipFree(c->dw_fast);
+    for (uint16_t* q : c->dw_fast)
+        if (q) (void)hipFree(q);
     {
         void* lp[] = {c->d_lstm, c->d_vec, c->d_state[0], c->d_state[1], c->d_lprobs, c->d_lgate, c->d_ssync};
         for (void* p : lp)
@@ -529,32 +533,45 @@ static int upload_weights(ethcnn_ctx* c) {
         d.fc3_w[h] = c->dw_arena + offs[10 + 2 * h];
         d.fc3_b[h] = c->dw_arena + offs[11 + 2 * h];
     }
-    d.fc1_fast = nullptr;  // plan 1's image of W1 belongs to the previous weights: repacked on the next plan-1 pass
+    d.fc1_fast[0] = d.fc1_fast[1] = nullptr;  // the fast plans' images of W1 belong to the previous weights: repacked on the next such pass
     c->have_weights = true;
     return ETHCNN_OK;
 }
 
-// plan 1: W1 as three bf16 pieces in the bf16 MFMA's B-operand order (ethcnn_weights.cpp::pack_fc1_fast_image), once per weight load
-static int ensure_fast_weights(ethcnn_ctx* c) {
-    if (c->dw.fc1_fast) return 0;
-    const size_t n16 = (size_t)kNFeat * kNVec * 3;
+// plans 1 / 2: W1 as 16-bit pieces in the MFMA's B-operand order (ethcnn_weights.cpp::pack_fc1_fast_image), once per weight load
+static int ensure_fast_weights(ethcnn_ctx* c, int plan) {
+    if (c->dw.fc1_fast[plan - 1]) return 0;
+    const size_t n16 = (size_t)kNFeat * kNVec * fast_pieces(plan);
     std::vector<float> wcat((size_t)kNFeat * kNVec), b1(kNVec);
     pack_fc1(c->blob.data(), wcat.data(), b1.data());
-    {   // the feature order of the plan is a table of the trunk's register order: it must be a permutation of 0 .. 2687
+    {   // the feature order of the plans is a table of the trunk's register order: it must be a permutation of 0 .. 2687
         std::vector<char> seen(kNFeat, 0);
         for (int ch = 0; ch < kFastChunks; ++ch)
             for (int s8 = 0; s8 < 16; ++s8) {
                 const int k = fast_feature_k(ch, s8 >> 3, s8 & 7);
-                if (k < 0 || k >= kNFeat || seen[k]) return set_err(c, ETHCNN_ERR_ARG, "internal: FC1 plan 1 feature order is not a permutation (chunk %d)", ch);
+                if (k < 0 || k >= kNFeat || seen[k]) return set_err(c, ETHCNN_ERR_ARG, "internal: fast FC1 feature order is not a permutation (chunk %d)", ch);
                 seen[k] = 1;
             }
     }
+    float sw = 1.0f;
+    if (plan == 2) {
+        // powers of two that put the largest possible |feature| and the largest |weight| at <= 2^14 (fp16 overflows at 65504): the
+        // feature bound is a guarantee derived from the conv weights (|input| <= 1), not an observation
+        float wmax = 0.0f;
+        for (float v : wcat) wmax = std::max(wmax, std::fabs(v));
+        const float fmax = fast_feature_bound(c->blob.data());
+        if (!(wmax > 0.0f) || !(fmax > 0.0f) || !std::isfinite(wmax) || !std::isfinite(fmax))
+            return set_err(c, ETHCNN_ERR_ARG, "FC1 plan 2 needs finite, non-zero weights (max |W1| %g, feature bound %g)", (double)wmax, (double)fmax);
+        sw = std::exp2f(14.0f - std::ceil(std::log2(wmax)));
+        c->dw.fast_scale_w = sw;
+        c->dw.fast_scale_a = std::exp2f(14.0f - std::ceil(std::log2(fmax)));
+    }
     std::vector<uint16_t> img(n16);
-    pack_fc1_fast_image(wcat.data(), img.data());
-    if (!c->dw_fast) HIPCHK(c, hipMalloc((void**)&c->dw_fast, n16 * 2));
+    pack_fc1_fast_image(wcat.data(), plan, sw, img.data());
+    if (!c->dw_fast[plan - 1]) HIPCHK(c, hipMalloc((void**)&c->dw_fast[plan - 1], n16 * 2));
     HIPCHK(c, hipDeviceSynchronize());
-    HIPCHK(c, hipMemcpy(c->dw_fast, img.data(), n16 * 2, hipMemcpyHostToDevice));
-    c->dw.fc1_fast = c->dw_fast;
+    HIPCHK(c, hipMemcpy(c->dw_fast[plan - 1], img.data(), n16 * 2, hipMemcpyHostToDevice));
+    c->dw.fc1_fast[plan - 1] = c->dw_fast[plan - 1];
     return 0;
 }
 
@@ -696,7 +713,7 @@ extern "C" int ethcnn_set_fused_launch(ethcnn_ctx* c, int on) {
 
 extern "C" int ethcnn_set_fc1_plan(ethcnn_ctx* c, int plan) {
     if (!c) return ETHCNN_ERR_ARG;
-    if (plan != 0 && plan != 1) return set_err(c, ETHCNN_ERR_ARG, "FC1 plan must be 0 (exact fp32, default) or 1 (bf16 x 3 split), got %d", plan);
+    if (plan < 0 || plan > 2) return set_err(c, ETHCNN_ERR_ARG, "FC1 plan must be 0 (exact fp32, default), 1 (bf16 x 3 split) or 2 (fp16 x 2 split), got %d", plan);
     c->fc1_plan = plan;  // takes effect with the next pass enqueued
     return ETHCNN_OK;
 }
@@ -830,7 +847,7 @@ static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, lo
         c->times.ctus += n;
         c->last_n = n;
         c->last_parity = p;
-        c->last_fast = false;  // (the single-launch pass always computes FC1 exactly)
+        c->last_fast = 0;  // (the single-launch pass always computes FC1 exactly)
         return 0;
     }
     if (side_tile) {
@@ -862,16 +879,16 @@ static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, lo
         HIPCHK(c, hipEventRecord(c->e_tile[p], s_tile));
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->e_tile[p], 0));
     }
-    const bool fast = c->fc1_plan == 1;  // FC1 plan 1: trunk -> bf16 x 3 feature pieces -> FC1 on the bf16 matrix pipe
-    if (fast && (rc = ensure_fast_weights(c)) != 0) return rc;
+    const int fast = c->fc1_plan;  // FC1 plans 1 / 2: trunk -> 16-bit feature pieces -> FC1 on the 16-bit matrix pipe
+    if (fast && (rc = ensure_fast_weights(c, fast)) != 0) return rc;
     { StageTimer t(c, ETHCNN_STAGE_TRUNK); launch_trunk(w, c->dw, n, false, c->stream, fast); }
     LAUNCH_OK("trunk");
     if (side_tile) HIPCHK(c, hipEventRecord(c->e_trunk[p], c->stream));
     Workspace wv = w;
     if (!c->debug_capture) wv.h2 = wv.logits = wv.raw = nullptr;
     if (fast) {
-        { StageTimer t(c, ETHCNN_STAGE_FC1, n); launch_fc1_fast(w, c->dw, n, w.h1, c->stream); }
-        LAUNCH_OK("FC1 (plan 1)");
+        { StageTimer t(c, ETHCNN_STAGE_FC1, n); launch_fc1_fast(w, c->dw, n, w.h1, fast, c->stream); }
+        LAUNCH_OK("FC1 (plan 1 / 2)");
         { StageTimer t(c, ETHCNN_STAGE_HEADS); launch_heads(wv, c->dw, n, qn, g.nctu, ctu0, c->thr1, c->thr2, d_probs_pass, c->stream, c->gate_fold ? (int)nchunks : 0); }
         if (!c->gate_fold) { StageTimer t(c, ETHCNN_STAGE_GATE); launch_gate(w, n, g.nctu, ctu0, c->thr2, d_probs_pass, c->stream); }
         LAUNCH_OK("heads / gate");
@@ -1641,20 +1658,24 @@ extern "C" int ethcnn_debug_fetch(ethcnn_ctx* c, int which, float* out, size_t n
     if (!src || nfloats > (size_t)c->last_n * per) return set_err(c, ETHCNN_ERR_ARG, "debug_fetch: last pass had %d CTUs", c->last_n);
     if (which != ETHCNN_DBG_FEATURES) return ethcnn_memcpy_d2h(c, out, src, nfloats * 4);
     if (c->last_fast) {
-        // plan 1: the trunk left every feature as three bf16 pieces whose sum IS the feature (exact split): add them back
+        // plans 1 / 2: the trunk left every feature as 16-bit pieces: add them back (plan 1: the sum IS the feature, the split is
+        // exact; plan 2: (h0 + h1) / scale, equal to the feature to 2^-24 relative)
+        const int plan = c->last_fast, np = fast_pieces(plan);
         const size_t n = (nfloats + kNFeat - 1) / kNFeat, pairs = (n + 31) / 32;
-        std::vector<uint16_t> rawb(pairs * (kFastPairBytes / 2));
+        std::vector<uint16_t> rawb(pairs * (size_t)(fast_pair_bytes(plan) / 2));
         int rc = ethcnn_memcpy_d2h(c, rawb.data(), c->ws.featb, rawb.size() * 2);
         if (rc) return rc;
-        auto f32 = [](uint16_t h) { const uint32_t u = (uint32_t)h << 16; float f; std::memcpy(&f, &u, 4); return f; };
+        auto bf = [](uint16_t h) { const uint32_t u = (uint32_t)h << 16; float f; std::memcpy(&f, &u, 4); return f; };
+        auto hf = [](uint16_t h) { return f16_f32(h); };
+        const float inv = 1.0f / c->dw.fast_scale_a;
         for (size_t row = 0; row * kNFeat < nfloats; ++row)
             for (int ch = 0; ch < kFastChunks; ++ch)
                 for (int kh = 0; kh < 2; ++kh)
                     for (int idx = 0; idx < 8; ++idx) {
                         const size_t o = row * kNFeat + (size_t)fast_feature_k(ch, kh, idx);
                         if (o >= nfloats) continue;
-                        const uint16_t* rec = rawb.data() + ((row / 32) * kFastChunks + ch) * 3 * 512 + (kh * 32 + row % 32) * 8 + idx;
-                        out[o] = (f32(rec[0]) + f32(rec[512])) + f32(rec[1024]);
+                        const uint16_t* rec = rawb.data() + ((row / 32) * kFastChunks + ch) * np * 512 + (kh * 32 + row % 32) * 8 + idx;
+                        out[o] = plan == 1 ? (bf(rec[0]) + bf(rec[512])) + bf(rec[1024]) : (hf(rec[0]) + hf(rec[512])) * inv;
                     }
         return ETHCNN_OK;
     }

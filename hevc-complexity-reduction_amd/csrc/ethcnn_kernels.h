@@ -33,13 +33,14 @@ struct FrameGeom {
 // max_blocks > 0: slab-staged persistent form with at most that many blocks (one per CU when it runs beside FC1)
 void launch_tile(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, const Workspace& ws, int n_flags,
                  hipStream_t s, int max_blocks = 0);
-// k1: xs/xm/xl -> feat (fast: -> featb, every feature as three bf16 pieces in the bf16 MFMA's operand order, FC1 plan 1)
-void launch_trunk(const Workspace& ws, const DeviceWeights& w, int n, bool resi, hipStream_t s, bool fast = false);
+// k1: xs/xm/xl -> feat (fc1_plan 1 / 2: -> featb, every feature as three bf16 / two fp16 pieces in the 16-bit MFMA's operand order)
+void launch_trunk(const Workspace& ws, const DeviceWeights& w, int n, bool resi, hipStream_t s, int fc1_plan = 0);
 // k2: feat -> h1 (bias + leaky-ReLU fused); out may be ws.h1 or a caller buffer (resi vectors)
 void launch_fc1(const Workspace& ws, const DeviceWeights& w, int n, float* out, hipStream_t s);
-// k2, plan 1 (ethcnn_fc1_fast.hip): featb -> h1 on the bf16 matrix pipe: six bf16 products per fp32 product (exact three-way
-// splits of both operands, terms i + j <= 2), fp32 accumulate; same bias + leaky-ReLU epilogue, same h1 layout
-void launch_fc1_fast(const Workspace& ws, const DeviceWeights& w, int n, float* out, hipStream_t s);
+// k2, plans 1 / 2 (ethcnn_fc1_fast.hip): featb -> h1 on the 16-bit matrix pipe: six bf16 products per fp32 product (exact three-way
+// splits of both operands, terms i + j <= 2) or three fp16 products (two-way splits of the scaled operands), fp32 accumulate; same
+// bias + leaky-ReLU epilogue, same h1 layout
+void launch_fc1_fast(const Workspace& ws, const DeviceWeights& w, int n, float* out, int plan, hipStream_t s);
 // k3+k4 fused: h1 -> h2 -> logits, raw probs, probs and per-chunk gate flags.  gate_nchunks > 0: the batch gates are applied
 // inside the launch (ws.flags = sync area: arrival counters behind the 2 * gate_nchunks predicates, zero on
 // entry); 0: probs are left ungated for launch_gate

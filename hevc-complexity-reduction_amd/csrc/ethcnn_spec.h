@@ -27,16 +27,63 @@ static_assert((long long)kMaxCtusPerPass * kNVec * 4 < (1ll << 31), "FC1 / heads
 static_assert((long long)kMaxCtusPerPass * kNOut * 4 < (1ll << 31), "heads / gate: probability byte offsets must fit int32");
 static_assert(2 * kMaxCtusPerPass < (1 << 24), "gate_chunk: r0 + ctu must be exact in float");
 
-// ---- FC1 plan 1 ("fast": exact three-way bf16 split on the bf16 matrix pipe, ethcnn_fc1_fast.hip).
-// Features of the plan: every fp32 feature as three bf16 pieces (a = a0 + a1 + a2 exactly), in v_mfma_f32_32x32x16_bf16
-// A-operand order: featb[pair of groups = 32 CTUs][chunk of 16 k: 168][piece: 3][1 KiB = [k half: 2][row: 32][8 bf16]].
+// ---- FC1 plans 1 and 2 ("fast": split operands on the 16-bit matrix pipe, ethcnn_fc1_fast.hip).
+//   plan 1: every fp32 feature / weight as THREE bf16 pieces, a = a0 + a1 + a2 exactly; six products (i + j <= 2)
+//   plan 2: every fp32 feature / weight, scaled by a power of two, as TWO fp16 pieces, a 2^s = a0 + a1 to 2^-24 relative
+//           (two 11-bit significands, round to nearest even); three products (a0 w0, a1 w0, a0 w1)
+// Features of a plan with NP pieces, in v_mfma_f32_32x32x16_{bf16,f16} A-operand order:
+//   featb[pair of groups = 32 CTUs][chunk of 16 k: 168][piece: NP][1 KiB = [k half: 2][row: 32][8 x 16 bit]].
 // Which feature sits in (chunk, k half, slot) is fast_feature_k below: the order in which the trunk's registers hold them.
 constexpr int kFastChunks = kNFeat / 16;                     // 168 K chunks of 16
-constexpr int kFastPairBytes = kFastChunks * 3 * 1024;       // one pair of groups: 504 KiB (= 32 CTUs x 2688 x 6 B)
-static_assert((long long)(kMaxCtusPerPass / 32) * kFastPairBytes < (1ll << 31), "trunk / FC1 plan 1: pair image byte offset must fit int32");
+constexpr int fast_pieces(int plan) { return plan == 1 ? 3 : 2; }
+constexpr int fast_pair_bytes(int plan) { return kFastChunks * fast_pieces(plan) * 1024; }  // 504 KiB / 336 KiB per 32 CTUs
+constexpr int kFastPairBytes = fast_pair_bytes(1);           // the workspace is sized for the larger form
+static_assert((long long)(kMaxCtusPerPass / 32) * kFastPairBytes < (1ll << 31), "trunk / FC1 fast plans: pair image byte offset must fit int32");
 // feature index held by slot `idx` (0..7) of k half `kh` of chunk `c`: chunk = 8 T + 2 p + (g >> 1), kh = g & 1 for trunk task T
 // (unit position inside the group: 16 S, 4 M, 1 L), register pair p of the task and MFMA k-group g; slots 0..3 / 4..7 = the two quads of the pair
 int fast_feature_k(int chunk, int kh, int idx);
+// plan 2: a bound no feature of an All-Intra CTU can exceed (|input| <= 1 after mean removal; per-channel bounds pushed through
+// the three conv layers of every branch) -- the feature scale 2^s is chosen from it so that no fp16 piece can overflow
+float fast_feature_bound(const float* blob);
+// fp32 <-> IEEE binary16 on the host (round to nearest even, subnormals kept: what v_cvt_pk_f16_f32 / v_cvt_f32_f16 do on the device)
+inline uint16_t f16_rne(float x) {
+    uint32_t u;
+    __builtin_memcpy(&u, &x, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u, e = (u >> 23) & 0xffu;
+    uint32_t m = u & 0x7fffffu;
+    if (e == 0xffu) return (uint16_t)(sign | 0x7c00u | (m ? 0x200u : 0u));
+    const int E = (int)e - 127 + 15;
+    if (E >= 31) return (uint16_t)(sign | 0x7c00u);
+    if (E <= 0) {
+        if (E < -10) return (uint16_t)sign;
+        m |= 0x800000u;
+        const int shift = 14 - E;  // 14 .. 24
+        uint32_t half = m >> shift;
+        const uint32_t rem = m & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
+        if (rem > halfway || (rem == halfway && (half & 1u))) ++half;
+        return (uint16_t)(sign | half);
+    }
+    uint32_t half = ((uint32_t)E << 10) | (m >> 13);
+    const uint32_t rem = m & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (half & 1u))) ++half;
+    return (uint16_t)(sign | half);
+}
+inline float f16_f32(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+    uint32_t u;
+    if (e == 0) {
+        const float f = (float)m * 5.9604644775390625e-08f;  // m 2^-24, exact
+        __builtin_memcpy(&u, &f, 4);
+        u |= sign;
+    } else if (e == 31) {
+        u = sign | 0x7f800000u | (m << 13);
+    } else {
+        u = sign | ((e + 112u) << 23) | (m << 13);
+    }
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+}
 
 // branches in feature order S, M, L (net_CNN.py:150 concat order)
 enum Branch { kS = 0, kM = 1, kL = 2 };
@@ -119,9 +166,10 @@ struct DeviceWeights {
     // the same weights in MFMA-operand order per 16-column tile: [28 tiles][168 sub-chunks of 16 k][64 lanes][4]: lane (col, g)
     // holds W1[16 u + 4 g + e][16 t + col], e = 0..3 -- one dwordx4 load per lane per sub-chunk, no LDS (single-launch pass)
     float* fc1_lane16 = nullptr;
-    // FC1 plan 1: W1 as three bf16 pieces in v_mfma_f32_32x32x16_bf16 B-operand order, [168 chunks][14 column tiles of 32][3 pieces]
-    // [1 KiB = [k half][32 columns][8 bf16]], k order = fast_feature_k (pack_fc1_fast_image)
-    uint16_t* fc1_fast = nullptr;
+    // FC1 plans 1 / 2: W1 as NP 16-bit pieces in the 32x32x16 MFMA's B-operand order, [168 chunks][14 column tiles of 32][NP pieces]
+    // [1 KiB = [k half][32 columns][8]], k order = fast_feature_k (pack_fc1_fast_image); index = plan - 1
+    uint16_t* fc1_fast[2] = {nullptr, nullptr};
+    float fast_scale_a = 1.0f, fast_scale_w = 1.0f;  // plan 2: powers of two applied to features / W1 before the fp16 split
     float* fc1_b = nullptr;    // [448]
     float* fc2_w[3] = {nullptr, nullptr, nullptr};  // [n1+1][n2] (last row = qp row)
     float* fc2_b[3] = {nullptr, nullptr, nullptr};
@@ -137,7 +185,7 @@ void pack_trunk_fragments(const float* blob, float* w_out /*[3][84][64]*/, float
 void pack_fc1(const float* blob, float* w_out /*[2688][448]*/, float* b_out /*[448]*/);
 void pack_fc1_image(const float* w_cat /*[2688][448]*/, int bn, int bk, float* img_out /*[2688*448]*/);
 void pack_fc1_lane_image(const float* w_cat /*[2688][448]*/, float* img_out /*[2688*448]*/);
-void pack_fc1_fast_image(const float* w_cat /*[2688][448]*/, uint16_t* img_out /*[2688*448*3]*/);
+void pack_fc1_fast_image(const float* w_cat /*[2688][448]*/, int plan, float scale_w, uint16_t* img_out /*[2688*448*NP]*/);
 void split_bf16x3(float x, uint16_t* p0, uint16_t* p1, uint16_t* p2);  // exact: x = p0 + p1 + p2, round to nearest even at each step
 void pack_fc2_lane_image(const float* w2 /*[n1+1][n2]*/, int n1, int n2, float* img_out /*[n1*n2]*/);
 void synth_blob(uint64_t seed, double head_gain, float* blob_out /*[kBlobFloats]*/);

@@ -31,11 +31,11 @@
 
 namespace ethcnn {
 
-template <bool RESI, bool FAST = false>
+template <bool RESI, int FAST = 0>
 __global__ __launch_bounds__(256) void k1_trunk(const uint4* __restrict__ XS, const uint4* __restrict__ XM,
                                                 const uint4* __restrict__ XL, int N, int bS, int bM,
                                                 const float* __restrict__ wfrag, const float* __restrict__ bfrag,
-                                                float* __restrict__ F) {
+                                                float* __restrict__ F, float fscale) {
     __shared__ float wl[RESI ? kTrunkResiLds : kTrunkWFrags * 64];  // this block's branch: 84 A-operand fragments, 21 KB (+ resi: the table of preprocessed pixel sums)
     // wave-uniform on purpose (readfirstlane): task, group and unit indices then live in SGPRs, and every load / store
     // below is "SGPR base + one 32-bit VGPR lane offset" (saddr form) instead of a 64-bit per-lane address: a VMEM
@@ -43,9 +43,9 @@ __global__ __launch_bounds__(256) void k1_trunk(const uint4* __restrict__ XS, co
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.x;
     const int groups = (N + 15) / 16;
-    if (b < bS) Trunk<0, RESI, false, false, FAST>::run(XS, groups * 16, b * 4 + w, bS * 4, wfrag, bfrag, F, N, wl);
-    else if (b < bS + bM) Trunk<1, RESI, false, false, FAST>::run(XM, groups * 4, (b - bS) * 4 + w, bM * 4, wfrag, bfrag, F, N, wl);
-    else Trunk<2, RESI, false, false, FAST>::run(XL, groups, (b - bS - bM) * 4 + w, (int)(gridDim.x - bS - bM) * 4, wfrag, bfrag, F, N, wl);
+    if (b < bS) Trunk<0, RESI, false, false, FAST>::run(XS, groups * 16, b * 4 + w, bS * 4, wfrag, bfrag, F, N, wl, nullptr, nullptr, 0, nullptr, fscale);
+    else if (b < bS + bM) Trunk<1, RESI, false, false, FAST>::run(XM, groups * 4, (b - bS) * 4 + w, bM * 4, wfrag, bfrag, F, N, wl, nullptr, nullptr, 0, nullptr, fscale);
+    else Trunk<2, RESI, false, false, FAST>::run(XL, groups, (b - bS - bM) * 4 + w, (int)(gridDim.x - bS - bM) * 4, wfrag, bfrag, F, N, wl, nullptr, nullptr, 0, nullptr, fscale);
 }
 
 // blocks per 256 of the S / M / L branches: tasks 16 : 4 : 1, weighted by their instruction-mix cost per task (M / L tasks
@@ -56,22 +56,25 @@ __global__ __launch_bounds__(256) void k1_trunk(const uint4* __restrict__ XS, co
 #define TRUNK_SH_L 13
 #endif
 
-void launch_trunk(const Workspace& ws, const DeviceWeights& w, int n, bool resi, hipStream_t s, bool fast) {
+void launch_trunk(const Workspace& ws, const DeviceWeights& w, int n, bool resi, hipStream_t s, int fc1_plan) {
     // tasks per group: 16 S, 4 M, 1 L -- all 240 MFMAs.  768 blocks = 3 per CU (156 VGPRs, 21 KB LDS).
     const int groups = (n + 15) / 16, tS = groups * 16, tM = groups * 4, tL = groups;
     auto blocks = [](int tasks, int budget) { int b = (tasks + 3) / 4; return b < budget ? b : budget; };
     static int per_cu = 0;
     if (!per_cu) { const char* e = getenv("ETHCNN_TRUNK_BLOCKS_PER_CU"); per_cu = e ? atoi(e) : 3; }  // development knob
     const int bS = blocks(tS, TRUNK_SH_S * per_cu), bM = blocks(tM, TRUNK_SH_M * per_cu), bL = blocks(tL, TRUNK_SH_L * per_cu);
-    if (fast)  // FC1 plan 1 (All-Intra passes only): features leave as bf16 x 3 pieces in ws.featb
-        hipLaunchKernelGGL((k1_trunk<false, true>), dim3(bS + bM + bL), dim3(256), 0, s, ws.xs, ws.xm, ws.xl, n, bS, bM,
-                           w.trunk_w, w.trunk_b, reinterpret_cast<float*>(ws.featb));
+    if (fc1_plan == 1)  // FC1 plan 1 (All-Intra passes only): features leave as bf16 x 3 pieces in ws.featb
+        hipLaunchKernelGGL((k1_trunk<false, 1>), dim3(bS + bM + bL), dim3(256), 0, s, ws.xs, ws.xm, ws.xl, n, bS, bM,
+                           w.trunk_w, w.trunk_b, reinterpret_cast<float*>(ws.featb), 1.0f);
+    else if (fc1_plan == 2)  // plan 2: fp16 x 2 pieces of the scaled features
+        hipLaunchKernelGGL((k1_trunk<false, 2>), dim3(bS + bM + bL), dim3(256), 0, s, ws.xs, ws.xm, ws.xl, n, bS, bM,
+                           w.trunk_w, w.trunk_b, reinterpret_cast<float*>(ws.featb), w.fast_scale_a);
     else if (resi)
         hipLaunchKernelGGL(k1_trunk<true>, dim3(bS + bM + bL), dim3(256), 0, s, ws.xs, ws.xm, ws.xl, n, bS, bM,
-                           w.trunk_w, w.trunk_b, ws.feat);
+                           w.trunk_w, w.trunk_b, ws.feat, 1.0f);
     else
         hipLaunchKernelGGL(k1_trunk<false>, dim3(bS + bM + bL), dim3(256), 0, s, ws.xs, ws.xm, ws.xl, n, bS, bM,
-                           w.trunk_w, w.trunk_b, ws.feat);
+                           w.trunk_w, w.trunk_b, ws.feat, 1.0f);
 }
 
 }  // namespace ethcnn

@@ -77,8 +77,33 @@ __device__ __forceinline__ void store_pair_bf16x3(const f32x4& qa, const f32x4& 
     }
 }
 
-template <int BR, bool RESI, bool DIRECT = false, bool SC1 = false, bool FAST = false>
+// FC1 plan 2: the same register pair as two fp16 pieces of the SCALED value (scale = a power of two chosen at weight load so that
+// no feature can overflow fp16, ethcnn_weights.cpp::fast_feature_bound): h0 = fp16(a s), h1 = fp16(a s - h0), round to nearest
+// even: a s = h0 + h1 to 2^-24 relative.  ~32 VALU per pair.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+template <bool SC1>
+__device__ __forceinline__ void store_pair_f16x2(const f32x4& qa, const f32x4& qb, float scale, __amdgpu_buffer_rsrc_t rF, int voff) {
+    float r[8] = {qa[0] * scale, qa[1] * scale, qa[2] * scale, qa[3] * scale, qb[0] * scale, qb[1] * scale, qb[2] * scale, qb[3] * scale};
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        u32x4 P;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f16x2 h = __builtin_convertvector((f32x2){r[2 * i], r[2 * i + 1]}, f16x2);
+            P[i] = __builtin_bit_cast(unsigned, h);
+            if (p == 0) {
+                r[2 * i] -= (float)h[0];
+                r[2 * i + 1] -= (float)h[1];
+            }
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(P, rF, voff + p * 1024, 0, SC1 ? kAuxSc1 : 0);
+    }
+}
+
+// FAST = FC1 plan the features are written for: 0 fp32 group images (feat), 1 bf16 x 3 / 2 fp16 x 2 pieces (featb)
+template <int BR, bool RESI, bool DIRECT = false, bool SC1 = false, int FAST = 0>
 struct Trunk {
+    static constexpr int FCH = (FAST == 1 ? 3 : 2) * 1024;  // bytes of one chunk record of a pair image (pieces x 1 KiB)
     static constexpr int POOL = (BR == 0) ? 1 : (BR == 1 ? 2 : 4);
     static constexpr float SCALE = 1.0f / (float)(POOL * POOL);
     static constexpr float C255S = (1.0f / 255.0f) * SCALE;  // exact: SCALE is a power of two
@@ -233,7 +258,7 @@ struct Trunk {
     static __device__ __forceinline__ void run(const uint4* __restrict__ X, int ntasks, int wave, int nwaves,
                                                const float* __restrict__ wfrag, const float* __restrict__ bfrag,
                                                float* __restrict__ F, int N, float* wl, const DirectSrc* src = nullptr,
-                                               int* claim = nullptr, int tag = 0, int* s_owned = nullptr) {
+                                               int* claim = nullptr, int tag = 0, int* s_owned = nullptr, float fscale = 1.0f) {
         const int lane = threadIdx.x & 63;
         const int col = lane & 15, g = lane >> 4;
         // single-launch pass: the block CLAIMS its work item (one exchange on the item's own word; `tag` = this launch's epoch).
@@ -287,7 +312,7 @@ struct Trunk {
         // hazard recognizer assumes a register soffset removes the ">64-bit store data" hazard -- and on gfx950 lanes
         // 12..15 of every row then stored the overwritten value (profiles/r02_fc1_variants.txt, "buffer_store hazard").
         const int lane16 = lane * 16;
-        const int lane_off = FAST ? (g >> 1) * 3072 + (g & 1) * 512 + col * 16  // plan 1: [chunk][piece][k half][row][8 bf16]
+        const int lane_off = FAST ? (g >> 1) * FCH + (g & 1) * 512 + col * 16  // plans 1 / 2: [chunk][piece][k half][row][8 x 16 bit]
                                   : (col * 4 + g * 64) * 4;  // feature stores: [k/4][16 CTUs][4] -> g, col
         const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(X), 0, -1, 0x00020000);
         const __amdgpu_buffer_rsrc_t rF = __builtin_amdgcn_make_buffer_rsrc(F, 0, -1, 0x00020000);
@@ -316,7 +341,11 @@ struct Trunk {
             const int Fg = grp * (kNFeat * 16 * 4);  // uniform byte offset of the group image (< 2^31: <= 8192 groups)
             // plan 1: this task's 8 chunks inside its pair image (unit position T: 16 S, 4 M, 1 L), rows 16 .. 31 for the odd group
             const int Tpos = (BR == 0) ? (task & 15) : (BR == 1 ? 16 + (task & 3) : 20);
-            const int Fb = (grp >> 1) * kFastPairBytes + Tpos * 8 * 3072 + (grp & 1) * 256;
+            const int Fb = (grp >> 1) * (kFastChunks * FCH) + Tpos * 8 * FCH + (grp & 1) * 256;
+            auto store_pair = [&](const f32x4& qa, const f32x4& qb, int pair) {
+                if (FAST == 1) store_pair_bf16x3<SC1>(qa, qb, rF, lane_off + Fb + pair * 2 * FCH);
+                else store_pair_f16x2<SC1>(qa, qb, fscale, rF, lane_off + Fb + pair * 2 * FCH);
+            };
 
             // conv1 of position q2: 4 patches (q1) x 4 k-steps (s = kx); lane supplies v[patch][ky=g][kx=s]
 #define CONV1(q2, c1)                                                                                  \
@@ -346,7 +375,7 @@ struct Trunk {
         a2[q2][0] = lrelu4(c2[0]);                                                                     \
         a2[q2][1] = lrelu4(c2[1]);                                                                     \
         if (FAST) {                                                                                    \
-            if (((q2) & 1) && valid) store_pair_bf16x3<SC1>(a2[(q2) - 1][0], a2[q2][0], rF, lane_off + Fb + ((q2) >> 1) * 2 * 3072); \
+            if (((q2) & 1) && valid) store_pair(a2[(q2) - 1][0], a2[q2][0], (q2) >> 1);                \
         } else if (valid) {                                                                            \
             const int slot = (2 * by + ((q2) >> 1)) * (2 * NB) + 2 * bx + ((q2) & 1);                  \
             const int dst = Fg + ((OFF2 + slot * 24) >> 2) * 256;                                      \
@@ -410,8 +439,8 @@ struct Trunk {
                 }
             if (FAST) {
                 if (valid) {
-                    store_pair_bf16x3<SC1>(zq[0], zq[1], rF, lane_off + Fb + 4 * 3072);
-                    store_pair_bf16x3<SC1>(lrelu4(c3[0]), lrelu4(c3[1]), rF, lane_off + Fb + 6 * 3072);
+                    store_pair(zq[0], zq[1], 2);
+                    store_pair(lrelu4(c3[0]), lrelu4(c3[1]), 3);
                 }
             } else if (valid) {
                 const int dst = Fg + ((OFF3 + (by * NB + bx) * 32) >> 2) * 256;

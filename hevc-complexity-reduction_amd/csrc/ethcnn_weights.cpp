@@ -2,6 +2,7 @@
 //
 // Tensor table == the key/shape/offset table of the reference's TF-V2 checkpoints
 // (/root/reference/HM-16.5_Test_AI/bin/model_2000000_qp*.dat.index).
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -256,20 +257,63 @@ void split_bf16x3(float x, uint16_t* p0, uint16_t* p1, uint16_t* p2) {
     *p2 = bf16_rne(r2);                  // exact: at most 8 significant bits are left
 }
 
-void pack_fc1_fast_image(const float* w_cat, uint16_t* img) {
+void pack_fc1_fast_image(const float* w_cat, int plan, float scale_w, uint16_t* img) {
+    const int np = fast_pieces(plan);
     for (int c = 0; c < kFastChunks; ++c)
         for (int t = 0; t < kNVec / 32; ++t) {
-            uint16_t* rec = img + ((size_t)c * (kNVec / 32) + t) * 3 * 512;  // three 1 KiB pieces
+            uint16_t* rec = img + ((size_t)c * (kNVec / 32) + t) * np * 512;  // NP 1 KiB pieces
             for (int lane = 0; lane < 64; ++lane) {
                 const int n = lane & 31, kh = lane >> 5;
                 for (int idx = 0; idx < 8; ++idx) {
                     const float w = w_cat[(size_t)fast_feature_k(c, kh, idx) * kNVec + 32 * t + n];
                     uint16_t p[3];
-                    split_bf16x3(w, &p[0], &p[1], &p[2]);
-                    for (int q = 0; q < 3; ++q) rec[q * 512 + lane * 8 + idx] = p[q];
+                    if (plan == 1) {
+                        split_bf16x3(w, &p[0], &p[1], &p[2]);
+                    } else {  // fp16 x 2, round to nearest even at both steps (ethcnn_spec.h::f16_rne)
+                        const float ws = w * scale_w;  // exact: a power of two, no overflow / underflow by the choice of the scale
+                        p[0] = f16_rne(ws);
+                        p[1] = f16_rne(ws - f16_f32(p[0]));
+                    }
+                    for (int q = 0; q < np; ++q) rec[q * 512 + lane * 8 + idx] = p[q];
                 }
             }
         }
+}
+
+// |input| <= 1 (All-Intra: v = x/255 - block mean, both in [0, 1]) -> per-channel bounds of conv1, conv2, conv3 outputs
+// (leaky-ReLU never grows a magnitude); the features are the conv2 and conv3 outputs of the three branches
+float fast_feature_bound(const float* blob) {
+    double worst = 0.0;
+    for (int br = 0; br < 3; ++br) {
+        const float* W1 = blob + kOffConvW[br][0];  // [4][4][1][16]
+        const float* W2 = blob + kOffConvW[br][1];  // [2][2][16][24]
+        const float* W3 = blob + kOffConvW[br][2];  // [2][2][24][32]
+        const float* B1 = blob + kOffConvB[br][0];
+        const float* B2 = blob + kOffConvB[br][1];
+        const float* B3 = blob + kOffConvB[br][2];
+        double b1[16], b2[24], b3[32];
+        for (int co = 0; co < 16; ++co) {
+            double sacc = std::fabs((double)B1[co]);
+            for (int t = 0; t < 16; ++t) sacc += std::fabs((double)W1[t * 16 + co]);
+            b1[co] = sacc;
+        }
+        for (int co = 0; co < 24; ++co) {
+            double sacc = std::fabs((double)B2[co]);
+            for (int q = 0; q < 4; ++q)
+                for (int ci = 0; ci < 16; ++ci) sacc += std::fabs((double)W2[(q * 16 + ci) * 24 + co]) * b1[ci];
+            b2[co] = sacc;
+            worst = std::max(worst, sacc);
+        }
+        for (int co = 0; co < 32; ++co) {
+            double sacc = std::fabs((double)B3[co]);
+            for (int q = 0; q < 4; ++q)
+                for (int ci = 0; ci < 24; ++ci) sacc += std::fabs((double)W3[(q * 24 + ci) * 32 + co]) * b2[ci];
+            b3[co] = sacc;
+            worst = std::max(worst, sacc);
+        }
+        (void)b3;
+    }
+    return (float)(worst * 1.0001);
 }
 
 void pack_fc2_lane_image(const float* w2, int n1, int n2, float* img) {

@@ -474,8 +474,9 @@ class EthCnn(object):
         return v.value
 
     def set_fc1_plan(self, plan=1):
-        """FC1 plan: 0 = exact fp32 (default, bit-identical to the oracle); 1 = exact three-way bf16 splits on the bf16 matrix
-        pipe for passes that take the multi-launch path (as accurate against float64, NOT bit-identical; include/ethcnn.h)."""
+        """FC1 plan: 0 = exact fp32 (default, bit-identical to the oracle); 1 = exact three-way bf16 splits / 2 = two-way fp16
+        splits on the 16-bit matrix pipe for passes that take the multi-launch path (as accurate against float64, NOT
+        bit-identical; include/ethcnn.h)."""
         self._chk(self.lib.ethcnn_set_fc1_plan(self.h, int(plan)))
 
     def fc1_plan(self):

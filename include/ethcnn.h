@@ -213,16 +213,20 @@ int ethcnn_reset_stage_times(ethcnn_ctx* ctx);
 int ethcnn_set_fused_launch(ethcnn_ctx* ctx, int mode);
 /* FC1 plan.  FC1 ([N,2688] x [2688,448]) is 78 % of the path's arithmetic.
  *   0 (default)  exact fp32 on v_mfma_f32_16x16x4_f32: every result of the library is bit-identical to oracle/ethcnn_oracle.c;
- *   1 ("fast")   passes that take the multi-launch path (more than 2304 CTUs, or rows that are not 16-byte aligned) run FC1 on the
- *                BF16 matrix pipe (16x the fp32 MFMA rate) with EXACT three-way bf16 splits of both operands: the trunk writes
- *                every feature as a0 + a1 + a2 (exactly the fp32 value), W1 is split the same way at load, and the six products
- *                a_i w_j with i + j <= 2 are accumulated in fp32 (the three dropped terms are below 2^-27 of the product).
- *                Measured against float64 the sums are as accurate as plan 0's fmaf chains (profiles/r04_bf16x3_probe.txt), but
- *                the ORDER of the fp32 additions differs, so probabilities agree with plan 0 / the oracle to about 1e-6, not
- *                bit for bit (tests: <= 1e-4, the north star's tolerance; thresholded decisions may differ on knife edges only).
- *                Everything else (trunk convolutions, heads, gates) is computed exactly as in plan 0.  The single-launch small
- *                pass and the LDP path always use plan 0.  Env ETHCNN_FC1_PLAN=1 starts contexts in plan 1.
- * Takes effect with the next pass enqueued. */
+ *   1 ("fast", bf16 x 3)  passes that take the multi-launch path (more than 2304 CTUs, or rows that are not 16-byte aligned) run
+ *                FC1 on the BF16 matrix pipe (16x the fp32 MFMA rate) with EXACT three-way bf16 splits of both operands: the trunk
+ *                writes every feature as a0 + a1 + a2 (exactly the fp32 value), W1 is split the same way at load, and the six
+ *                products a_i w_j with i + j <= 2 are accumulated in fp32 (the three dropped terms are below 2^-27 of the product);
+ *   2 ("fast", fp16 x 2)  the same structure with TWO fp16 pieces per operand (power-of-two scaled so that no piece can overflow:
+ *                the feature bound is derived from the conv weights at load, not observed) and THREE products: h0 + h1
+ *                represents the scaled fp32 value to 2^-24 relative.  Half the matrix instructions and two thirds of the bytes of
+ *                plan 1: the faster of the two.
+ * Measured against float64 the sums of plans 1 and 2 are as accurate as plan 0's fmaf chains (profiles/r04_bf16x3_probe.txt:
+ * the error of a 2688-term fp32 sum is set by the roundings of its accumulation), but the ORDER of the fp32 additions differs,
+ * so probabilities agree with plan 0 / the oracle to about 1e-6, not bit for bit (tests: <= 1e-4, the north star's tolerance;
+ * thresholded decisions may differ on knife edges only).  Everything else (trunk convolutions, heads, gates) is computed
+ * exactly as in plan 0.  The single-launch small pass and the LDP path always use plan 0.  Env ETHCNN_FC1_PLAN=1|2 starts
+ * contexts in that plan.  Takes effect with the next pass enqueued. */
 int ethcnn_set_fc1_plan(ethcnn_ctx* ctx, int plan);
 int ethcnn_get_fc1_plan(const ethcnn_ctx* ctx);
 /* Single-launch small pass (default on): a pass of <= 2304 CTUs (up to one 3840x2160 picture) whose rows are 16-byte aligned (width, pitch, frame stride and

@@ -1,9 +1,10 @@
-"""-m gpu: FC1 plan 1 (ethcnn_set_fc1_plan(ctx, 1): FC1 as exact three-way bf16 splits on the bf16 matrix pipe,
-csrc/ethcnn_fc1_fast.hip) against the oracle.  Plan 1 is opt-in and NOT bit-identical to the oracle by design (the fp32
-additions happen in another order), so its bar is the north star's: probabilities within 1e-4 (tolerance written in every
-assert below; measured ~1e-6), thresholded decisions equal except on knife edges -- plus what makes it "not narrower
-arithmetic": the trunk's split features add back to the oracle's features BIT FOR BIT, and the error against the float64
-restatement is no worse than twice the exact plan's."""
+"""-m gpu: FC1 plans 1 and 2 (ethcnn_set_fc1_plan: FC1 on the 16-bit matrix pipe with split operands -- exact three-way
+bf16 splits / two-way fp16 splits of power-of-two scaled values; csrc/ethcnn_fc1_fast.hip) against the oracle.  The plans
+are opt-in and NOT bit-identical to the oracle by design (the fp32 additions happen in another order), so their bar is the
+north star's: probabilities within 1e-4 (tolerance written in every assert below; measured ~1e-6), thresholded decisions
+equal except on knife edges -- plus what makes them "not narrower arithmetic": the trunk's split features add back to the
+oracle's features (plan 1: BIT FOR BIT; plan 2: to 2^-23 relative), and the error against the float64 restatement is no
+worse than twice the exact plan's."""
 import os
 
 import numpy as np
@@ -30,20 +31,21 @@ def _mixed_ctus(rng, n):
     return ctus
 
 
-@pytest.fixture()
-def fast_ctx(pkg):
+@pytest.fixture(params=[1, 2], ids=["bf16x3", "fp16x2"])
+def fast_ctx(pkg, request):
     c = pkg.EthCnn(device=0)
-    c.set_small_pass_launch(False)  # plan 1 lives in the multi-launch path; small test batches must take it too
-    c.set_fc1_plan(1)
-    assert c.fc1_plan() == 1
+    c.set_small_pass_launch(False)  # the fast plans live in the multi-launch path; small test batches must take it too
+    c.set_fc1_plan(request.param)
+    assert c.fc1_plan() == request.param
     yield c
     c.close()
 
 
 @pytest.mark.parametrize("n,gain,qp", [(1, 1.0, 32), (37, 8.0, 22), (333, 8.0, 27), (2500, 1.0, 37), (263, 8.0, 32)])
-def test_stages_under_plan_1(pkg, fast_ctx, oracle, n, gain, qp):
+def test_stages_under_the_fast_plans(pkg, fast_ctx, oracle, n, gain, qp):
     e = pkg.ethcnn
     c = fast_ctx
+    plan = c.fc1_plan()
     rng = np.random.default_rng(500 + n)
     blob = oracle.synth_blob(11, gain)
     c.load_blob(blob)
@@ -52,8 +54,11 @@ def test_stages_under_plan_1(pkg, fast_ctx, oracle, n, gain, qp):
     c.set_debug_capture(True)
     got = c.predict_ctus(ctus, qp)
     F = oracle.features(blob, ctus, mode=0)
-    gF = c.debug_fetch(e.DBG_FEATURES, n)  # the three bf16 pieces of every feature, added back on the host
-    assert np.array_equal(_bits(gF), _bits(F)), "the split features are not the oracle's features: max |d| = %g" % np.abs(gF - F).max()
+    gF = c.debug_fetch(e.DBG_FEATURES, n)  # the 16-bit pieces of every feature, added back on the host
+    if plan == 1:
+        assert np.array_equal(_bits(gF), _bits(F)), "the split features are not the oracle's features: max |d| = %g" % np.abs(gF - F).max()
+    else:  # two fp16 pieces: 2^-24 relative while the low piece is a normal number, 2^-25 of the scaled unit below that
+        assert np.all(np.abs(gF - F) <= np.abs(F) * 2.0 ** -23 + 2.0 ** -30), np.abs(gF - F).max()
     H1 = oracle.fc1(blob, F)
     gH1 = c.debug_fetch(e.DBG_FC1, n)
     scale = max(1.0, float(np.abs(H1).max()))
@@ -74,12 +79,12 @@ def test_stages_under_plan_1(pkg, fast_ctx, oracle, n, gain, qp):
     c.set_fc1_plan(0)
     assert np.array_equal(_bits(c.predict_ctus(ctus, qp)), _bits(P))
     assert np.array_equal(_bits(c.debug_fetch(e.DBG_FC1, n)), _bits(H1))
-    c.set_fc1_plan(1)
-    assert np.array_equal(_bits(c.predict_ctus(ctus, qp)), _bits(got)), "plan 1 is not deterministic"
+    c.set_fc1_plan(plan)
+    assert np.array_equal(_bits(c.predict_ctus(ctus, qp)), _bits(got)), "the fast plan is not deterministic"
     c.set_debug_capture(False)
 
 
-def test_reference_graph_golden_under_plan_1(fast_ctx, oracle):
+def test_reference_graph_golden_under_the_fast_plans(fast_ctx, oracle):
     """All golden AI sets executed through the reference's serialized graphs (2,388 CTUs): plan 1 within 1e-4 of them
     (plan 0's own bar on these vectors is 1e-5; plan 1 is asserted to that too since it measures ~4e-6)."""
     import sys
@@ -103,8 +108,9 @@ def test_reference_graph_golden_under_plan_1(fast_ctx, oracle):
     assert total >= 2000
 
 
+@pytest.mark.parametrize("plan", [1, 2])
 @pytest.mark.parametrize("w,h,frames,qp", [(3840, 2160, 3, 32), (1920, 1080, 6, 22), (4928, 3264, 1, 27), (200, 136, 2, 37)])
-def test_frames_under_plan_1(pkg, oracle, w, h, frames, qp):
+def test_frames_under_the_fast_plans(pkg, oracle, w, h, frames, qp, plan):
     """Sampled C2 / C3 / C4 frames (and a ragged small one): ungated probabilities within 1e-4 of the oracle and of
     float64; every thresholded decision that differs from the exact plan's is a knife edge; with the shipped gates the
     two plans' outputs agree to 1e-4 wherever the gate decisions agree."""
@@ -117,7 +123,7 @@ def test_frames_under_plan_1(pkg, oracle, w, h, frames, qp):
     c.set_small_pass_launch(False)
     c.set_thresholds(-1.0, -1.0)
     exact = c.predict_luma(luma, w, h, frames, qp)
-    c.set_fc1_plan(1)
+    c.set_fc1_plan(plan)
     fast = c.predict_luma(luma, w, h, frames, qp)
     can = oracle.predict_frames(blob, luma, w, h, frames, qp, -1.0, -1.0, mode=0)
     assert np.array_equal(_bits(exact), _bits(can))
@@ -148,8 +154,9 @@ def test_frames_under_plan_1(pkg, oracle, w, h, frames, qp):
         assert edge, "gate patterns differ without a knife-edge sub-batch maximum"
 
 
-def test_plan_1_env_and_file_entry(pkg, oracle, tmp_path):
-    """ETHCNN_FC1_PLAN=1 starts contexts in plan 1; the file entry point (staging ring, several passes) takes it."""
+@pytest.mark.parametrize("plan", [1, 2])
+def test_plan_env_and_file_entry(pkg, oracle, tmp_path, plan):
+    """ETHCNN_FC1_PLAN=1|2 starts contexts in that plan; the file entry point (staging ring, several passes) takes it."""
     import subprocess
     import sys
     import bench
@@ -163,9 +170,9 @@ def test_plan_1_env_and_file_entry(pkg, oracle, tmp_path):
             f.write(chroma)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = ("import importlib, sys; sys.path.insert(0, %r); p = importlib.import_module('hevc-complexity-reduction_amd'); "
-            "c = p.EthCnn(device=0); assert c.fc1_plan() == 1; c.load_synthetic(1, 8.0); "
-            "print(c.predict_yuv_file(%r, %d, %d, %d, %r))" % (root, yuv, w, h, qp, str(tmp_path / "fast.dat")))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ETHCNN_FC1_PLAN="1"), capture_output=True, text=True, timeout=300)
+            "c = p.EthCnn(device=0); assert c.fc1_plan() == %d; c.load_synthetic(1, 8.0); "
+            "print(c.predict_yuv_file(%r, %d, %d, %d, %r))" % (root, plan, yuv, w, h, qp, str(tmp_path / "fast.dat")))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ETHCNN_FC1_PLAN=str(plan)), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip() == str(frames), (r.stdout, r.stderr[-800:])
     got = np.fromfile(str(tmp_path / "fast.dat"), dtype="<f4").reshape(-1, 21)
     want = oracle.predict_frames(oracle.synth_blob(1, 8.0), luma, w, h, frames, qp, 0.5, 0.5, mode=0)

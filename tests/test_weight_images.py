@@ -18,6 +18,11 @@ extern "C" {
 void t_fc1_lane(const float* w, float* out) { ethcnn::pack_fc1_lane_image(w, out); }
 void t_fc2_lane(const float* w, int n1, int n2, float* out) { ethcnn::pack_fc2_lane_image(w, n1, n2, out); }
 void t_fc1_img(const float* w, int bn, int bk, float* out) { ethcnn::pack_fc1_image(w, bn, bk, out); }
+int t_fast_k(int chunk, int kh, int idx) { return ethcnn::fast_feature_k(chunk, kh, idx); }
+void t_fc1_fast(const float* w, int plan, float scale, unsigned short* out) { ethcnn::pack_fc1_fast_image(w, plan, scale, out); }
+unsigned short t_f16(float x) { return ethcnn::f16_rne(x); }
+float t_f16_back(unsigned short h) { return ethcnn::f16_f32(h); }
+float t_bound(const float* blob) { return ethcnn::fast_feature_bound(blob); }
 }
 """
 
@@ -81,3 +86,98 @@ def test_fc1_lds_image(packers, bn, bk):
     assert np.array_equal(img, want)
     # every element of W1 appears exactly once
     assert np.array_equal(np.sort(out), np.sort(w.reshape(-1)))
+
+
+# ---- FC1 plans 1 / 2 (round 4): feature order, 16-bit split images of W1, host fp16 conversion, feature bound
+def _fast_kmap(packers):
+    packers.t_fast_k.restype = ctypes.c_int
+    return np.array([[[packers.t_fast_k(c, kh, i) for i in range(8)] for kh in range(2)] for c in range(168)])
+
+
+def test_fast_feature_order_is_a_permutation_of_the_trunk_register_order(packers):
+    """chunk = 8 T + 2 p + (g >> 1), k half = g & 1; slots 0..3 / 4..7 = quads 2 p, 2 p + 1 of trunk task T (ethcnn_weights.cpp):
+    a bijection onto 0..2687 whose conv2 / conv3 placement follows SURVEY A.2's feature map."""
+    km = _fast_kmap(packers)
+    assert sorted(km.reshape(-1).tolist()) == list(range(2688))
+    OFF2, OFF3, NB = (672, 2208, 2592), (0, 512, 640), (4, 2, 1)
+    for T in range(21):
+        br = 0 if T < 16 else (1 if T < 20 else 2)
+        t = T if br == 0 else (T - 16 if br == 1 else 0)
+        nb = NB[br]
+        by, bx = (t // 4, t % 4) if br == 0 else ((t // 2, t % 2) if br == 1 else (0, 0))
+        slot = lambda q2: (2 * by + (q2 >> 1)) * (2 * nb) + 2 * bx + (q2 & 1)
+        for p in range(4):
+            for g in range(4):
+                got = km[8 * T + 2 * p + (g >> 1), g & 1]
+                for half in range(2):
+                    n = 2 * p + half
+                    if n < 4:
+                        want = [OFF2[br] + slot(n) * 24 + 4 * g + e for e in range(4)]
+                    elif n < 6:
+                        want = [OFF2[br] + slot(2 * (n - 4) + (g >> 1)) * 24 + 16 + 4 * (g & 1) + e for e in range(4)]
+                    else:
+                        want = [OFF3[br] + (by * nb + bx) * 32 + 16 * (n - 6) + 4 * g + e for e in range(4)]
+                    assert got[4 * half:4 * half + 4].tolist() == want, (T, p, g, half)
+
+
+def test_host_fp16_conversion_matches_numpy(packers):
+    packers.t_f16.restype = ctypes.c_ushort
+    packers.t_f16.argtypes = [ctypes.c_float]
+    packers.t_f16_back.restype = ctypes.c_float
+    packers.t_f16_back.argtypes = [ctypes.c_ushort]
+    rng = np.random.default_rng(5)
+    xs = np.concatenate([rng.standard_normal(3000).astype(np.float32) * np.float32(10.0) ** rng.integers(-9, 5, 3000).astype(np.float32),
+                         np.array([0.0, -0.0, 65504.0, 65519.9, 65520.0, 1e6, 2.0 ** -24, 2.0 ** -25, 1.5 * 2.0 ** -25, 2.0 ** -14, 6.1e-5,
+                                   0.333251953125 + 2.0 ** -13, 1.0 + 2.0 ** -11, 1.0 + 3 * 2.0 ** -11], np.float32)])
+    with np.errstate(over="ignore"):
+        want = xs.astype(np.float16)
+    for x, w in zip(xs, want):
+        h = packers.t_f16(float(x))
+        assert h == int(w.view(np.uint16)), (x, hex(h), hex(int(w.view(np.uint16))))
+        if np.isfinite(w):
+            assert packers.t_f16_back(h) == float(w)
+
+
+@pytest.mark.parametrize("plan", [1, 2])
+def test_fc1_fast_image(packers, plan):
+    """[168 chunks][14 column tiles][NP pieces][k half 2][32 columns][8]: piece q of W1[fast_feature_k(c, kh, idx)][32 t + n];
+    plan 1: three bf16 pieces that add back to the weight EXACTLY; plan 2: two fp16 pieces of the scaled weight, to 2^-24 relative"""
+    rng = np.random.default_rng(plan)
+    w = (rng.standard_normal((2688, 448)) * 0.03).astype(np.float32)
+    w[5, 7] = 0.0
+    npieces = 3 if plan == 1 else 2
+    scale = np.float32(2.0 ** 17) if plan == 2 else np.float32(1.0)
+    out = np.empty(2688 * 448 * npieces, np.uint16)
+    packers.t_fc1_fast.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_int, ctypes.c_float, ctypes.POINTER(ctypes.c_ushort)]
+    packers.t_fc1_fast(_fp(w), plan, float(scale), out.ctypes.data_as(ctypes.POINTER(ctypes.c_ushort)))
+    img = out.reshape(168, 14, npieces, 2, 32, 8)
+    km = _fast_kmap(packers)  # [168][2][8]
+    src = w[km][:, :, :, :].reshape(168, 2, 8, 14, 32).transpose(0, 3, 1, 4, 2)  # -> [c][t][kh][n][idx]
+    if plan == 1:
+        pieces = (img.astype(np.uint32) << 16).view(np.float32)
+        back = (pieces[:, :, 0] + pieces[:, :, 1]) + pieces[:, :, 2]
+        assert np.array_equal(back.view(np.uint32), src.view(np.uint32))
+        assert np.array_equal(pieces[:, :, 0], ((src.view(np.uint32) + 0x7fff + ((src.view(np.uint32) >> 16) & 1)) & 0xffff0000).view(np.float32))
+    else:
+        h = img.view(np.float16).astype(np.float32)
+        ws = src * scale
+        assert np.array_equal(h[:, :, 0], ws.astype(np.float16).astype(np.float32))
+        assert np.array_equal(h[:, :, 1], (ws - h[:, :, 0]).astype(np.float16).astype(np.float32))
+        assert np.abs((h[:, :, 0] + h[:, :, 1]) - ws).max() <= np.abs(ws).max() * 2.0 ** -23
+
+
+def test_feature_bound_holds_on_random_ctus(packers):
+    """fast_feature_bound is a guarantee (sum of |weights| through the three conv layers, |input| <= 1): no feature the oracle
+    computes may exceed it"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ethcnn_np as oracle
+    packers.t_bound.restype = ctypes.c_float
+    rng = np.random.default_rng(3)
+    for seed, gain in ((1, 8.0), (11, 1.0)):
+        blob = oracle.synth_blob(seed, gain)
+        bound = packers.t_bound(_fp(blob))
+        ctus = rng.integers(0, 256, size=(48, 64, 64), dtype=np.uint8)
+        ctus[:8] = (rng.integers(0, 2, size=(8, 64, 64)) * 255).astype(np.uint8)  # extreme contrast
+        F = oracle.features(blob, ctus, mode=0)
+        assert np.isfinite(bound) and 0 < np.abs(F).max() <= bound, (np.abs(F).max(), bound)
