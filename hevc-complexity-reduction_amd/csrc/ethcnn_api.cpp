@@ -1213,8 +1213,11 @@ extern "C" int ethcnn_predict_luma(ethcnn_ctx* c, const uint8_t* luma, int w, in
 // shard == false: frames [0, all) -> out_path via temp file + rename.
 // shard == true : frames [f0, f1) pwritten at f0 * nctu * 84 into the EXISTING, pre-sized
 //                 out_path (one worker per GPU, disjoint ranges, no collective).
-static int yuv_frames(ethcnn_ctx* c, const char* yuv, int w, int h, int qp, const char* out_path, bool shard,
+// mode 0: the whole file -> out_path (temp + rename); 1: shard, frames [f0, f1) pwritten at their place into an existing, pre-sized
+// out_path; 2: range, frames [f0, f1) -> an out_path of their own (temp + rename) = get_prob(n_frames_start, n_frames_end)
+static int yuv_frames(ethcnn_ctx* c, const char* yuv, int w, int h, int qp, const char* out_path, int mode,
                       int64_t f0, int64_t f1, int64_t* nframes_out) {
+    const bool shard = (mode == 1);
     if (w <= 0 || h <= 0) return set_err(c, ETHCNN_ERR_ARG, "bad frame size %dx%d", w, h);
     struct stat st;
     if (stat(yuv, &st) != 0) return set_err(c, ETHCNN_ERR_IO, "cannot stat %s: %s", yuv, std::strerror(errno));
@@ -1224,7 +1227,7 @@ static int yuv_frames(ethcnn_ctx* c, const char* yuv, int w, int h, int qp, cons
                        (long long)st.st_size, w, h, (long long)frame_bytes);
     const int64_t total = st.st_size / frame_bytes;
     if (nframes_out) *nframes_out = total;
-    if (!shard) { f0 = 0; f1 = total; }
+    if (mode == 0) { f0 = 0; f1 = total; }
     if (f0 < 0 || f1 < f0 || f1 > total) return set_err(c, ETHCNN_ERR_ARG, "frame range [%lld,%lld) outside 0..%lld", (long long)f0, (long long)f1, (long long)total);
     const int nctu = ((w + 63) / 64) * ((h + 63) / 64);
     FILE* fin = std::fopen(yuv, "rb");
@@ -1293,13 +1296,19 @@ static int yuv_frames(ethcnn_ctx* c, const char* yuv, int w, int h, int qp, cons
 extern "C" int ethcnn_predict_yuv_file(ethcnn_ctx* c, const char* yuv, int w, int h, int qp, const char* out_path,
                                        int64_t* nframes_out) {
     if (!c || !yuv || !out_path) return c ? set_err(c, ETHCNN_ERR_ARG, "null path") : ETHCNN_ERR_ARG;
-    return yuv_frames(c, yuv, w, h, qp, out_path, false, 0, 0, nframes_out);
+    return yuv_frames(c, yuv, w, h, qp, out_path, 0, 0, 0, nframes_out);
+}
+
+extern "C" int ethcnn_predict_yuv_range(ethcnn_ctx* c, const char* yuv, int w, int h, int qp, const char* out_path,
+                                        int64_t frame_begin, int64_t frame_end) {
+    if (!c || !yuv || !out_path) return c ? set_err(c, ETHCNN_ERR_ARG, "null path") : ETHCNN_ERR_ARG;
+    return yuv_frames(c, yuv, w, h, qp, out_path, 2, frame_begin, frame_end, nullptr);
 }
 
 extern "C" int ethcnn_predict_yuv_shard(ethcnn_ctx* c, const char* yuv, int w, int h, int qp, const char* out_path,
                                         int64_t frame_begin, int64_t frame_end) {
     if (!c || !yuv || !out_path) return c ? set_err(c, ETHCNN_ERR_ARG, "null path") : ETHCNN_ERR_ARG;
-    return yuv_frames(c, yuv, w, h, qp, out_path, true, frame_begin, frame_end, nullptr);
+    return yuv_frames(c, yuv, w, h, qp, out_path, 1, frame_begin, frame_end, nullptr);
 }
 
 // -------------------------------------------------------------- config #5 -----------

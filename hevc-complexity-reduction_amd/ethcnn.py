@@ -75,6 +75,7 @@ SIGNATURES = {
     "ethcnn_predict_luma": (_i, [_vp, _vp, _i, _i, _pd, _pd, _i, _i, _fp]),
     "ethcnn_predict_yuv_file": (_i, [_vp, _cp, _i, _i, _i, _cp, ctypes.POINTER(ctypes.c_int64)]),
     "ethcnn_predict_yuv_shard": (_i, [_vp, _cp, _i, _i, _i, _cp, ctypes.c_int64, ctypes.c_int64]),
+    "ethcnn_predict_yuv_range": (_i, [_vp, _cp, _i, _i, _i, _cp, ctypes.c_int64, ctypes.c_int64]),
     "ethcnn_ckpt_read_blob": (_i, [_cp, _fp, _sz, ctypes.c_char_p, _sz]),
     "ethcnn_resi_vectors_device":(_i, [_vp, _vp, _i, _i, _pd, _vp]),
     "ethcnn_resi_vectors": (_i, [_vp, _vp, _i, _i, _pd, _fp]),
@@ -340,6 +341,12 @@ class EthCnn(object):
         self._chk(self.lib.ethcnn_predict_yuv_file(self.h, os.fsencode(yuv_path), width, height, int(qp),
                                                    os.fsencode(out_path), ctypes.byref(nf)))
         return nf.value
+
+    def predict_yuv_range(self, yuv_path, width, height, qp, out_path, frame_begin, frame_end):
+        """frames [frame_begin, frame_end) -> an out_path holding exactly those (get_prob's n_frames_start / n_frames_end)"""
+        self._chk(self.lib.ethcnn_predict_yuv_range(self.h, os.fsencode(yuv_path), width, height, int(qp),
+                                                    os.fsencode(out_path), int(frame_begin), int(frame_end)))
+        return int(frame_end) - int(frame_begin)
 
     def predict_yuv_shard(self, yuv_path, width, height, qp, out_path, frame_begin, frame_end):
         self._chk(self.lib.ethcnn_predict_yuv_shard(self.h, os.fsencode(yuv_path), width, height, int(qp),

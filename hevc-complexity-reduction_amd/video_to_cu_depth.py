@@ -38,13 +38,17 @@ def get_y_conv_on_large_data(ctx, input_image, qp_seq):
 
 
 def get_prob(ctx, yuv_name, image_size, save_file, qp_seq, n_frames_start, n_frames_end, frame_width, frame_height):
-    """video_to_cu_depth.py:75-118.  The reference always passes start=0, end=all frames."""
+    """video_to_cu_depth.py:75-118: frames [n_frames_start, n_frames_end) of the file -> save_file (which then holds exactly
+    those frames; the reference reads and discards the first n_frames_start, :86-87).  Its own call passes 0 and the frame
+    count (:139-140)."""
     assert image_size == IMAGE_SIZE
     frame_bytes = frame_width * frame_height * 3 // 2
     total = get_file_size(yuv_name) // frame_bytes
-    if n_frames_start != 0 or n_frames_end != total:
-        raise ValueError("get_prob: only the reference's own call (all frames from 0) is supported")
-    return ctx.predict_yuv_file(yuv_name, frame_width, frame_height, qp_seq, save_file)
+    if n_frames_start == 0 and n_frames_end == total:
+        return ctx.predict_yuv_file(yuv_name, frame_width, frame_height, qp_seq, save_file)
+    if not 0 <= n_frames_start <= n_frames_end <= total:
+        raise ValueError("get_prob: frame range [%d, %d) outside the file's %d frames" % (n_frames_start, n_frames_end, total))
+    return ctx.predict_yuv_range(yuv_name, frame_width, frame_height, qp_seq, save_file, n_frames_start, n_frames_end)
 
 
 def restore_model(ctx, qp_seq, model_dir='.'):

@@ -106,6 +106,12 @@ int ethcnn_predict_yuv_file(ethcnn_ctx* ctx, const char* yuv_path, int width, in
 int ethcnn_predict_yuv_shard(ethcnn_ctx* ctx, const char* yuv_path, int width, int height, int qp,
                              const char* out_path, int64_t frame_begin, int64_t frame_end);
 
+/* get_prob(yuv_name, ..., n_frames_start, n_frames_end, ...) (video_to_cu_depth.py:75-118): frames [frame_begin, frame_end) of the
+ * file (the reference reads and discards the first n_frames_start frames, :86-87) -> an `out_path` that holds exactly those
+ * frames, written to a temp file and renamed.  The reference's own call passes 0 and the frame count = ethcnn_predict_yuv_file. */
+int ethcnn_predict_yuv_range(ethcnn_ctx* ctx, const char* yuv_path, int width, int height, int qp,
+                             const char* out_path, int64_t frame_begin, int64_t frame_end);
+
 /* ---- config #5 front-end: resi_cnn (HM-16.5_Test_LDP/bin/net_CNN_LSTM_one_step.py:151-199)
  *      fed as in resi_to_cu_depth_LDP.py:72-101.  One frame; vec = float32 [nctu][448]. */
 int ethcnn_resi_vectors_device(ethcnn_ctx* ctx, const uint8_t* d_luma, int width, int height,

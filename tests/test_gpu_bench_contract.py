@@ -71,3 +71,33 @@ def test_box_calibration_is_a_plausible_mfma_rate(pkg):
             c.measure_mfma_rate(60.0)
     finally:
         c.close()
+
+
+def test_one_gpu_line_states_the_north_star_ratio_and_the_fast_plans():
+    """The default (N = 1) line on a short C2 run: contract keys, `roofline` + `cpu_baseline`, the north star's ratio
+    (`vs_baseline` = S3 GPU / S3 oracle port, `vs_tf_cpu_proxy`, `north_star_10x`, each naming scope / cores / kind "port"),
+    and the two opt-in FC1 plans reported BESIDE the exact headline (`fast_plan` = bf16 x 3, `fast_plan_fp16x2`) -- the headline
+    itself stays dtype f32 and bit-exact."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c2", "--steps", "4", "--warmup", "1", "--ramp-ms", "20",
+                        "--cpu-seconds", "3"], capture_output=True, text=True, env=_env(), timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["dtype"] == "f32" and d["parity_first_frame_bit_exact"] is True
+    assert d["vs_baseline"] is not None and d["vs_baseline"] > 1.0
+    det = d["vs_baseline_detail"]
+    assert det["kind"] == "port" and det["cores"] >= 1 and "S3" in det["scope"]
+    assert d["vs_tf_cpu_proxy"] > 1.0 and d["vs_tf_cpu_proxy_detail"]["kind"] == "port"
+    assert isinstance(d["north_star_10x"], bool)
+    hs = d["host_scopes"]
+    assert abs(d["vs_baseline"] - hs["s3_file_to_file_ctus_per_s"] / next(
+        b["value"] for b in d["cpu_baselines"] if b["name"].startswith("B1 oracle") and "file scope" in b["name"])) < 1e-9
+    for key, dtype_word in (("fast_plan", "bf16x3"), ("fast_plan_fp16x2", "fp16x2")):
+        fp = d[key]
+        assert dtype_word in fp["dtype"] and fp["value"] > 0 and fp["roofline"]["peak"] == 2500.0
+        assert fp["gate_pattern_equal"] is False or fp["max_abs_vs_exact"] <= 1e-4  # north star's tolerance
+        assert fp["flips_vs_exact"] <= 2

@@ -98,3 +98,28 @@ def test_native_c_cli_matches(pkg, oracle, tmp_path):
     assert r.returncode == 1 and "model_2000000_qp20~25.dat" in r.stderr
     r = subprocess.run([tool, "seq.yuv", str(w + 8), str(h), str(qp)], cwd=str(tmp_path), capture_output=True, text=True)
     assert r.returncode == 1 and r.stderr
+
+
+def test_get_prob_frame_sub_range(pkg, oracle, tmp_path):
+    """get_prob(n_frames_start, n_frames_end) (video_to_cu_depth.py:75-87: the first n_frames_start frames are read and dropped):
+    the host mirror routes a sub-range to ethcnn_predict_yuv_range; the output file holds exactly those frames, bit-exact vs
+    the oracle; an empty range gives an empty file; a range outside the file is an error."""
+    v = pkg.video_to_cu_depth
+    w, h, frames, qp = 416, 240, 7, 32
+    yuv = _yuv(str(tmp_path / "seq.yuv"), w, h, frames, 5)
+    blob = oracle.synth_blob(4, 8.0)
+    c = pkg.EthCnn(device=0)
+    c.load_blob(blob)
+    c.set_thresholds(0.5, 0.5)
+    out = str(tmp_path / "part.dat")
+    luma_all = oracle.predict_frames(blob, yuv, w, h, frames, qp, 0.5, 0.5, frame_stride=w * h * 3 // 2).reshape(frames, -1, 21)
+    for a, b in ((2, 5), (0, 7), (6, 7), (3, 3)):
+        n = v.get_prob(c, str(tmp_path / "seq.yuv"), 64, out, qp, a, b, w, h)
+        got = np.fromfile(out, dtype="<f4").reshape(-1, 21)
+        assert n == b - a and got.shape[0] == (b - a) * 28
+        assert np.array_equal(got.view(np.uint32), luma_all[a:b].reshape(-1, 21).view(np.uint32)), (a, b)
+    for a, b in ((-1, 3), (2, 8), (5, 4)):
+        with pytest.raises((ValueError, pkg.EthCnnError)):
+            v.get_prob(c, str(tmp_path / "seq.yuv"), 64, out, qp, a, b, w, h)
+    assert not [f for f in os.listdir(str(tmp_path)) if ".tmp." in f]
+    c.close()
