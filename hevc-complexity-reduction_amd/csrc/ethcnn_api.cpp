@@ -356,16 +356,16 @@ extern "C" int ethcnn_create(ethcnn_ctx** out, const ethcnn_options* opt) {
                 return set_err(nullptr, ETHCNN_ERR_DEVICE, "cannot create HIP events on device %d", dev);
             }
     }
-    if (const char* e = std::getenv("ETHCNN_OVERLAP")) c->overlap = std::atoi(e) != 0;  // development knob (A/B runs)
-    if (const char* e = std::getenv("ETHCNN_SMALL")) c->small_launch = std::atoi(e) != 0;  // development knob (A/B runs)
+    if (const char* e = dev_env("ETHCNN_OVERLAP")) c->overlap = std::atoi(e) != 0;  // development knob (A/B runs)
+    if (const char* e = dev_env("ETHCNN_SMALL")) c->small_launch = std::atoi(e) != 0;  // development knob (A/B runs)
     if (const char* e = std::getenv("ETHCNN_FC1_PLAN")) {  // user-facing: start contexts in FC1 plan 1 / 2
         const int pl = std::atoi(e);
         c->fc1_plan = (pl == 1 || pl == 2) ? pl : 0;
     }
-    if (const char* e = std::getenv("ETHCNN_FUSED")) c->fused = std::atoi(e) != 0;      // development knob (A/B runs)
-    if (const char* e = std::getenv("ETHCNN_GATE_FOLD")) c->gate_fold = std::atoi(e) != 0;  // development knob (A/B runs)
-    if (const char* e = std::getenv("ETHCNN_DONE_WORD")) c->done_sync = std::atoi(e) != 0;  // development knob (A/B runs)
-    if (const char* e = std::getenv("ETHCNN_LSTM_ONE_LAUNCH")) c->lstm_one_launch = std::atoi(e) != 0;  // development knob (A/B runs)
+    if (const char* e = dev_env("ETHCNN_FUSED")) c->fused = std::atoi(e) != 0;      // development knob (A/B runs)
+    if (const char* e = dev_env("ETHCNN_GATE_FOLD")) c->gate_fold = std::atoi(e) != 0;  // development knob (A/B runs)
+    if (const char* e = dev_env("ETHCNN_DONE_WORD")) c->done_sync = std::atoi(e) != 0;  // development knob (A/B runs)
+    if (const char* e = dev_env("ETHCNN_LSTM_ONE_LAUNCH")) c->lstm_one_launch = std::atoi(e) != 0;  // development knob (A/B runs)
     if (hipHostMalloc((void**)&c->h_done, 64, hipHostMallocDefault) != hipSuccess) {
         ethcnn_destroy(c);
         return set_err(nullptr, ETHCNN_ERR_DEVICE, "cannot allocate the completion word on device %d", dev);
@@ -421,7 +421,7 @@ extern "C" int ethcnn_create(ethcnn_ctx** out, const ethcnn_options* opt) {
             }
         }
     }
-    if (const char* e = std::getenv("ETHCNN_TILE_BLOCKS")) c->tile_blocks = std::max(1, std::atoi(e));
+    if (const char* e = dev_env("ETHCNN_TILE_BLOCKS")) c->tile_blocks = std::max(1, std::atoi(e));
     *out = c;
     return ETHCNN_OK;
 }
@@ -1243,7 +1243,7 @@ static int yuv_frames(ethcnn_ctx* c, const char* yuv, int w, int h, int qp, cons
     // (nt_copy): pread straight into the staging buffer writes its lines through the cache (read-for-ownership + write
     // back) beside the DMA engine.  ETHCNN_FILE_IO=direct keeps the single-copy form.  (A read-only mapping of the file
     // + nt_copy, one copy and no syscalls, was measured at HALF the rate: page faults.)
-    static const bool bounce = [] { const char* e = getenv("ETHCNN_FILE_IO"); return !(e && std::strcmp(e, "direct") == 0); }();
+    static const bool bounce = [] { const char* e = dev_env("ETHCNN_FILE_IO"); return !(e && std::strcmp(e, "direct") == 0); }();
     constexpr size_t kBounce = 128u << 10;
     auto fill = [&](uint8_t* dst, int g0, int nf) -> int {
         // luma only; chroma (w*h/2 bytes per frame) is never read (:47-48)
@@ -1512,7 +1512,7 @@ static int ldp_step_impl(ethcnn_ctx* c, const uint8_t* luma, int w, int h, ptrdi
     // page-locked luma is read in place over PCIe by the tile stage (one coalesced pass while it runs): measured 123.8 us per
     // 1080p call against 128.3 us for "DMA it into HBM first, then the single-launch pass" (profiles/r03_latency_ldp.txt;
     // ETHCNN_LDP_INPLACE=0 selects the latter for A/B runs)
-    static const bool copy_first = [] { const char* e = std::getenv("ETHCNN_LDP_INPLACE"); return e && std::atoi(e) == 0; }();
+    static const bool copy_first = [] { const char* e = dev_env("ETHCNN_LDP_INPLACE"); return e && std::atoi(e) == 0; }();
     const bool in_place = in_pinned(c, luma, lbytes) && !copy_first;
     if (in_place) d_luma = luma;
     else HIPCHK(c, hipMemcpyAsync(c->d_in[0], luma, lbytes, hipMemcpyHostToDevice, c->stream));

@@ -101,7 +101,7 @@ static void launch_fc1_regs(const float* feat, const float* wlane, const float* 
 static int fc1_variant() {
     static int v = -2;
     if (v == -2) {
-        const char* e = getenv("ETHCNN_FC1_VARIANT");  // development knob: tile-shape A/B runs
+        const char* e = dev_env("ETHCNN_FC1_VARIANT");  // development knob: tile-shape A/B runs
         v = e ? atoi(e) : -1;
     }
     return v;

@@ -147,7 +147,7 @@ void launch_fc1_heads(const Workspace& ws, const DeviceWeights& w, int n, float 
     P.fc1_blocks = P.rem_blocks + (unsigned)((big_tiles + 7) / 8) * 8 * 4;
     P.heads_blocks = (unsigned)((n + 63) / 64) * 3u;
 #ifdef ETHCNN_EXPERIMENTS  // A/B builds only (scripts/build_variant.sh NAME -DETHCNN_EXPERIMENTS): these produce WRONG results
-    static const int exp_mode = [] { const char* e = getenv("ETHCNN_FUSED_EXP"); return e ? atoi(e) : 0; }();
+    static const int exp_mode = [] { const char* e = dev_env("ETHCNN_FUSED_EXP"); return e ? atoi(e) : 0; }();
     if (exp_mode == 1) P.heads_blocks = 0;  // FC1 part alone (agent-scope stores + completion counters), no heads blocks
 #endif
     P.sync = ws.flags;

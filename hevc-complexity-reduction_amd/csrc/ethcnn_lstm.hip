@@ -725,7 +725,7 @@ void launch_lstm(const float* d_vec, const float* d_state_in, float* d_state_out
         P.probs = d_probs;
         P.sync = d_gate;
         P.epoch = epoch;
-        static const int steal_test = [] { const char* e = getenv("ETHCNN_LSTM_STEAL_TEST"); return e ? atoi(e) : 0; }();  // tests
+        static const int steal_test = [] { const char* e = dev_env("ETHCNN_LSTM_STEAL_TEST"); return e ? atoi(e) : 0; }();  // tests
         P.steal_test = steal_test > 1 ? steal_test : 0;
         P.done = done;
         P.done_seq = done_seq;

@@ -383,7 +383,7 @@ void launch_small_pass(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int
     P.bS = (P.ngroups * 16 + 3) / 4;
     P.bM = (P.ngroups * 4 + 3) / 4;
     P.bL = P.ngroups;  // one L task per block
-    static const int force = [] { const char* e = getenv("ETHCNN_SMALL_SHAPE"); return e ? atoi(e) : -1; }();  // development knob
+    static const int force = [] { const char* e = dev_env("ETHCNN_SMALL_SHAPE"); return e ? atoi(e) : -1; }();  // development knob
     // 64 x 16 tiles (register-fed FC1 and heads) up to 1536 CTUs, 64 x 32 above (scripts/latency_mid.py, profiles/r03_latency_mid.txt:
     // 920 CTUs 61.8 vs 81.5 us, 1536 CTUs 82.9 vs 89.9, 1800 CTUs 101.2 vs 99.6)
     int shape = n <= 1536 ? 0 : (n <= 2304 ? 1 : 2);
@@ -413,11 +413,11 @@ void launch_small_pass(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int
     P.probs = d_probs;
     P.exp = 0;
     P.epoch = epoch;
-    static const int steal_test = [] { const char* e = getenv("ETHCNN_SMALL_STEAL_TEST"); return e ? atoi(e) : 0; }();  // tests
+    static const int steal_test = [] { const char* e = dev_env("ETHCNN_SMALL_STEAL_TEST"); return e ? atoi(e) : 0; }();  // tests
     P.steal_test = steal_test > 1 ? steal_test : 0;
     unsigned blocks = (unsigned)(P.bS + P.bM + P.bL) + P.fc1_blocks + P.heads_blocks;
 #ifdef ETHCNN_EXPERIMENTS  // A/B builds only (scripts/build_variant.sh NAME -DETHCNN_EXPERIMENTS): these produce WRONG results
-    static const int exp_mode = [] { const char* e = getenv("ETHCNN_SMALL_EXP"); return e ? atoi(e) : 0; }();
+    static const int exp_mode = [] { const char* e = dev_env("ETHCNN_SMALL_EXP"); return e ? atoi(e) : 0; }();
     P.exp = exp_mode;                                                            // 1: consumers do not wait
     if (exp_mode == 2) blocks = (unsigned)(P.bS + P.bM + P.bL);                  // trunk part alone
     if (exp_mode == 3) blocks = (unsigned)(P.bS + P.bM + P.bL) + P.fc1_blocks;   // trunk + FC1

@@ -6,10 +6,21 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 
 #include "../../include/ethcnn.h"
 
 namespace ethcnn {
+
+// Development knobs (A/B switches, forced-steal test modes; scripts/README.md lists them) are read from the environment ONLY by the
+// experiments build of the library (make exp: -DETHCNN_EXPERIMENTS -> lib_exp/libethcnn.so, what the tests of those paths and the
+// A/B scripts load through ETHCNN_LIB).  The shipped library ignores them: it reads ETHCNN_DEVICE(S), ETHCNN_FC1_PLAN,
+// ETHCNN_HOST_THREADS, ETHCNN_LOCAL_WORKERS, ETHCNN_NUMA_BIND and nothing else.
+#ifdef ETHCNN_EXPERIMENTS
+inline const char* dev_env(const char* name) { return std::getenv(name); }
+#else
+inline const char* dev_env(const char*) { return nullptr; }
+#endif
 
 constexpr int kCtu = 64;
 constexpr int kNOut = 21;

@@ -20,22 +20,23 @@
 namespace ethcnn {
 
 // ------------------------------------------------------------------------ crc32c ----
-static uint32_t g_crc_table[8][256];
-static bool g_crc_init = false;
-static void crc_init() {
-    if (g_crc_init) return;
-    for (uint32_t i = 0; i < 256; ++i) {
-        uint32_t c = i;
-        for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : (c >> 1);
-        g_crc_table[0][i] = c;
+// slicing-by-8 tables, built once: a function-local static is initialised exactly once under concurrent first calls (C++11),
+// which a hand-rolled "if (!done)" flag is not -- ethcnn_load_checkpoint can be called from several threads on several contexts
+struct CrcTables {
+    uint32_t t[8][256];
+    CrcTables() {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : (c >> 1);
+            t[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; ++i)
+            for (int k = 1; k < 8; ++k) t[k][i] = (t[k - 1][i] >> 8) ^ t[0][t[k - 1][i] & 0xff];
     }
-    for (uint32_t i = 0; i < 256; ++i)
-        for (int t = 1; t < 8; ++t)
-            g_crc_table[t][i] = (g_crc_table[t - 1][i] >> 8) ^ g_crc_table[0][g_crc_table[t - 1][i] & 0xff];
-    g_crc_init = true;
-}
+};
 uint32_t crc32c(const void* data, size_t n) {
-    crc_init();
+    static const CrcTables tables;
+    const uint32_t (&g_crc_table)[8][256] = tables.t;
     const uint8_t* p = (const uint8_t*)data;
     uint32_t c = 0xFFFFFFFFu;
     while (n >= 8) {

@@ -150,7 +150,8 @@ def read_ckpt_index(index_path):
     rc = lib.ethcnn_ckpt_read_index(index_path.encode(), ents, 256, ctypes.byref(n), err, 400)
     if rc:
         raise EthCnnError(rc, err.value.decode("utf-8", "replace"))
-    return [(e.name.decode(), e.dtype, tuple(e.shape[i] for i in range(e.rank)), e.shard, e.offset, e.size, e.crc32c)
+    # (names come from a file: a corrupted key need not be UTF-8 -- found by tests/test_ckpt.py's byte-flip fuzz)
+    return [(e.name.decode("utf-8", "replace"), e.dtype, tuple(e.shape[i] for i in range(e.rank)), e.shard, e.offset, e.size, e.crc32c)
             for e in ents[: n.value]]
 
 

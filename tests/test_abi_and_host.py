@@ -187,3 +187,25 @@ def test_bench_refuses_without_gpu_or_with_mismatched_world(tmp_path):
         pytest.skip("GPU present: covered by tests/test_gpu_bench_contract.py")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True)
     assert r.returncode != 0 and not any(l.startswith("{") for l in r.stdout.splitlines())
+
+
+def test_development_knobs_are_compiled_out_of_the_shipped_library():
+    """A/B switches and forced-steal test modes are read from the environment by the EXPERIMENTS build only
+    (csrc `make exp` -> lib_exp/libethcnn.so, ethcnn_spec.h::dev_env).  The shipped library does not even contain their names;
+    it keeps the user-facing variables."""
+    dev = [b"ETHCNN_SMALL_STEAL_TEST", b"ETHCNN_LSTM_STEAL_TEST", b"ETHCNN_FC1_VARIANT", b"ETHCNN_OVERLAP", b"ETHCNN_FUSED", b"ETHCNN_GATE_FOLD",
+           b"ETHCNN_DONE_WORD", b"ETHCNN_LSTM_ONE_LAUNCH", b"ETHCNN_TILE_BLOCKS", b"ETHCNN_FILE_IO", b"ETHCNN_LDP_INPLACE", b"ETHCNN_SMALL_SHAPE",
+           b"ETHCNN_TRUNK_BLOCKS_PER_CU", b"ETHCNN_SMALL_EXP", b"ETHCNN_FUSED_EXP"]
+    keep = [b"ETHCNN_FC1_PLAN", b"ETHCNN_NUMA_BIND", b"ETHCNN_HOST_THREADS", b"ETHCNN_LOCAL_WORKERS"]
+    shipped = open(os.path.join(ROOT, "hevc-complexity-reduction_amd", "lib", "libethcnn.so"), "rb").read()
+    for k in dev:
+        assert k + b"\0" not in shipped, k
+    for k in keep:
+        assert k + b"\0" in shipped, k
+    exp = os.path.join(ROOT, "hevc-complexity-reduction_amd", "lib_exp", "libethcnn.so")
+    if not os.path.exists(exp):
+        import __graft_entry__ as ge
+        ge.build()
+    blob = open(exp, "rb").read()
+    for k in dev:
+        assert k + b"\0" in blob, k

@@ -286,7 +286,8 @@ def test_one_launch_frame_kernel_both_forms_and_forced_claim_or_execute(pkg, ora
     """ % (root, root))
     for env in ({}, {"ETHCNN_LSTM_ONE_LAUNCH": "0"}, {"ETHCNN_LSTM_STEAL_TEST": "2"}, {"ETHCNN_LSTM_STEAL_TEST": "3"},
                 {"ETHCNN_LSTM_STEAL_TEST": "7"}):
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        from conftest import exp_env  # the knobs exist in the experiments build only
+        r = subprocess.run([sys.executable, "-c", code], env=exp_env(**env), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and "ok" in r.stdout, (env, r.stdout[-300:], r.stderr[-1500:])
 
 

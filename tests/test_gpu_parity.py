@@ -298,7 +298,8 @@ def test_fc1_shapes_over_short_row_ranges_are_bit_identical():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, ETHCNN_SMALL="0", ROWS="1,17,63,65,510,576,577,1152,1153,1792,1793,3000")
+    from conftest import exp_env  # ETHCNN_FC1_VARIANT / ETHCNN_SMALL exist in the experiments build only
+    env = exp_env(ETHCNN_SMALL="0", ROWS="1,17,63,65,510,576,577,1152,1153,1792,1793,3000")
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fc1_rows.py"), "-1", "2", "3", "4", "7", "8", "9"],
                        env=env, capture_output=True, text=True, timeout=280)
     lines = [l for l in r.stdout.splitlines() if l.startswith("v")]

@@ -172,8 +172,9 @@ def test_claim_or_execute_when_producer_blocks_never_run(pkg, oracle):
         print("steal ok")
     """ % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
     for k in ("2", "3", "7"):
+        from conftest import exp_env  # the knob exists in the experiments build only
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
-                           env=dict(os.environ, ETHCNN_SMALL_STEAL_TEST=k))
+                           env=exp_env(ETHCNN_SMALL_STEAL_TEST=k))
         assert r.returncode == 0 and "steal ok" in r.stdout, (k, r.stdout[-800:], r.stderr[-1500:])
 
 
