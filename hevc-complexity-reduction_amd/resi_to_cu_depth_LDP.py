@@ -58,6 +58,10 @@ THR_FILE = 'Thr_info.txt'
 MODEL_CNN_FILE = 'model_LDP_2000000_qp22~37.dat'  # :159
 
 
+class StaleStateError(IOError):
+    """state.dat cannot be the state of the previous frame (see get_state_in_from_one_file)."""
+
+
 def send_init_signal(init_file):
     with open(init_file, 'w+') as f:
         f.write('1')
@@ -115,8 +119,9 @@ def get_state_in_from_one_file(state_file, num_vectors, i_frame, geometry=None):
             tag = None  # no sidecar: somebody else's state.dat (the reference daemon writes none) -> trusted as there
         if tag is not None:
             if tag[:1] == ['pending']:
-                raise IOError('%s is stale: the state of frame %s was never written (daemon stopped after its ending signal)'
-                              % (state_file, tag[1] if len(tag) > 1 else '?'))
+                raise StaleStateError('%s is stale: the state of frame %s was never written (the daemon that served it stopped after '
+                                      'its ending signal); delete %s%s to accept %s as it is, or restart the encode'
+                                      % (state_file, tag[1] if len(tag) > 1 else '?', state_file, STATE_INDEX_SUFFIX, state_file))
             if len(tag) != 3 or (geometry is not None and [str(int(g)) for g in geometry] != tag[1:]):
                 raise IOError('%s belongs to another sequence (%s), frame %d is %s' % (state_file, ' '.join(tag), i_frame, geometry))
         want = num_vectors * LSTM_DEPTH * 2 * VECTOR_LENGTH
@@ -194,8 +199,12 @@ def restore_lstm(ctx, qp_seq, model_dir='.'):
     return 'synthetic(seed=%s)' % seed
 
 
-def serve(workdir='.', max_frames=None, idle_timeout=None, poll_s=2e-4, device=0, verbose=True):
-    """The daemon loop (:148-190).  Returns the number of frames predicted."""
+def serve(workdir='.', max_frames=None, idle_timeout=None, poll_s=2e-4, device=0, verbose=True, accept_stale=False):
+    """The daemon loop (:148-190).  Returns the number of frames predicted.
+    A stale state.dat (sidecar says "pending": the daemon that served that frame stopped between its ending signal and its
+    state write) stops the daemon with StaleStateError and a message that names the recovery -- delete state.dat.idx to accept
+    state.dat as it is, or restart the encode -- unless accept_stale is set, in which case the file is used as it is after
+    a warning.  (HM then keeps spinning on pred_end.sig, exactly as it does when the reference's daemon dies.)"""
     p = lambda name: os.path.join(workdir, name)
     ctx = _e.EthCnn(device=device)
     try:
@@ -235,8 +244,15 @@ def serve(workdir='.', max_frames=None, idle_timeout=None, poll_s=2e-4, device=0
             # the state of frame i_frame - 1 is resident in HBM when this daemon produced it for this geometry and the
             # state.dat it wrote then is still the one on disk; anything else goes through the file, as in the reference
             resident = i_frame > 1 and last_key == (frame_width, frame_height, i_frame - 1) and state_sig == _file_sig(p(STATE_FILE))
-            state_in = None if (resident or i_frame <= 1) else get_state_in_from_one_file(p(STATE_FILE), num_vectors, i_frame,
-                                                                                           (frame_width, frame_height))
+            try:
+                state_in = None if (resident or i_frame <= 1) else get_state_in_from_one_file(p(STATE_FILE), num_vectors, i_frame,
+                                                                                               (frame_width, frame_height))
+            except StaleStateError as exc:
+                sys.stderr.write('resi_to_cu_depth_LDP: %s\n' % exc)
+                if not accept_stale:
+                    raise
+                os.remove(p(STATE_FILE) + STATE_INDEX_SUFFIX)  # accepted: state.dat is taken as it is, as the reference would
+                state_in = get_state_in_from_one_file(p(STATE_FILE), num_vectors, i_frame, (frame_width, frame_height))
             if state_in is not None:
                 state_in = np.asarray(state_in, dtype=np.float32).reshape(num_vectors, 2, VECTOR_LENGTH)
             depth_out = ctx.ldp_step(luma, frame_width, frame_height, qp_seq, i_frame, state_in,
@@ -257,6 +273,7 @@ def main(argv):
     """`python resi_to_cu_depth_LDP.py` in HM-LDP's bin/ (no arguments, like the reference);
     optional: --max-frames N, --idle-timeout SECONDS."""
     max_frames = idle = None
+    accept_stale = False
     args = list(argv[1:])
     while args:
         a = args.pop(0)
@@ -264,8 +281,13 @@ def main(argv):
             max_frames = int(args.pop(0))
         elif a == '--idle-timeout':
             idle = float(args.pop(0))
+        elif a == '--accept-stale':
+            accept_stale = True
         else:
-            sys.stderr.write('usage: resi_to_cu_depth_LDP.py [--max-frames N] [--idle-timeout S]\n')
+            sys.stderr.write('usage: resi_to_cu_depth_LDP.py [--max-frames N] [--idle-timeout S] [--accept-stale]\n')
             return 2
-    serve('.', max_frames=max_frames, idle_timeout=idle)
+    try:
+        serve('.', max_frames=max_frames, idle_timeout=idle, accept_stale=accept_stale)
+    except StaleStateError:
+        return 1  # (the message, with the recovery step, is already on stderr)
     return 0

@@ -5,6 +5,7 @@ synthetic moving sequence while a predictor daemon answers its command.dat / pre
 
     ldp_e2e.py gpu    <outdir>   daemon = hevc-complexity-reduction_amd/resi_to_cu_depth_LDP.serve (MI355X)
     ldp_e2e.py gpu-cli <outdir>  same, started as a separate process through the root launcher resi_to_cu_depth_LDP.py
+    ldp_e2e.py gpu-native <outdir>  the native daemon (tools/resi_to_cu_depth_ldp.c over the C ABI), a separate process
     ldp_e2e.py oracle <outdir>   daemon = the same protocol answered by the CPU oracle (test infrastructure)
 
 Both write <outdir>/<mode>.json: bitstream md5 + a crc32 of every frame's cu_depth.dat / state.dat.
@@ -109,10 +110,15 @@ def main():
         cli = subprocess.Popen([sys.executable, "resi_to_cu_depth_LDP.py", "--max-frames", str(FRAMES - 1), "--idle-timeout", "300"],
                                cwd=work, env=dict(os.environ, ETHCNN_SYNTHETIC_SEED=str(SEED)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         th = threading.Thread(target=cli.wait, daemon=True)
+    elif mode == "gpu-native":  # the C daemon over the ABI, started in the encoder's directory like the Python one
+        exe_d = os.path.join(ROOT, "hevc-complexity-reduction_amd", "bin", "resi_to_cu_depth_ldp")
+        cli = subprocess.Popen([exe_d, "--max-frames", str(FRAMES - 1), "--idle-timeout", "300"],
+                               cwd=work, env=dict(os.environ, ETHCNN_SYNTHETIC_SEED=str(SEED)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        th = threading.Thread(target=cli.wait, daemon=True)
     else:
         th = threading.Thread(target=(gpu_daemon if mode == "gpu" else oracle_daemon), args=(work, FRAMES - 1, log), daemon=True)
     th.start()
-    time.sleep(6.0 if mode == "gpu-cli" else (3.0 if mode == "gpu" else 0.5))  # the reference's daemon is started by hand before the encoder, too
+    time.sleep(6.0 if mode == "gpu-cli" else (3.0 if mode in ("gpu", "gpu-native") else 0.5))  # the reference's daemon is started by hand before the encoder, too
     exe = os.path.join(ROOT, "oracle", "_ref", "hm_ldp", "TAppEncoderLDP")
     t0 = time.time()
     r = subprocess.run([exe, "-c", os.path.join(ROOT, "scripts", "hm_ldp_test.cfg"), "-i", "seq.yuv", "-wdt", str(W), "-hgt", str(H),
@@ -125,7 +131,10 @@ def main():
     pred = [l.strip() for l in r.stdout.splitlines() if "Predicting Time" in l]
     res = {"mode": mode, "frames": FRAMES, "bitstream_md5": hashlib.md5(open(os.path.join(work, "str.bin"), "rb").read()).hexdigest(),
            "bitstream_bytes": os.path.getsize(os.path.join(work, "str.bin")), "per_frame_crc": log,
-           "encoder_seconds": enc_s, "hm_predicting_time_lines": pred}
+           "encoder_seconds": enc_s, "hm_predicting_time_lines": pred,
+           # what the daemon left behind: the last frame's files (every mode must agree on them byte for byte)
+           "final_cu_depth_crc": zlib.crc32(open(os.path.join(work, "cu_depth.dat"), "rb").read()),
+           "final_state_crc": zlib.crc32(open(os.path.join(work, "state.dat"), "rb").read())}
     json.dump(res, open(os.path.join(out, mode + ".json"), "w"), indent=1)
     print(json.dumps(res))
     shutil.rmtree(work, ignore_errors=True)
