@@ -171,6 +171,7 @@ struct ethcnn_ctx {
     int* flags1 = nullptr;
     hipStream_t s_tile = nullptr;
     hipEvent_t e_tile[2] = {}, e_trunk[2] = {}, e_main = nullptr;
+    hipEvent_t e_band[4] = {};  // one big picture, host -> host: "the rows of piece k are in HBM" (predict_luma_latency)
     int* d_lgate = nullptr;  // LSTM heads launch: gate predicates + ticket tree (lstm_gate_words)
     int lgate_chunks = 0;    // its capacity in ints
     bool lgate_clean = false;
@@ -349,7 +350,8 @@ extern "C" int ethcnn_create(ethcnn_ctx** out, const ethcnn_options* opt) {
         return set_err(nullptr, ETHCNN_ERR_DEVICE, "cannot create HIP streams on device %d", dev);
     }
     {
-        hipEvent_t* evs[] = {&c->e_tile[0], &c->e_tile[1], &c->e_trunk[0], &c->e_trunk[1], &c->e_main};
+        hipEvent_t* evs[] = {&c->e_tile[0], &c->e_tile[1], &c->e_trunk[0], &c->e_trunk[1], &c->e_main,
+                             &c->e_band[0], &c->e_band[1], &c->e_band[2], &c->e_band[3]};
         for (hipEvent_t* e : evs)
             if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) {
                 ethcnn_destroy(c);
@@ -462,7 +464,7 @@ extern "C" void ethcnn_destroy(ethcnn_ctx* c) {
             if (p) (void)hipFree(p);
     }
     {
-        hipEvent_t evs[] = {c->e_tile[0], c->e_tile[1], c->e_trunk[0], c->e_trunk[1], c->e_main};
+        hipEvent_t evs[] = {c->e_tile[0], c->e_tile[1], c->e_trunk[0], c->e_trunk[1], c->e_main, c->e_band[0], c->e_band[1], c->e_band[2], c->e_band[3]};
         for (hipEvent_t e : evs)
             if (e) (void)hipEventDestroy(e);
     }
@@ -1159,7 +1161,9 @@ static int predict_luma_latency(ethcnn_ctx* c, const uint8_t* luma, int w, int h
     if (rc) return rc;
     const bool packed = pitch == w && fstride == (ptrdiff_t)plane;
     const uint8_t* src = luma;
-    if (!(packed && in_pinned(c, luma, in_bytes))) {  // tight planes into the pinned staging buffer
+    const bool banded = nframes == 1 && g.nctu > kSubBatch && c->small_launch && w % 16 == 0;  // (below)
+    const bool stage_rows = !(packed && in_pinned(c, luma, in_bytes));
+    if (stage_rows && !banded) {  // tight planes into the pinned staging buffer
         for (int f = 0; f < nframes; ++f) {
             const uint8_t* s = luma + (size_t)f * fstride;
             uint8_t* d = c->h_in[0] + (size_t)f * plane;
@@ -1168,10 +1172,36 @@ static int predict_luma_latency(ethcnn_ctx* c, const uint8_t* luma, int w, int h
         }
         src = c->h_in[0];
     }
-    HIPCHK(c, hipMemcpyAsync(c->d_in[0], src, in_bytes, hipMemcpyHostToDevice, c->stream));
-    for (const Pass& p : plan_passes(g.nctu, nframes, c->max_ctus)) {
-        rc = run_pass(c, c->d_in[0], g, p.ctu0, p.n, qp, c->d_out[0] + (size_t)p.ctu0 * kNOut);
-        if (rc) break;
+    if (banded) {
+        // One big picture (3840x2160: 8.3 MB = 151 us of PCIe against ~100 us of kernels, serial until round 4): the picture is
+        // cut on its gate sub-batch boundaries (1024 CTUs in raster order: video_to_cu_depth.py:61-73, so gate scope is intact) and
+        // the rows the next piece needs travel on the copy stream while the previous piece computes; each piece is one
+        // single-launch pass.  Same passes as a small workspace would plan: results are bit-identical.
+        int rows_done = 0, k = 0;
+        for (int ctu0 = 0; ctu0 < g.nctu && rc == 0; ctu0 += kSubBatch) {
+            const int n = std::min(kSubBatch, g.nctu - ctu0);
+            const int row_end = std::min(h, ((ctu0 + n - 1) / g.cw + 1) * kCtu);
+            hipEvent_t ready = nullptr;
+            if (row_end > rows_done) {
+                if (stage_rows) {  // pageable / pitched caller memory: this piece's rows into the pinned staging buffer first -- while
+                                   // the previous piece's DMA and kernels run
+                    for (int y = rows_done; y < row_end; ++y) std::memcpy(c->h_in[0] + (size_t)y * w, luma + (size_t)y * pitch, (size_t)w);
+                    src = c->h_in[0];
+                }
+                HIPCHK(c, hipMemcpyAsync(c->d_in[0] + (size_t)rows_done * w, src + (size_t)rows_done * w, (size_t)(row_end - rows_done) * w,
+                                         hipMemcpyHostToDevice, c->copy_in));
+                ready = c->e_band[k++ % 4];
+                HIPCHK(c, hipEventRecord(ready, c->copy_in));
+                rows_done = row_end;
+            }
+            rc = run_pass(c, c->d_in[0], g, ctu0, n, qp, c->d_out[0] + (size_t)ctu0 * kNOut, ready);
+        }
+    } else {
+        HIPCHK(c, hipMemcpyAsync(c->d_in[0], src, in_bytes, hipMemcpyHostToDevice, c->stream));
+        for (const Pass& p : plan_passes(g.nctu, nframes, c->max_ctus)) {
+            rc = run_pass(c, c->d_in[0], g, p.ctu0, p.n, qp, c->d_out[0] + (size_t)p.ctu0 * kNOut);
+            if (rc) break;
+        }
     }
     if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
     // (letting the single-launch pass write the probabilities straight into page-locked host memory and report through the

@@ -8,7 +8,7 @@ pkg = importlib.import_module("hevc-complexity-reduction_amd")
 ctx = pkg.EthCnn(0)
 bench.pin_to_gpu_numa_node(ctx.device_name)
 ctx.load_synthetic(1, 8.0)
-for name, w, h in (("416x240", 416, 240), ("768x512", 768, 512), ("1280x720", 1280, 720), ("1920x1080", 1920, 1080), ("3840x2160", 3840, 2160)):
+for name, w, h in (("416x240", 416, 240), ("768x512", 768, 512), ("1280x720", 1280, 720), ("1920x1080", 1920, 1080), ("3840x2160", 3840, 2160), ("4928x3264", 4928, 3264)):
     luma = bench.synth_luma(w, h, 1, 3)
     nctu = pkg.ethcnn.ctus_per_frame(w, h)
     for _ in range(20):

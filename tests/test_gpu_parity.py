@@ -59,7 +59,8 @@ def test_stages_bit_exact(pkg, ctx, oracle, n, gain, qp):
         assert np.array_equal(gP > thr, P > thr)
 
 
-@pytest.mark.parametrize("w,h,frames", [(768, 512, 1), (200, 136, 2), (1920, 1080, 2), (72, 72, 1), (64, 64, 1), (4928, 3264, 1)])
+@pytest.mark.parametrize("w,h,frames", [(768, 512, 1), (200, 136, 2), (1920, 1080, 2), (72, 72, 1), (64, 64, 1), (4928, 3264, 1),
+                                        (3840, 2160, 1), (2560, 1600, 1), (2576, 1600, 1)])
 def test_frames_bit_exact(ctx, oracle, w, h, frames):
     """Zero-padded raster tiling + per-frame 1024-CTU gate scope (4928x3264: 3927 CTUs =
     3x1024 + 855; 72x72: every CTU ragged)."""
