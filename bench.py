@@ -258,7 +258,7 @@ def main():
                                  "bound": "mfma", "achieved": nprod * f_alg, "peak": PEAK_BF16_MFMA_TFLOPS,
                                  "unit": "TFLOP/s (16-bit products issued)", "frac": nprod * f_alg / PEAK_BF16_MFMA_TFLOPS,
                                  "algorithmic_f32_tflops": f_alg, "avg_launch_ms": f_ms, "launches_timed": f_st["timed"]["fc1"],
-                                 "flop_per_ctu_issued": nprod * FC1_FLOP_PER_CTU, "traffic": None,
+                                 "flop_per_ctu_issued": nprod * FC1_FLOP_PER_CTU, **pmc_traffic_fast(args.workload, plan),
                                  "note": "the chip lowers its shader clock under dense 16-bit MFMA streams (profiles/r04_power_probe.txt): "
                                          "the data-sheet peak assumes 2.4 GHz"},
                     "stages_ms_per_step": {k: v / 3.0 for k, v in f_all["ms"].items()},
@@ -648,6 +648,24 @@ def fc1_source_stamp():
     """identifies the FC1 kernel source: the git blob hashes of the two files that hold its device code"""
     src = os.path.join(ROOT, "hevc-complexity-reduction_amd", "csrc")
     return "+".join(git_blob_sha1(os.path.join(src, f))[:12] for f in ("ethcnn_dense.hip", "ethcnn_fc1_tile.h"))
+
+
+def fc1_fast_source_stamp():
+    src = os.path.join(ROOT, "hevc-complexity-reduction_amd", "csrc")
+    return git_blob_sha1(os.path.join(src, "ethcnn_fc1_fast.hip"))[:12]
+
+
+def pmc_traffic_fast(workload, plan):
+    """HBM bytes per k_fc1_fast launch from the committed PMC passes (profiles/fc1_traffic.json, key <workload>_plan<n>), valid only
+    for the kernel source they were taken at"""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "fc1_traffic.json")))["%s_plan%d" % (workload, plan)]
+        if d.get("kernel_source_blob") != fc1_fast_source_stamp():
+            return {"traffic": None, "traffic_note": "profiles/fc1_traffic.json is from another version of ethcnn_fc1_fast.hip: re-run scripts/gpu_round.sh"}
+        return {"traffic": d["bytes_per_launch"], "traffic_unit": "B/launch", "traffic_algorithmic": d["algorithmic_bytes_per_launch"],
+                "traffic_source": d["source"]}
+    except Exception:
+        return {"traffic": None}
 
 
 def git_blob_sha1(path):

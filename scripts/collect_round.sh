@@ -2,7 +2,7 @@
 # copies the judged summaries of the last scripts/gpu_round.sh call from gpurun_out/ (scratch) to profiles/ (tracked)
 # usage: scripts/collect_round.sh r02
 set -eu
-R=${1:-r03}
+R=${1:-r04}
 cd "$(dirname "$0")/.."
 for wl in c2 c3 c4 c5; do [ -s gpurun_out/bench_$wl.json ] && cp gpurun_out/bench_$wl.json profiles/${R}_bench_$wl.json; done
 for wl in c2 c3; do
@@ -17,6 +17,8 @@ if [ -s gpurun_out/latency_mid_now.txt ]; then { grep "^#" profiles/${R}_latency
 [ -s gpurun_out/small_pass_timeline.txt ] && cp gpurun_out/small_pass_timeline.txt profiles/${R}_small_pass_timeline.txt
 [ -s gpurun_out/launch_plans.txt ] && cp gpurun_out/launch_plans.txt profiles/${R}_launch_plans.txt
 [ -s gpurun_out/dist_smoke.json ] && cp gpurun_out/dist_smoke.json profiles/${R}_dist_smoke_2ranks_1gpu.json
+[ -s gpurun_out/power_probe.txt ] && cp gpurun_out/power_probe.txt profiles/${R}_power_probe.txt
+[ -s gpurun_out/ldp_handshake.txt ] && cp gpurun_out/ldp_handshake.txt profiles/${R}_ldp_handshake.txt
 python - "$R" <<'PY'
 import csv, glob, collections, json, sys
 R = sys.argv[1]

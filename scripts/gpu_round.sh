@@ -25,17 +25,13 @@ for e in d.get("cpu_baselines", []): print("cpu:", {k: e.get(k) for k in ("name"
 print("host_scopes:", d.get("host_scopes"))
 PY
 python scripts/latency.py > gpurun_out/latency.txt 2>&1; cat gpurun_out/latency.txt
-{ echo "# the same with the single-launch small pass OFF (ETHCNN_SMALL=0: tile / trunk / FC1 / heads / gate launches)"; ETHCNN_SMALL=0 python scripts/latency.py; } > gpurun_out/latency_five_launches.txt 2>&1; cat gpurun_out/latency_five_launches.txt
-if [ -x scripts/ubench/small_probe ]; then (cd scripts/ubench && ./small_probe 1920 1080 0 && ./small_probe 1920 1080 1 && ./small_probe 768 512 0 && ./small_probe 3840 2160 0) > gpurun_out/small_pass_timeline.txt 2>&1; cat gpurun_out/small_pass_timeline.txt; fi
-# launch plans of the big pass, same box, back to back (plan 0 = default)
-for rep in 1 2; do for plan in "0:" "1:ETHCNN_FUSED=1" "2:ETHCNN_GATE_FOLD=1"; do
-  env ${plan#*:} python bench.py --no-cpu-baseline --no-host-scopes --steps 30 > gpurun_out/plan${plan%%:*}_$rep.json 2>/dev/null
-done; done
-python scripts/summarize.py "gpurun_out/plan*.json" | tee gpurun_out/launch_plans.txt
+# (development knobs are read by the experiments build only: ETHCNN_LIB selects it)
+EXP=$REPO/hevc-complexity-reduction_amd/lib_exp/libethcnn.so
+{ echo "# the same with the single-launch small pass OFF (experiments build, ETHCNN_SMALL=0: tile / trunk / FC1 / heads / gate launches)"; ETHCNN_LIB=$EXP ETHCNN_SMALL=0 python scripts/latency.py; } > gpurun_out/latency_five_launches.txt 2>&1; cat gpurun_out/latency_five_launches.txt
+python scripts/power_probe.py 2500 > gpurun_out/power_probe.txt 2>&1; tail -70 gpurun_out/power_probe.txt
+python scripts/ldp_handshake.py 1000 > gpurun_out/ldp_handshake.txt 2>&1; cut -c1-200 gpurun_out/ldp_handshake.txt
 python scripts/latency_ldp.py --cpu > gpurun_out/latency_ldp.txt 2>&1; cat gpurun_out/latency_ldp.txt
 python scripts/latency_host.py > gpurun_out/latency_host.txt 2>&1; cat gpurun_out/latency_host.txt
-python scripts/latency_mid.py > gpurun_out/latency_mid_now.txt 2>&1; cat gpurun_out/latency_mid_now.txt
-if [ -x scripts/ubench/lstm_probe ]; then (cd scripts/ubench && ./lstm_probe 1920 1080 && ./lstm_probe 832 480) > gpurun_out/lstm_timeline.txt 2>&1; cat gpurun_out/lstm_timeline.txt; fi
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_$WL -o $WL -- python $REPO/bench.py --workload $WL --no-cpu-baseline --no-host-scopes > $REPO/gpurun_out/prof_$WL.log 2>&1
 cd $REPO
@@ -58,7 +54,7 @@ def per_step(tag, counter):
     tot, steps = 0.0, 0
     for f in glob.glob("gpurun_out/pmc_%s_%s/**/*counter_collection.csv" % (wl, tag), recursive=True):
         for r in csv.DictReader(open(f)):
-            if "k_fc1" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+            if "k_fc1" in r["Kernel_Name"] and "k_fc1_fast" not in r["Kernel_Name"] and r["Counter_Name"] == counter:
                 tot += float(r["Counter_Value"])
                 steps += 1 if ("k_fc1_bulk" in r["Kernel_Name"] or "<2, 7, 4, 1" in r["Kernel_Name"]) else 0
     return (tot / steps, steps) if steps else (None, 0)
@@ -71,10 +67,23 @@ if fe is not None and wr is not None:
                 "bytes_per_launch": int(fe*1024*2 + wr*1024), "fetch_size_kb_reported": fe, "write_size_kb_reported": wr,
                 "steps_averaged": n1, "algorithmic_bytes_per_launch": n*2688*4 + 2688*448*4 + n*448*4,
                 "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of `python bench.py --workload %s --no-cpu-baseline --no-host-scopes --steps 5 --warmup 1` (scripts/gpu_round.sh), summed over the FC1 dispatches of a step; FETCH_SIZE x2 (gfx950 correction)" % wl}}
+    # the fast plans' FC1 kernel (bench.py runs all three plans): one dispatch per step each
+    for plan in (1, 2):
+        def fast(tag, counter):
+            v = [float(r["Counter_Value"]) for f in glob.glob("gpurun_out/pmc_%s_%s/**/*counter_collection.csv" % (wl, tag), recursive=True)
+                 for r in csv.DictReader(open(f)) if "k_fc1_fast<%d" % plan in r["Kernel_Name"] and r["Counter_Name"] == counter]
+            return (sum(v) / len(v), len(v)) if v else (None, 0)
+        (ffe, k1), (fwr, k2) = fast("FETCH_SIZE", "FETCH_SIZE"), fast("WRITE_SIZE", "WRITE_SIZE")
+        if ffe is not None and fwr is not None:
+            npieces = 3 if plan == 1 else 2
+            out["%s_plan%d" % (wl, plan)] = {"kernel_source_blob": bench.fc1_fast_source_stamp(),
+                "bytes_per_launch": int(ffe*1024*2 + fwr*1024), "fetch_size_kb_reported": ffe, "write_size_kb_reported": fwr, "steps_averaged": k1,
+                "algorithmic_bytes_per_launch": n*2688*2*npieces + 2688*448*2*npieces + n*448*4,
+                "source": "the same passes, dispatches of k_fc1_fast<%d, 7> (FETCH_SIZE x2)" % plan}
     json.dump(out, open("gpurun_out/fc1_traffic_%s.json" % wl,"w"), indent=1); print("fc1 traffic:", out)
 PY
 }
-PMCS=("FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"); pmc_passes
+PMCS=("FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA"); pmc_passes
 if [ "$WL" = c3 ]; then WL=c2; PMCS=("FETCH_SIZE" "WRITE_SIZE"); pmc_passes; WL=c3; fi
 head -12 gpurun_out/prof_$WL/${WL}_kernel_stats.csv
 python - <<'PY'
