@@ -56,6 +56,16 @@ int fast_feature_k(int chunk, int kh, int idx);
 // plan 2: a bound no feature of an All-Intra CTU can exceed (|input| <= 1 after mean removal; per-channel bounds pushed through
 // the three conv layers of every branch) -- the feature scale 2^s is chosen from it so that no fp16 piece can overflow
 float fast_feature_bound(const float* blob);
+// ---- plan 3: the trunk's three conv layers on the 16-bit matrix pipe as well (fp16 x 2 splits; ethcnn_trunk_fast.hip).
+// Per branch, A operands as fp16 pieces in MFMA order (halves): [conv1: 4 fragments x 64 lanes x 4 = piece 0, piece 1, 16 x piece 0,
+// 16 x piece 1 (the last two for the L branch's high pixel-sum digits)][conv2: (t, s, piece) 8 fragments x 64 x 8][conv3: (t, s,
+// piece) 12 fragments x 64 x 8]; per-lane constants (floats): [24 slots x 64 lanes]: conv1 -S1 Wsum (4), S1 b1 (4), conv2 sa b2
+// (t, r: 8), conv3 sa b3 (t, r: 8); scalars per branch: C1 = c255 2^-p 2^-sw1 S1, U2 = sa / (S1 2^sw2), U3 = 2^-sw3.
+constexpr int kTrunk16Halves = 4 * 64 * 4 + 8 * 64 * 8 + 12 * 64 * 8;  // 11,264 per branch
+constexpr int kTrunk16Conv2At = 4 * 64 * 4, kTrunk16Conv3At = kTrunk16Conv2At + 8 * 64 * 8;
+constexpr int kTrunk16Consts = 24 * 64;
+struct Trunk16Scalars { float C1[3], U2[3], U3[3]; };
+void pack_trunk_f16(const float* blob, float scale_a, uint16_t* w_out /*[3][kTrunk16Halves]*/, float* c_out /*[3][kTrunk16Consts]*/, Trunk16Scalars* sc);
 // fp32 <-> IEEE binary16 on the host (round to nearest even, subnormals kept: what v_cvt_pk_f16_f32 / v_cvt_f32_f16 do on the device)
 inline uint16_t f16_rne(float x) {
     uint32_t u;
@@ -180,6 +190,9 @@ struct DeviceWeights {
     // FC1 plans 1 / 2: W1 as NP 16-bit pieces in the 32x32x16 MFMA's B-operand order, [168 chunks][14 column tiles of 32][NP pieces]
     // [1 KiB = [k half][32 columns][8]], k order = fast_feature_k (pack_fc1_fast_image); index = plan - 1
     uint16_t* fc1_fast[2] = {nullptr, nullptr};
+    uint16_t* trunk16_w = nullptr;  // plan 3: [3][kTrunk16Halves]
+    float* trunk16_c = nullptr;     //         [3][kTrunk16Consts]
+    Trunk16Scalars trunk16_s{};
     float fast_scale_a = 1.0f, fast_scale_w = 1.0f;  // plan 2: powers of two applied to features / W1 before the fp16 split
     float* fc1_b = nullptr;    // [448]
     float* fc2_w[3] = {nullptr, nullptr, nullptr};  // [n1+1][n2] (last row = qp row)

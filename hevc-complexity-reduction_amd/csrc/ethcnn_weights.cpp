@@ -316,6 +316,94 @@ float fast_feature_bound(const float* blob) {
     return (float)(worst * 1.0001);
 }
 
+// ---- plan 3: trunk A operands as fp16 x 2 pieces (ethcnn_trunk_fast.hip)
+static void f16x2(float x, uint16_t* hi, uint16_t* lo) {
+    *hi = f16_rne(x);
+    *lo = f16_rne(x - f16_f32(*hi));
+}
+static float pow2_scale(double maxabs) {  // the power of two that puts maxabs at <= 2^14 (fp16 overflows at 65504)
+    return std::exp2f(14.0f - std::ceil(std::log2((float)maxabs)));
+}
+void pack_trunk_f16(const float* blob, float scale_a, uint16_t* w_out, float* c_out, Trunk16Scalars* sc) {
+    for (int br = 0; br < 3; ++br) {
+        const float* W1 = blob + kOffConvW[br][0];  // [4][4][1][16]
+        const float* W2 = blob + kOffConvW[br][1];  // [2][2][16][24]
+        const float* W3 = blob + kOffConvW[br][2];  // [2][2][24][32]
+        const float* B1 = blob + kOffConvB[br][0];
+        const float* B2 = blob + kOffConvB[br][1];
+        const float* B3 = blob + kOffConvB[br][2];
+        uint16_t* w = w_out + (size_t)br * kTrunk16Halves;
+        float* c = c_out + (size_t)br * kTrunk16Consts;
+        double m1 = 0, m2 = 0, m3 = 0, bound1 = 0;
+        for (int i = 0; i < 16 * 16; ++i) m1 = std::max(m1, (double)std::fabs(W1[i]));
+        for (int i = 0; i < 64 * 24; ++i) m2 = std::max(m2, (double)std::fabs(W2[i]));
+        for (int i = 0; i < 96 * 32; ++i) m3 = std::max(m3, (double)std::fabs(W3[i]));
+        double wsum[16];
+        for (int co = 0; co < 16; ++co) {
+            double sabs = std::fabs((double)B1[co]), ssum = 0;
+            for (int t = 0; t < 16; ++t) { sabs += std::fabs((double)W1[t * 16 + co]); ssum += (double)W1[t * 16 + co]; }
+            wsum[co] = ssum;
+            bound1 = std::max(bound1, sabs);  // |input| <= 1
+        }
+        // conv1 weights are multiplied by pixel SUMS up to 255 (S), 1020 (M), 255 / 15 (L digits): exact products need no headroom,
+        // only the scaled pieces must stay finite: 2^10 leaves room for the x 16 copy of the L branch
+        const float s1w = std::exp2f(10.0f - std::ceil(std::log2((float)m1)));
+        const float s2w = pow2_scale(m2), s3w = pow2_scale(m3);
+        const float S1 = pow2_scale(bound1 * 1.0001);
+        const int pool = br == 0 ? 1 : (br == 1 ? 2 : 4);
+        const float c255s = (1.0f / 255.0f) * (1.0f / (float)(pool * pool));
+        sc->C1[br] = c255s * (1.0f / s1w) * S1;  // powers of two around c255s: exact
+        sc->U2[br] = scale_a / (S1 * s2w);
+        sc->U3[br] = 1.0f / s3w;
+        for (int lane = 0; lane < 64; ++lane) {
+            const int row = lane & 15, kb = lane >> 4;
+            for (int i = 0; i < 4; ++i) {  // conv1: k = 4 kb + i = (ky = kb, kx = i)
+                const float v = W1[(kb * 4 + i) * 16 + row] * s1w;
+                uint16_t hi, lo, hi16, lo16;
+                f16x2(v, &hi, &lo);
+                f16x2(v * 16.0f, &hi16, &lo16);
+                w[(0 * 64 + lane) * 4 + i] = hi;
+                w[(1 * 64 + lane) * 4 + i] = lo;
+                w[(2 * 64 + lane) * 4 + i] = hi16;
+                w[(3 * 64 + lane) * 4 + i] = lo16;
+            }
+            for (int t = 0; t < 2; ++t)
+                for (int st = 0; st < 2; ++st)
+                    for (int i = 0; i < 8; ++i) {  // conv2: k step st covers patches 2 st, 2 st + 1; ci = 4 kb + (i & 3)
+                        const int q1 = 2 * st + (i >> 2), ci = 4 * kb + (i & 3), co = 16 * t + row;
+                        const float v = co < 24 ? W2[(q1 * 16 + ci) * 24 + co] * s2w : 0.0f;
+                        uint16_t hi, lo;
+                        f16x2(v, &hi, &lo);
+                        w[kTrunk16Conv2At + (((t * 2 + st) * 2 + 0) * 64 + lane) * 8 + i] = hi;
+                        w[kTrunk16Conv2At + (((t * 2 + st) * 2 + 1) * 64 + lane) * 8 + i] = lo;
+                    }
+            for (int t = 0; t < 2; ++t)
+                for (int st = 0; st < 3; ++st)
+                    for (int i = 0; i < 8; ++i) {
+                        int q2, ci;
+                        if (st < 2) { q2 = 2 * st + (i >> 2); ci = 4 * kb + (i & 3); }                          // channels 0..15 of two positions
+                        else { q2 = 2 * (i >> 2) + (kb >> 1); ci = 16 + 4 * (kb & 1) + (i & 3); }                // channels 16..23, the packed quads
+                        const float v = W3[(q2 * 24 + ci) * 32 + 16 * t + row] * s3w;
+                        uint16_t hi, lo;
+                        f16x2(v, &hi, &lo);
+                        w[kTrunk16Conv3At + (((t * 3 + st) * 2 + 0) * 64 + lane) * 8 + i] = hi;
+                        w[kTrunk16Conv3At + (((t * 3 + st) * 2 + 1) * 64 + lane) * 8 + i] = lo;
+                    }
+            // constants of C-layout rows 4 g + r (g = kb here: lane = col + 16 g)
+            for (int r = 0; r < 4; ++r) {
+                const int ch = 4 * kb + r;
+                c[(0 + r) * 64 + lane] = (float)(-(double)S1 * wsum[ch]);
+                c[(4 + r) * 64 + lane] = S1 * B1[ch];
+                for (int t = 0; t < 2; ++t) {
+                    const int co = 16 * t + ch;
+                    c[(8 + t * 4 + r) * 64 + lane] = co < 24 ? scale_a * B2[co] : 0.0f;
+                    c[(16 + t * 4 + r) * 64 + lane] = scale_a * B3[co];
+                }
+            }
+        }
+    }
+}
+
 void pack_fc2_lane_image(const float* w2, int n1, int n2, float* img) {
     for (int j = 0; j < n2 / 16; ++j)
         for (int kc = 0; kc < n1 / 16; ++kc)

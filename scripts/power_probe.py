@@ -11,16 +11,29 @@ def rd(p):
         return None
 def pwf(h):
     return h + ("/power1_average" if os.path.exists(h + "/power1_average") else "/power1_input")
-cap = rd(hw[0] + "/power1_cap")
-print("cap W:", cap and cap / 1e6, " (%d GPUs visible in sysfs: the busiest one is the job's)" % len(hw))
+# the job's GPU among the node's: by PCI address (HIP sees one device, sysfs all eight)
+import ctypes
+mine = None
+try:
+    hip = ctypes.CDLL("libamdhip64.so")
+    buf = ctypes.create_string_buffer(64)
+    if hip.hipDeviceGetPCIBusId(buf, 64, 0) == 0:
+        bdf = buf.value.decode().lower()
+        for h in hw:
+            if os.path.realpath(os.path.join(h, "..", "..")).lower().endswith(bdf):
+                mine = h
+except Exception as exc:
+    print("PCI lookup failed:", exc)
+cap = rd((mine or hw[0]) + "/power1_cap")
+print("cap W:", cap and cap / 1e6, " job's GPU:", mine or "unknown (the busiest of %d is taken)" % len(hw))
 p = subprocess.Popen([sys.executable, "bench.py", "--no-cpu-baseline", "--no-host-scopes", "--steps", steps], stdout=open("gpurun_out/power_bench.json", "w"), stderr=subprocess.DEVNULL)
 t0 = time.time()
 rows = []
 while p.poll() is None:
-    best = max(hw, key=lambda h: rd(pwf(h)) or 0)
+    best = mine or max(hw, key=lambda h: rd(pwf(h)) or 0)
     rows.append((time.time() - t0, rd(pwf(best)), rd(best + "/freq1_input"), best.split("/")[4]))
     time.sleep(0.02)
-print("samples", len(rows))
+print("samples", len(rows), "(20 ms apart; bench.py runs its exact region, then plan 1, then plan 2)")
 for i in range(0, len(rows), max(1, len(rows) // 60)):
     t, w, f, name = rows[i]
     print("t %6.2f s  %s power %7.1f W  sclk %s MHz" % (t, name, (w or 0) / 1e6, (f or 0) / 1e6))
