@@ -206,7 +206,7 @@ def main():
     fast = {}
     if not ldp and not args.no_fast_plan:
         exact_out = d_out.download(np.float32, ctus_per_step * 21).reshape(-1, 21) if rank == 0 else None
-        for plan in (1, 2):
+        for plan in (1, 2, 3):
             ctx.set_profiling(0)
             ctx.set_fc1_plan(plan)
             t_ramp = time.perf_counter()
@@ -245,20 +245,22 @@ def main():
                 f_alg = FC1_FLOP_PER_CTU * f_st["timed_ctus"]["fc1"] / (f_st["ms"]["fc1"] * 1e-3) / 1e12 if f_st["ms"]["fc1"] > 0 else 0.0
                 same_zero = bool(np.array_equal(fast_out == 0.0, exact_out == 0.0))
                 nprod = 6 if plan == 1 else 3
+                fc1_plan = 2 if plan == 3 else plan
                 fast[plan] = {
                     "value": ctus_per_step * args.steps * world / f_elapsed, "unit": "CTU/s", "ms_per_step": f_elapsed / args.steps * 1e3,
                     "dtype": ("bf16x3 split, f32 accumulate" if plan == 1 else "fp16x2 split (power-of-two scaled), f32 accumulate") +
-                             " (FC1 only; trunk, heads and gates exact f32 as in `value`)",
+                             (" (FC1 only; trunk, heads and gates exact f32 as in `value`)" if plan < 3 else
+                              " (FC1 AND the trunk's three conv layers; heads and gates exact f32 as in `value`)"),
                     "plan": "ethcnn_set_fc1_plan(ctx, %d): " % plan +
                             ("every fp32 feature / weight as three bf16 pieces (exact split), the six products with i + j <= 2 on "
                              "v_mfma_f32_32x32x16_bf16" if plan == 1 else
                              "every scaled fp32 feature / weight as two fp16 pieces (2^-24 relative), three products on "
                              "v_mfma_f32_32x32x16_f16") + "; opt-in, never the default",
-                    "roofline": {"kernel": "k_fc1_fast<%d,7> (FC1 [N,2688]x[2688,448] as %d 16-bit products per fp32 product)" % (plan, nprod),
+                    "roofline": {"kernel": "k_fc1_fast<%d,7> (FC1 [N,2688]x[2688,448] as %d 16-bit products per fp32 product)" % (fc1_plan, nprod),
                                  "bound": "mfma", "achieved": nprod * f_alg, "peak": PEAK_BF16_MFMA_TFLOPS,
                                  "unit": "TFLOP/s (16-bit products issued)", "frac": nprod * f_alg / PEAK_BF16_MFMA_TFLOPS,
                                  "algorithmic_f32_tflops": f_alg, "avg_launch_ms": f_ms, "launches_timed": f_st["timed"]["fc1"],
-                                 "flop_per_ctu_issued": nprod * FC1_FLOP_PER_CTU, **pmc_traffic_fast(args.workload, plan),
+                                 "flop_per_ctu_issued": nprod * FC1_FLOP_PER_CTU, **pmc_traffic_fast(args.workload, fc1_plan),
                                  "note": "the chip lowers its shader clock under dense 16-bit MFMA streams (profiles/r04_power_probe.txt): "
                                          "the data-sheet peak assumes 2.4 GHz"},
                     "stages_ms_per_step": {k: v / 3.0 for k, v in f_all["ms"].items()},
@@ -339,6 +341,8 @@ def main():
             result["fast_plan"] = fast[1]
         if 2 in fast:
             result["fast_plan_fp16x2"] = fast[2]
+        if 3 in fast:
+            result["fast_plan_fp16x2_trunk"] = fast[3]
         if sharded is not None:
             result["host_scopes"] = sharded
         if not ldp and not (args.no_host_scopes and args.no_cpu_baseline):

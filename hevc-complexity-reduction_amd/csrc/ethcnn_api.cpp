@@ -193,6 +193,7 @@ struct ethcnn_ctx {
     int fc1_plan = 0;        // 0 = exact fp32 FC1 (default; bit-identical to the oracle); 1 / 2 = "fast": FC1 of the multi-launch path on the
                              // 16-bit matrix pipe with split operands, bf16 x 3 / fp16 x 2 (ethcnn_fc1_fast.hip; ethcnn_set_fc1_plan, env ETHCNN_FC1_PLAN)
     uint16_t* dw_fast[2] = {nullptr, nullptr};  // W1 in the form of plan 1 / 2 (packed on first use), 7.2 / 4.8 MB
+    uint16_t* dw_trunk16 = nullptr;             // plan 3: the trunk's A operands as fp16 x 2 pieces + its per-lane constants (one allocation)
     int last_fast = 0;       // the FC1 plan of the last pass (debug_fetch reads the features of plans 1 / 2 from ws.featb)
     int fused = 0;           // 1 = big passes run FC1 + heads + gates as ONE launch (ethcnn_set_fused_launch, env ETHCNN_FUSED=1).
                              // Off by default: measured equal-to-1 % slower than the separate launches
@@ -362,7 +363,7 @@ extern "C" int ethcnn_create(ethcnn_ctx** out, const ethcnn_options* opt) {
     if (const char* e = dev_env("ETHCNN_SMALL")) c->small_launch = std::atoi(e) != 0;  // development knob (A/B runs)
     if (const char* e = std::getenv("ETHCNN_FC1_PLAN")) {  // user-facing: start contexts in FC1 plan 1 / 2
         const int pl = std::atoi(e);
-        c->fc1_plan = (pl == 1 || pl == 2) ? pl : 0;
+        c->fc1_plan = (pl >= 1 && pl <= 3) ? pl : 0;
     }
     if (const char* e = dev_env("ETHCNN_FUSED")) c->fused = std::atoi(e) != 0;      // development knob (A/B runs)
     if (const char* e = dev_env("ETHCNN_GATE_FOLD")) c->gate_fold = std::atoi(e) != 0;  // development knob (A/B runs)
@@ -458,6 +459,7 @@ extern "C" void ethcnn_destroy(ethcnn_ctx* c) {
     if (c->dw_arena) (void)hipFree(c->dw_arena);
     for (uint16_t* q : c->dw_fast)
         if (q) (void)hipFree(q);
+    if (c->dw_trunk16) (void)hipFree(c->dw_trunk16);
     {
         void* lp[] = {c->d_lstm, c->d_vec, c->d_state[0], c->d_state[1], c->d_lprobs, c->d_lgate, c->d_ssync};
         for (void* p : lp)
@@ -536,12 +538,29 @@ static int upload_weights(ethcnn_ctx* c) {
         d.fc3_b[h] = c->dw_arena + offs[11 + 2 * h];
     }
     d.fc1_fast[0] = d.fc1_fast[1] = nullptr;  // the fast plans' images of W1 belong to the previous weights: repacked on the next such pass
+    d.trunk16_w = nullptr;
+    d.trunk16_c = nullptr;
     c->have_weights = true;
     return ETHCNN_OK;
 }
 
 // plans 1 / 2: W1 as 16-bit pieces in the MFMA's B-operand order (ethcnn_weights.cpp::pack_fc1_fast_image), once per weight load
 static int ensure_fast_weights(ethcnn_ctx* c, int plan) {
+    if (plan == 3) {  // plan 3 = plan 2's FC1 + the trunk's convolutions as fp16 x 2 (ethcnn_trunk_fast.hip)
+        int rc = ensure_fast_weights(c, 2);
+        if (rc || c->dw.trunk16_w) return rc;
+        const size_t wbytes = (size_t)3 * kTrunk16Halves * 2, cbytes = (size_t)3 * kTrunk16Consts * 4;
+        std::vector<uint16_t> wimg((size_t)3 * kTrunk16Halves);
+        std::vector<float> cimg((size_t)3 * kTrunk16Consts);
+        pack_trunk_f16(c->blob.data(), c->dw.fast_scale_a, wimg.data(), cimg.data(), &c->dw.trunk16_s);
+        if (!c->dw_trunk16) HIPCHK(c, hipMalloc((void**)&c->dw_trunk16, wbytes + cbytes));
+        HIPCHK(c, hipDeviceSynchronize());
+        HIPCHK(c, hipMemcpy(c->dw_trunk16, wimg.data(), wbytes, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(reinterpret_cast<char*>(c->dw_trunk16) + wbytes, cimg.data(), cbytes, hipMemcpyHostToDevice));
+        c->dw.trunk16_w = c->dw_trunk16;
+        c->dw.trunk16_c = reinterpret_cast<float*>(reinterpret_cast<char*>(c->dw_trunk16) + wbytes);
+        return 0;
+    }
     if (c->dw.fc1_fast[plan - 1]) return 0;
     const size_t n16 = (size_t)kNFeat * kNVec * fast_pieces(plan);
     std::vector<float> wcat((size_t)kNFeat * kNVec), b1(kNVec);
@@ -715,7 +734,8 @@ extern "C" int ethcnn_set_fused_launch(ethcnn_ctx* c, int on) {
 
 extern "C" int ethcnn_set_fc1_plan(ethcnn_ctx* c, int plan) {
     if (!c) return ETHCNN_ERR_ARG;
-    if (plan < 0 || plan > 2) return set_err(c, ETHCNN_ERR_ARG, "FC1 plan must be 0 (exact fp32, default), 1 (bf16 x 3 split) or 2 (fp16 x 2 split), got %d", plan);
+    if (plan < 0 || plan > 3)
+        return set_err(c, ETHCNN_ERR_ARG, "plan must be 0 (exact fp32, default), 1 (FC1 bf16 x 3), 2 (FC1 fp16 x 2) or 3 (FC1 and trunk fp16 x 2), got %d", plan);
     c->fc1_plan = plan;  // takes effect with the next pass enqueued
     return ETHCNN_OK;
 }
@@ -883,13 +903,13 @@ static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, lo
     }
     const int fast = c->fc1_plan;  // FC1 plans 1 / 2: trunk -> 16-bit feature pieces -> FC1 on the 16-bit matrix pipe
     if (fast && (rc = ensure_fast_weights(c, fast)) != 0) return rc;
-    { StageTimer t(c, ETHCNN_STAGE_TRUNK); launch_trunk(w, c->dw, n, false, c->stream, fast); }
+    { StageTimer t(c, ETHCNN_STAGE_TRUNK); if (fast == 3) launch_trunk_f16(w, c->dw, n, c->stream); else launch_trunk(w, c->dw, n, false, c->stream, fast); }
     LAUNCH_OK("trunk");
     if (side_tile) HIPCHK(c, hipEventRecord(c->e_trunk[p], c->stream));
     Workspace wv = w;
     if (!c->debug_capture) wv.h2 = wv.logits = wv.raw = nullptr;
     if (fast) {
-        { StageTimer t(c, ETHCNN_STAGE_FC1, n); launch_fc1_fast(w, c->dw, n, w.h1, fast, c->stream); }
+        { StageTimer t(c, ETHCNN_STAGE_FC1, n); launch_fc1_fast(w, c->dw, n, w.h1, fast == 3 ? 2 : fast, c->stream); }
         LAUNCH_OK("FC1 (plan 1 / 2)");
         { StageTimer t(c, ETHCNN_STAGE_HEADS); launch_heads(wv, c->dw, n, qn, g.nctu, ctu0, c->thr1, c->thr2, d_probs_pass, c->stream, c->gate_fold ? (int)nchunks : 0); }
         if (!c->gate_fold) { StageTimer t(c, ETHCNN_STAGE_GATE); launch_gate(w, n, g.nctu, ctu0, c->thr2, d_probs_pass, c->stream); }
@@ -1699,7 +1719,7 @@ extern "C" int ethcnn_debug_fetch(ethcnn_ctx* c, int which, float* out, size_t n
     if (c->last_fast) {
         // plans 1 / 2: the trunk left every feature as 16-bit pieces: add them back (plan 1: the sum IS the feature, the split is
         // exact; plan 2: (h0 + h1) / scale, equal to the feature to 2^-24 relative)
-        const int plan = c->last_fast, np = fast_pieces(plan);
+        const int plan = c->last_fast == 3 ? 2 : c->last_fast, np = fast_pieces(plan);  // (plan 3 writes plan 2's form)
         const size_t n = (nfloats + kNFeat - 1) / kNFeat, pairs = (n + 31) / 32;
         std::vector<uint16_t> rawb(pairs * (size_t)(fast_pair_bytes(plan) / 2));
         int rc = ethcnn_memcpy_d2h(c, rawb.data(), c->ws.featb, rawb.size() * 2);

@@ -7,7 +7,7 @@ for f in sorted(glob.glob(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/v*.j
             f.split("/")[-1], d["value"] / 1e6, d["roofline"]["avg_launch_ms"], d["roofline"]["achieved"], d["roofline"]["frac"],
             "; box %.1f TF -> %.3f" % (box, d["roofline"]["achieved"] / box) if box else "",
             {k: round(x, 3) for k, x in d["stages_ms_per_step"].items()}, d.get("parity_first_frame_bit_exact")))
-        for key in ("fast_plan", "fast_plan_fp16x2"):
+        for key in ("fast_plan", "fast_plan_fp16x2", "fast_plan_fp16x2_trunk"):
           fp = d.get(key)
           if fp:
             print("    " + key + ": value %.2fM CTU/s  %.3f ms/step  fc1 %.3f ms (frac of bf16 peak %.3f)  stages %s  max|d| %s flips %s" % (

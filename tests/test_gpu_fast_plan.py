@@ -31,7 +31,7 @@ def _mixed_ctus(rng, n):
     return ctus
 
 
-@pytest.fixture(params=[1, 2], ids=["bf16x3", "fp16x2"])
+@pytest.fixture(params=[1, 2, 3], ids=["bf16x3", "fp16x2", "fp16x2+trunk"])
 def fast_ctx(pkg, request):
     c = pkg.EthCnn(device=0)
     c.set_small_pass_launch(False)  # the fast plans live in the multi-launch path; small test batches must take it too
@@ -57,8 +57,14 @@ def test_stages_under_the_fast_plans(pkg, fast_ctx, oracle, n, gain, qp):
     gF = c.debug_fetch(e.DBG_FEATURES, n)  # the 16-bit pieces of every feature, added back on the host
     if plan == 1:
         assert np.array_equal(_bits(gF), _bits(F)), "the split features are not the oracle's features: max |d| = %g" % np.abs(gF - F).max()
-    else:  # two fp16 pieces: 2^-24 relative while the low piece is a normal number, 2^-25 of the scaled unit below that
+    elif plan == 2:  # two fp16 pieces: 2^-24 relative while the low piece is a normal number, 2^-25 of the scaled unit below that
         assert np.all(np.abs(gF - F) <= np.abs(F) * 2.0 ** -23 + 2.0 ** -30), np.abs(gF - F).max()
+    else:  # plan 3: the convolutions themselves run as fp16 x 2 products with other rounding points: fp32-class agreement, relative
+        # to the scale of a CTU's features (a conv output is a signed sum: its own magnitude can be far below its terms')
+        r64 = oracle.forward64(blob, ctus, qp)["F"]
+        fscale = np.abs(F).max(axis=1, keepdims=True) + 1e-30
+        assert (np.abs(gF - F) / fscale).max() <= 2e-6, (np.abs(gF - F) / fscale).max()
+        assert (np.abs(gF - r64) / fscale).max() <= 3.0 * (np.abs(F - r64) / fscale).max() + 2e-7
     H1 = oracle.fc1(blob, F)
     gH1 = c.debug_fetch(e.DBG_FC1, n)
     scale = max(1.0, float(np.abs(H1).max()))
@@ -108,7 +114,7 @@ def test_reference_graph_golden_under_the_fast_plans(fast_ctx, oracle):
     assert total >= 2000
 
 
-@pytest.mark.parametrize("plan", [1, 2])
+@pytest.mark.parametrize("plan", [1, 2, 3])
 @pytest.mark.parametrize("w,h,frames,qp", [(3840, 2160, 3, 32), (1920, 1080, 6, 22), (4928, 3264, 1, 27), (200, 136, 2, 37)])
 def test_frames_under_the_fast_plans(pkg, oracle, w, h, frames, qp, plan):
     """Sampled C2 / C3 / C4 frames (and a ragged small one): ungated probabilities within 1e-4 of the oracle and of
@@ -154,7 +160,7 @@ def test_frames_under_the_fast_plans(pkg, oracle, w, h, frames, qp, plan):
         assert edge, "gate patterns differ without a knife-edge sub-batch maximum"
 
 
-@pytest.mark.parametrize("plan", [1, 2])
+@pytest.mark.parametrize("plan", [1, 2, 3])
 def test_plan_env_and_file_entry(pkg, oracle, tmp_path, plan):
     """ETHCNN_FC1_PLAN=1|2 starts contexts in that plan; the file entry point (staging ring, several passes) takes it."""
     import subprocess
