@@ -909,7 +909,7 @@ static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, lo
     Workspace wv = w;
     if (!c->debug_capture) wv.h2 = wv.logits = wv.raw = nullptr;
     if (fast) {
-        { StageTimer t(c, ETHCNN_STAGE_FC1, n); launch_fc1_fast(w, c->dw, n, w.h1, fast == 3 ? 2 : fast, c->stream); }
+        { StageTimer t(c, ETHCNN_STAGE_FC1, n); launch_fc1_fast(w, c->dw, n, w.h1, fast == 3 ? 2 : fast, c->stream, c->cus); }
         LAUNCH_OK("FC1 (plan 1 / 2)");
         { StageTimer t(c, ETHCNN_STAGE_HEADS); launch_heads(wv, c->dw, n, qn, g.nctu, ctu0, c->thr1, c->thr2, d_probs_pass, c->stream, c->gate_fold ? (int)nchunks : 0); }
         if (!c->gate_fold) { StageTimer t(c, ETHCNN_STAGE_GATE); launch_gate(w, n, g.nctu, ctu0, c->thr2, d_probs_pass, c->stream); }

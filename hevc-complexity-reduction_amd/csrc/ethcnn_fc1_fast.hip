@@ -68,21 +68,39 @@ template <> struct FastPlan<2> {
     static constexpr int PA[3] = {0, 1, 0}, PB[3] = {0, 0, 1};
 };
 
-template <int PLAN, int NS>
+// NINE: the stage also holds a NINTH row tile (below): one more A record per chunk
+template <int PLAN, int NS, bool NINE = false>
 struct FastShape {
     static constexpr int WM = 8, NST = 3, NP = FastPlan<PLAN>::NP;
-    static constexpr int PIECES = NP * (WM + NS);          // 1 KiB pieces per stage
+    static constexpr int ROWS = WM + (NINE ? 1 : 0);
+    static constexpr int PIECES = NP * (ROWS + NS);        // 1 KiB pieces per stage
     static constexpr int PER = (PIECES + WM - 1) / WM;     // DMA instructions per wave per chunk (the tail repeats the last piece)
     static constexpr int STAGE = PIECES * 1024;
-    static constexpr int LDS_BYTES = NST * STAGE;          // plan 1: 135 KB, plan 2: 90 KB
+    static constexpr int LDS_BYTES = NST * STAGE;          // plan 1: 135 KB, plan 2: 90 KB (96 KB with the ninth row tile)
 };
 
-template <int PLAN, int NS>
+// M tiles of a launch.  k_fc1_fast keeps ONE block per CU, so a grid runs in rounds of `cus` blocks, and C3's 3188 row tiles of 32
+// CTUs made 399 M tiles x 2 column halves = 798 blocks = 3.12 rounds: a fourth round for 4 % of the work (20 % of the stage).
+// NINE: the number of M tiles is cut to whole rounds (tiles = a multiple of cus / 2) and the row tiles left over -- fewer than
+// one per M tile -- are handed out one each to the first `extra` M tiles as a NINTH row tile, which the block's waves 0..6 share:
+// wave w multiplies it with column tile w (whose B fragments it holds anyway): 3 more MFMAs per chunk on one more accumulator.
+// Those blocks take 8/7 of a block time; the launch ends after 3 rounds + 1/7 instead of 4.
+struct FastTiles {
+    int tiles, extra;  // M tile t owns row tiles [8 t + min(t, extra), ... + 8 + (t < extra))
+};
+static inline FastTiles fast_tiles(int npairs, int cus, bool allow_nine) {
+    const int per_round = cus / 2;
+    const int whole = per_round > 0 ? (npairs / 8 / per_round) * per_round : 0;
+    if (allow_nine && whole > 0 && npairs - 8 * whole <= whole) return {whole, npairs - 8 * whole};
+    return {(npairs + 7) / 8, 0};
+}
+
+template <int PLAN, int NS, bool NINE>
 __device__ __forceinline__ void fc1_fast_tile(char* __restrict__ smem, const char* __restrict__ featb, const char* __restrict__ Wf,
                                               const float* __restrict__ bias, float* __restrict__ out, int M, float unscale, const int mt,
-                                              const int nb) {
+                                              const int nb, const int extra) {
     using P = FastPlan<PLAN>;
-    using S = FastShape<PLAN, NS>;
+    using S = FastShape<PLAN, NS, NINE>;
     using frag = typename P::frag;
     constexpr int WM = S::WM, NST = S::NST, NP = P::NP, NK = kFastChunks, PER = S::PER, STAGE = S::STAGE;
     static_assert(NST == 3 && NK % NST == 0, "three stages: chunk k + 2 reuses the stage of chunk k - 1");
@@ -93,7 +111,10 @@ __device__ __forceinline__ void fc1_fast_tile(char* __restrict__ smem, const cha
     const unsigned wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool late = wv >= 4;
     const int npairs = (M + 31) >> 5;
-    const int pair0 = mt * WM;
+    const int pair0 = mt * WM + (NINE ? min(mt, extra) : 0);
+    const bool has9 = NINE && mt < extra;                    // block-uniform: this M tile owns a ninth row tile
+    const bool mine9 = has9 && wv < (unsigned)NS;            // wave w < 7 multiplies it with column tile w
+    static_assert(!NINE || NS == 7, "the ninth row tile is shared by seven waves, one column tile each");
 
     f32x16 acc[NS];
 #pragma unroll
@@ -108,13 +129,13 @@ __device__ __forceinline__ void fc1_fast_tile(char* __restrict__ smem, const cha
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const unsigned q = min(wv + (unsigned)i * WM, (unsigned)(S::PIECES - 1));
-        if (q < (unsigned)(NP * WM)) {
-            const unsigned rt = q / NP, p = q - NP * rt;
+        if (q < (unsigned)(NP * S::ROWS)) {
+            const unsigned rt = q / NP, p = q - NP * rt;  // (row tile 8 of a block without one repeats a neighbour: read by nobody)
             const int pr = min(pair0 + (int)rt, npairs - 1);  // pairs beyond the pass repeat the last one (their rows are never stored)
             src[i] = featb + (size_t)pr * fast_pair_bytes(PLAN) + p * 1024u;
             step[i] = NP * 1024u;
         } else {
-            src[i] = Wf + (size_t)(nb * NS) * (NP * 1024) + (q - NP * WM) * 1024u;
+            src[i] = Wf + (size_t)(nb * NS) * (NP * 1024) + (q - NP * S::ROWS) * 1024u;
             step[i] = kFastColTiles * NP * 1024u;
         }
         dst[i] = q * 1024u;
@@ -142,7 +163,12 @@ __device__ __forceinline__ void fc1_fast_tile(char* __restrict__ smem, const cha
         __builtin_amdgcn_sched_barrier(0);                                                             \
     }
     const char* a_lds = smem + (NP * wv) * 1024 + lane * 16;
-    const char* b_lds = smem + (NP * WM) * 1024 + lane * 16;
+    const char* b_lds = smem + (NP * S::ROWS) * 1024 + lane * 16;
+    const char* a9_lds = smem + (NP * WM) * 1024 + lane * 16;   // the ninth row tile's A fragments
+    const char* b9_lds = b_lds + (NP * wv) * 1024;              // column tile wv once more (its own registers: wave-uniform index)
+    f32x16 acc9;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc9[r] = 0.f;
 
     PP_ISSUE(0, 0);
     PP_ISSUE(1, 1);
@@ -162,6 +188,14 @@ __device__ __forceinline__ void fc1_fast_tile(char* __restrict__ smem, const cha
             for (int j = 0; j < NS; ++j)
 #pragma unroll
                 for (int p = 0; p < NP; ++p) b[j][p] = *reinterpret_cast<const frag*>(b_lds + st * STAGE + (NP * j + p) * 1024);
+            frag a9[NP], b9[NP];
+            if (NINE && mine9) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    a9[p] = *reinterpret_cast<const frag*>(a9_lds + st * STAGE + p * 1024);
+                    b9[p] = *reinterpret_cast<const frag*>(b9_lds + st * STAGE + p * 1024);
+                }
+            }
             if (k + 2 < NK) vm_wait<PER>(); else vm_wait<0>();  // everything but the newest DMA group of this wave has landed
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             PP_BARRIER();
@@ -170,6 +204,10 @@ __device__ __forceinline__ void fc1_fast_tile(char* __restrict__ smem, const cha
             for (int q = 0; q < P::NPROD; ++q)
 #pragma unroll
                 for (int j = 0; j < NS; ++j) acc[j] = P::mfma(a[P::PA[q]], b[j][P::PB[q]], acc[j]);
+            if (NINE && mine9) {
+#pragma unroll
+                for (int q = 0; q < P::NPROD; ++q) acc9 = P::mfma(a9[P::PA[q]], b9[P::PB[q]], acc9);
+            }
             PP_BARRIER();
         }
     }
@@ -194,27 +232,42 @@ __device__ __forceinline__ void fc1_fast_tile(char* __restrict__ smem, const cha
                                                   lane_out + ((r & 3) + 8 * (r >> 2)) * kNVec * 4, (n0 + j * 32) * 4, 0);
         }
     }
+    if (NINE && mine9) {  // the ninth row tile: rows of pair pair0 + 8, this wave's column tile
+        const int m9 = (pair0 + WM) * 32;
+        const int lane9 = ((m9 + 4 * (lane >> 5)) * kNVec + (lane & 31)) * 4;
+        const float bv = bias[n0 + (int)wv * 32 + (lane & 31)];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float h = (PLAN == 2 ? acc9[r] * unscale : acc9[r]) + bv;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(0.2f * h, h)), rO,
+                                                  lane9 + ((r & 3) + 8 * (r >> 2)) * kNVec * 4, (n0 + (int)wv * 32) * 4, 0);
+        }
+    }
 }
 
-template <int PLAN, int NS>
+template <int PLAN, int NS, bool NINE>
 __global__ __launch_bounds__(512) void k_fc1_fast(const char* __restrict__ featb, const char* __restrict__ Wf,
-                                                  const float* __restrict__ bias, float* __restrict__ out, int M, float unscale) {
-    __shared__ __attribute__((aligned(16))) char smem[FastShape<PLAN, NS>::LDS_BYTES];  // the ONLY LDS object
+                                                  const float* __restrict__ bias, float* __restrict__ out, int M, float unscale,
+                                                  int tiles, int extra) {
+    __shared__ __attribute__((aligned(16))) char smem[FastShape<PLAN, NS, NINE>::LDS_BYTES];  // the ONLY LDS object
     int mt, nb;
     fc1_block_to_tile<kFastColTiles / NS, true>(blockIdx.x, mt, nb);  // the column blocks of an M tile share one XCD's L2
-    if (mt * 8 * 32 >= M) return;
-    fc1_fast_tile<PLAN, NS>(smem, featb, Wf, bias, out, M, unscale, mt, nb);
+    if (mt >= tiles) return;
+    fc1_fast_tile<PLAN, NS, NINE>(smem, featb, Wf, bias, out, M, unscale, mt, nb, extra);
 }
 
-void launch_fc1_fast(const Workspace& ws, const DeviceWeights& w, int n, float* out, int plan, hipStream_t s) {
+void launch_fc1_fast(const Workspace& ws, const DeviceWeights& w, int n, float* out, int plan, hipStream_t s, int cus) {
     const char* fb = reinterpret_cast<const char*>(ws.featb);
     const char* wf = reinterpret_cast<const char*>(w.fc1_fast[plan - 1]);
-    const int mtiles = ((n + 31) / 32 + 7) / 8;
-    const dim3 grid(((mtiles + 7) / 8) * 8 * 2);
+    // plan 1 has no registers left for the ninth row tile's accumulator (238 of 256): it keeps the plain tiling
+    const FastTiles ft = fast_tiles((n + 31) / 32, cus, plan == 2);
+    const dim3 grid(((ft.tiles + 7) / 8) * 8 * 2);
     if (plan == 1)
-        hipLaunchKernelGGL((k_fc1_fast<1, 7>), grid, dim3(512), 0, s, fb, wf, w.fc1_b, out, n, 1.0f);
+        hipLaunchKernelGGL((k_fc1_fast<1, 7, false>), grid, dim3(512), 0, s, fb, wf, w.fc1_b, out, n, 1.0f, ft.tiles, 0);
+    else if (ft.extra > 0)
+        hipLaunchKernelGGL((k_fc1_fast<2, 7, true>), grid, dim3(512), 0, s, fb, wf, w.fc1_b, out, n, 1.0f / (w.fast_scale_a * w.fast_scale_w), ft.tiles, ft.extra);
     else
-        hipLaunchKernelGGL((k_fc1_fast<2, 7>), grid, dim3(512), 0, s, fb, wf, w.fc1_b, out, n, 1.0f / (w.fast_scale_a * w.fast_scale_w));
+        hipLaunchKernelGGL((k_fc1_fast<2, 7, false>), grid, dim3(512), 0, s, fb, wf, w.fc1_b, out, n, 1.0f / (w.fast_scale_a * w.fast_scale_w), ft.tiles, 0);
 }
 
 }  // namespace ethcnn

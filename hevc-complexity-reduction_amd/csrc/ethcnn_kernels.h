@@ -42,7 +42,7 @@ void launch_fc1(const Workspace& ws, const DeviceWeights& w, int n, float* out, 
 // k2, plans 1 / 2 (ethcnn_fc1_fast.hip): featb -> h1 on the 16-bit matrix pipe: six bf16 products per fp32 product (exact three-way
 // splits of both operands, terms i + j <= 2) or three fp16 products (two-way splits of the scaled operands), fp32 accumulate; same
 // bias + leaky-ReLU epilogue, same h1 layout
-void launch_fc1_fast(const Workspace& ws, const DeviceWeights& w, int n, float* out, int plan, hipStream_t s);
+void launch_fc1_fast(const Workspace& ws, const DeviceWeights& w, int n, float* out, int plan, hipStream_t s, int cus = 256);
 // k3+k4 fused: h1 -> h2 -> logits, raw probs, probs and per-chunk gate flags.  gate_nchunks > 0: the batch gates are applied
 // inside the launch (ws.flags = sync area: arrival counters behind the 2 * gate_nchunks predicates, zero on
 // entry); 0: probs are left ungated for launch_gate

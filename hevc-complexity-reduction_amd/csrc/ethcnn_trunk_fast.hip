@@ -40,7 +40,12 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo
     for (int i = 0; i < 4; ++i) {
         const f16x2 h = __builtin_convertvector((f32x2){v[2 * i], v[2 * i + 1]}, f16x2);
         hi[i] = __builtin_bit_cast(unsigned, h);
-        const f16x2 l = __builtin_convertvector((f32x2){v[2 * i] - (float)h[0], v[2 * i + 1] - (float)h[1]}, f16x2);
+        // v - hi with the half read straight out of the packed register (v_fma_mix_f32: hi * -1.0 + v, exact like the subtraction):
+        // one instruction instead of v_cvt_f32_f16 + v_sub_f32
+        float r0, r1;
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi[i]), "v"(v[2 * i]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi[i]), "v"(v[2 * i + 1]));
+        const f16x2 l = __builtin_convertvector((f32x2){r0, r1}, f16x2);
         lo[i] = __builtin_bit_cast(unsigned, l);
     }
 }

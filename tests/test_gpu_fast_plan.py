@@ -115,7 +115,11 @@ def test_reference_graph_golden_under_the_fast_plans(fast_ctx, oracle):
 
 
 @pytest.mark.parametrize("plan", [1, 2, 3])
-@pytest.mark.parametrize("w,h,frames,qp", [(3840, 2160, 3, 32), (1920, 1080, 6, 22), (4928, 3264, 1, 27), (200, 136, 2, 37)])
+@pytest.mark.parametrize("w,h,frames,qp", [(3840, 2160, 3, 32), (1920, 1080, 6, 22), (4928, 3264, 1, 27), (200, 136, 2, 37),
+                                           # >= 32768 CTUs in one pass: k_fc1_fast's M tiles are cut to whole rounds and the left-over row
+                                           # tiles ride as a NINTH row tile of the first M tiles (plans 2 / 3; 34,680 CTUs: 60 of 128 tiles;
+                                           # 65,280: 0 extra of 255 -> plain tiling; 40,800: 1275 row tiles = 128 x 8 + 251 > 128 -> plain)
+                                           (3840, 2160, 17, 32), (3840, 2160, 32, 27), (3840, 2160, 20, 37)])
 def test_frames_under_the_fast_plans(pkg, oracle, w, h, frames, qp, plan):
     """Sampled C2 / C3 / C4 frames (and a ragged small one): ungated probabilities within 1e-4 of the oracle and of
     float64; every thresholded decision that differs from the exact plan's is a knife edge; with the shipped gates the
