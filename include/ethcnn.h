@@ -226,12 +226,16 @@ int ethcnn_set_fused_launch(ethcnn_ctx* ctx, int mode);
  *   2 ("fast", fp16 x 2)  the same structure with TWO fp16 pieces per operand (power-of-two scaled so that no piece can overflow:
  *                the feature bound is derived from the conv weights at load, not observed) and THREE products: h0 + h1
  *                represents the scaled fp32 value to 2^-24 relative.  Half the matrix instructions and two thirds of the bytes of
- *                plan 1: the faster of the two.
+ *                plan 1;
+ *   3 ("fast", fp16 x 2 + trunk)  plan 2, and the trunk's three conv layers on the 16-bit pipe as well (ethcnn_trunk_fast.hip):
+ *                conv1 on the exact integer pixel sums (mean removal folded into one fma per output), conv2 / conv3 with fp16 x 2
+ *                splits of activations and weights; the split features conv2 / conv3 produce are at once FC1's operands.  The
+ *                fastest plan.  Features then agree with the oracle's to ~1e-6 of their scale instead of bit for bit / 2^-23.
  * Measured against float64 the sums of plans 1 and 2 are as accurate as plan 0's fmaf chains (profiles/r04_bf16x3_probe.txt:
  * the error of a 2688-term fp32 sum is set by the roundings of its accumulation), but the ORDER of the fp32 additions differs,
  * so probabilities agree with plan 0 / the oracle to about 1e-6, not bit for bit (tests: <= 1e-4, the north star's tolerance;
  * thresholded decisions may differ on knife edges only).  Everything else (trunk convolutions, heads, gates) is computed
- * exactly as in plan 0.  The single-launch small pass and the LDP path always use plan 0.  Env ETHCNN_FC1_PLAN=1|2 starts
+ * exactly as in plan 0 (plan 3: heads and gates).  The single-launch small pass and the LDP path always use plan 0.  Env ETHCNN_FC1_PLAN=1|2|3 starts
  * contexts in that plan.  Takes effect with the next pass enqueued. */
 int ethcnn_set_fc1_plan(ethcnn_ctx* ctx, int plan);
 int ethcnn_get_fc1_plan(const ethcnn_ctx* ctx);

@@ -23,6 +23,7 @@ void t_fc1_fast(const float* w, int plan, float scale, unsigned short* out) { et
 unsigned short t_f16(float x) { return ethcnn::f16_rne(x); }
 float t_f16_back(unsigned short h) { return ethcnn::f16_f32(h); }
 float t_bound(const float* blob) { return ethcnn::fast_feature_bound(blob); }
+void t_pack_trunk16(const float* blob, float sa, unsigned short* w, float* c, ethcnn::Trunk16Scalars* sc) { ethcnn::pack_trunk_f16(blob, sa, w, c, sc); }
 }
 """
 
@@ -181,3 +182,77 @@ def test_feature_bound_holds_on_random_ctus(packers):
         ctus[:8] = (rng.integers(0, 2, size=(8, 64, 64)) * 255).astype(np.uint8)  # extreme contrast
         F = oracle.features(blob, ctus, mode=0)
         assert np.isfinite(bound) and 0 < np.abs(F).max() <= bound, (np.abs(F).max(), bound)
+
+
+def test_trunk_f16_images(packers):
+    """plan 3 (csrc/ethcnn_trunk_fast.hip): the trunk's A operands as fp16 x 2 pieces in MFMA order, the per-lane constants and the
+    per-branch scalars of pack_trunk_f16 against the checkpoint layout: every scale a power of two, pieces add back to the scaled
+    weight to 2^-22, fragment (lane, slot) -> (tap / patch / channel) maps as the kernel's comments say, constants = -S1 sum(w),
+    S1 b1, sa b2, sa b3."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ethcnn_np as oracle
+
+    class Sc(ctypes.Structure):
+        _fields_ = [("C1", ctypes.c_float * 3), ("U2", ctypes.c_float * 3), ("U3", ctypes.c_float * 3)]
+    blob = oracle.synth_blob(7, 4.0)
+    tv = oracle.tensor_views(blob)
+    # conv variables: L = Variable.._5, M = _6.._11, S = _12.._17 (ethcnn_spec.h); branches in feature order S, M, L
+    names = {0: ("Variable_12", "Variable_13", "Variable_14", "Variable_15", "Variable_16", "Variable_17"),
+             1: ("Variable_6", "Variable_7", "Variable_8", "Variable_9", "Variable_10", "Variable_11"),
+             2: ("Variable", "Variable_1", "Variable_2", "Variable_3", "Variable_4", "Variable_5")}
+    H, C = 4 * 64 * 4 + 8 * 64 * 8 + 12 * 64 * 8, 24 * 64
+    wimg = np.zeros(3 * H, np.uint16)
+    cimg = np.zeros(3 * C, np.float32)
+    sc = Sc()
+    sa = np.float32(2.0 ** 6)
+    fn = packers.t_pack_trunk16
+    fn.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_float, ctypes.POINTER(ctypes.c_ushort), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(Sc)]
+    fn(_fp(blob), float(sa), wimg.ctypes.data_as(ctypes.POINTER(ctypes.c_ushort)), _fp(cimg), ctypes.byref(sc))
+    halves = wimg.view(np.float16).astype(np.float64)
+
+    def pow2(x):
+        m, _ = np.frexp(x)
+        return m == 0.5
+    for br in range(3):
+        W1, B1, W2, B2, W3, B3 = (np.asarray(tv[n], np.float64) for n in names[br])
+        W1, W2, W3 = W1.reshape(16, 16), W2.reshape(4, 16, 24), W3.reshape(4, 24, 32)
+        pool = (1, 2, 4)[br]
+        c255s = np.float32(1.0 / 255.0) * np.float32(1.0 / (pool * pool))
+        w = halves[br * H:(br + 1) * H]
+        c = cimg[br * C:(br + 1) * C].reshape(24, 64).astype(np.float64)
+        S1 = c[4, 0] / B1[0]
+        s1w, s2w, s3w = float(c255s) * S1 / sc.C1[br], float(sa) / (S1 * sc.U2[br]), 1.0 / sc.U3[br]
+        for v in (S1, s1w, s2w, s3w):
+            assert pow2(v), (br, v)
+        assert np.abs(W1).max() * s1w * 16 < 65504 and np.abs(W2).max() * s2w <= 2 ** 14 and np.abs(W3).max() * s3w <= 2 ** 14
+        f1 = w[:4 * 64 * 4].reshape(4, 64, 4)
+        lane = np.arange(64)
+        row, kb = lane & 15, lane >> 4
+        for i in range(4):
+            want = W1[kb * 4 + i, row] * s1w
+            assert np.abs(f1[0, :, i] + f1[1, :, i] - want).max() <= np.abs(want).max() * 2.0 ** -21
+            assert np.abs(f1[2, :, i] + f1[3, :, i] - 16 * want).max() <= 16 * np.abs(want).max() * 2.0 ** -21
+        f2 = w[4 * 64 * 4:4 * 64 * 4 + 8 * 64 * 8].reshape(2, 2, 2, 64, 8)
+        f3 = w[4 * 64 * 4 + 8 * 64 * 8:].reshape(2, 3, 2, 64, 8)
+        for t in range(2):
+            for i in range(8):
+                for st in range(2):
+                    co = 16 * t + row
+                    want = np.where(co < 24, W2[2 * st + (i >> 2), 4 * kb + (i & 3), np.minimum(co, 23)], 0.0) * s2w
+                    assert np.abs(f2[t, st, 0, :, i] + f2[t, st, 1, :, i] - want).max() <= 2 ** 14 * 2.0 ** -21
+                for st in range(3):
+                    if st < 2:
+                        q2, ci = 2 * st + (i >> 2) + 0 * kb, 4 * kb + (i & 3)
+                    else:
+                        q2, ci = 2 * (i >> 2) + (kb >> 1), 16 + 4 * (kb & 1) + (i & 3)
+                    want = W3[q2, ci, 16 * t + row] * s3w
+                    assert np.abs(f3[t, st, 0, :, i] + f3[t, st, 1, :, i] - want).max() <= 2 ** 14 * 2.0 ** -21
+        for r in range(4):
+            ch = 4 * kb + r
+            assert np.allclose(c[r], -S1 * W1.sum(axis=0)[ch], rtol=1e-6, atol=1e-30)
+            assert np.allclose(c[4 + r], S1 * B1[ch], rtol=1e-7)
+            for t in range(2):
+                co = 16 * t + ch
+                assert np.allclose(c[8 + t * 4 + r], np.where(co < 24, float(sa) * B2[np.minimum(co, 23)], 0.0), rtol=1e-7)
+                assert np.allclose(c[16 + t * 4 + r], float(sa) * B3[co], rtol=1e-7)
