@@ -310,7 +310,11 @@ def main():
             "whole_path_frac_of_f32_mfma_peak": 2.0 * MAC_PER_CTU * total_ctus / elapsed / 1e12 / PEAK_F32_MFMA_TFLOPS / world,
             "ctu_load_stage": {"kernel": "k0_tile", "bound": "hbm", "achieved": tile_gbps, "peak": PEAK_HBM_GBPS,
                                "unit": "GB/s", "frac": tile_gbps / PEAK_HBM_GBPS, "avg_launch_ms": tile_ms,
-                               "algorithmic_bytes_per_ctu": 4096},
+                               "algorithmic_bytes_per_ctu": 4096,
+                               "counter_bytes_per_ctu": {"fetched": 4066, "written": 6656,
+                                                         "source": "rocprofv3 --pmc FETCH_SIZE (x2) / WRITE_SIZE of k0_tile_slab, profiles/r04_tile_fold.txt"},
+                               "form": "k0_tile_slab on a side stream beside FC1 of the previous step; the form folded into the trunk "
+                                       "(no slab records, no side stream) was measured 3.5 % slower per step (profiles/r04_tile_fold.txt)"},
         }
         # box calibration, right behind the timed region (same clocks, same temperature): what THIS GPU sustains in pure
         # exact-fp32 MFMAs.  Boxes of one pool differ by several per cent (round 3 saw 39.4 - 42.0 M CTU/s from the same code);

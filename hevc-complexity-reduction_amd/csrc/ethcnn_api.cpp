@@ -888,6 +888,10 @@ static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, lo
         // (measured: trunk 556 -> 819 us, tile 180 -> 511 us, step period 2.60 -> 2.73 ms; profiles/r02_overlap_trace.txt)
         HIPCHK(c, hipStreamWaitEvent(s_tile, c->e_trunk[p ^ 1], 0));
     }
+    // A/B knob (experiments build): CTU-load stage folded into the trunk for big exact passes (profiles/r04_tile_fold.txt)
+    static const bool fold_knob = [] { const char* e = dev_env("ETHCNN_TILE_FOLD"); return e && std::atoi(e) != 0; }();
+    const bool fold = fold_knob && c->fc1_plan == 0 && (g.width % 16 == 0) && (g.pitch % 16 == 0) && (g.frame_stride % 16 == 0) &&
+                      (reinterpret_cast<uintptr_t>(d_luma) % 16 == 0);
     (void)hipGetLastError();  // launch errors below are reported per stage; drop anything stale first
 #define LAUNCH_OK(name)                                                                                            \
     do {                                                                                                           \
@@ -895,7 +899,12 @@ static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, lo
         if (le_ != hipSuccess) return set_err(c, ETHCNN_ERR_DEVICE, "launch of the %s stage failed: %s", name, hipGetErrorString(le_)); \
     } while (0)
     // the tile stage also zeroes the pass's sync area (gate predicates, sub-batch arrival counters, tile completion counters of the fused launch)
-    { StageTimer t(c, ETHCNN_STAGE_TILE, n, s_tile); launch_tile(d_luma, g, ctu0, n, w, sync_words(n, (int)nchunks), s_tile, side_tile ? c->tile_blocks : 0); }
+    if (fold) {  // no tile launch: only the pass's sync area is cleared (what the tile stage does on the way)
+        HIPCHK(c, hipMemsetAsync(w.flags, 0, (size_t)sync_words(n, (int)nchunks) * sizeof(int), s_tile));
+    } else {
+        StageTimer t(c, ETHCNN_STAGE_TILE, n, s_tile);
+        launch_tile(d_luma, g, ctu0, n, w, sync_words(n, (int)nchunks), s_tile, side_tile ? c->tile_blocks : 0);
+    }
     LAUNCH_OK("tile");
     if (side_tile) {
         HIPCHK(c, hipEventRecord(c->e_tile[p], s_tile));
@@ -903,7 +912,10 @@ static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, lo
     }
     const int fast = c->fc1_plan;  // FC1 plans 1 / 2: trunk -> 16-bit feature pieces -> FC1 on the 16-bit matrix pipe
     if (fast && (rc = ensure_fast_weights(c, fast)) != 0) return rc;
-    { StageTimer t(c, ETHCNN_STAGE_TRUNK); if (fast == 3) launch_trunk_f16(w, c->dw, n, c->stream); else launch_trunk(w, c->dw, n, false, c->stream, fast); }
+    { StageTimer t(c, ETHCNN_STAGE_TRUNK);
+      if (fold) launch_trunk_direct(d_luma, g, ctu0, w, c->dw, n, c->stream);
+      else if (fast == 3) launch_trunk_f16(w, c->dw, n, c->stream);
+      else launch_trunk(w, c->dw, n, false, c->stream, fast); }
     LAUNCH_OK("trunk");
     if (side_tile) HIPCHK(c, hipEventRecord(c->e_trunk[p], c->stream));
     Workspace wv = w;

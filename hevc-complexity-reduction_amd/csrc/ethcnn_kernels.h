@@ -35,6 +35,8 @@ void launch_tile(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, co
                  hipStream_t s, int max_blocks = 0);
 // k1: xs/xm/xl -> feat (fc1_plan 1 / 2: -> featb, every feature as three bf16 / two fp16 pieces in the 16-bit MFMA's operand order)
 void launch_trunk(const Workspace& ws, const DeviceWeights& w, int n, bool resi, hipStream_t s, int fc1_plan = 0);
+// k1 with the CTU-load stage folded in (A/B form, experiments build: ethcnn_trunk.hip); needs small_pass_ok-style 16-byte alignment
+void launch_trunk_direct(const uint8_t* d_luma, const FrameGeom& g, long ctu0, const Workspace& ws, const DeviceWeights& w, int n, hipStream_t s);
 // k1, plan 3 (ethcnn_trunk_fast.hip): the same trunk with its convolutions on the 16-bit matrix pipe (fp16 x 2 splits) -> featb in plan 2's form
 void launch_trunk_f16(const Workspace& ws, const DeviceWeights& w, int n, hipStream_t s);
 // k2: feat -> h1 (bias + leaky-ReLU fused); out may be ws.h1 or a caller buffer (resi vectors)

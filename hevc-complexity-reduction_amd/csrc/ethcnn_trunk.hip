@@ -56,6 +56,31 @@ __global__ __launch_bounds__(256) void k1_trunk(const uint4* __restrict__ XS, co
 #define TRUNK_SH_L 13
 #endif
 
+// A/B form (experiments build, ETHCNN_TILE_FOLD=1): the CTU-load stage folded into the trunk for big passes as
+// well -- S / M waves gather their records straight from the luma frames (Trunk<.., DIRECT>, as the single-launch small pass does), an
+// L task (64 KB of pixels) is one block whose four waves gather together and whose wave 0 computes.  No k0_tile_slab, no 6,656 B per
+// CTU of slab records written and read back, no side stream.  Measured, not kept: profiles/r04_tile_fold.txt.
+__global__ __launch_bounds__(256) void k1_trunk_direct(DirectSrc src, int N, int bS, int bM, const float* __restrict__ wfrag,
+                                                       const float* __restrict__ bfrag, float* __restrict__ F) {
+    __shared__ float wl[kTrunkWFrags * 64 + 8 * 64 * 4];  // weight fragments + the L gather's exchange area
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x;
+    const int groups = (N + 15) / 16;
+    if (b < bS) Trunk<0, false, true>::run(nullptr, groups * 16, b * 4 + w, bS * 4, wfrag, bfrag, F, N, wl, &src);
+    else if (b < bS + bM) Trunk<1, false, true>::run(nullptr, groups * 4, (b - bS) * 4 + w, bM * 4, wfrag, bfrag, F, N, wl, &src);
+    else Trunk<2, false, true>::run(nullptr, groups, b - bS - bM, 1 << 30, wfrag, bfrag, F, N, wl, &src);  // one L task per block
+}
+
+void launch_trunk_direct(const uint8_t* d_luma, const FrameGeom& g, long ctu0, const Workspace& ws, const DeviceWeights& w, int n, hipStream_t s) {
+    const int groups = (n + 15) / 16, tS = groups * 16, tM = groups * 4;
+    auto blocks = [](int tasks, int budget) { int b = (tasks + 3) / 4; return b < budget ? b : budget; };
+    const int bS = blocks(tS, TRUNK_SH_S * 3), bM = blocks(tM, TRUNK_SH_M * 3);
+    DirectSrc src;
+    src.luma = d_luma; src.width = g.width; src.height = g.height; src.pitch = g.pitch; src.frame_stride = g.frame_stride;
+    src.cw = g.cw; src.nctu = g.nctu; src.ctu0 = ctu0; src.n_total = n;
+    hipLaunchKernelGGL(k1_trunk_direct, dim3(bS + bM + groups), dim3(256), 0, s, src, n, bS, bM, w.trunk_w, w.trunk_b, ws.feat);
+}
+
 void launch_trunk(const Workspace& ws, const DeviceWeights& w, int n, bool resi, hipStream_t s, int fc1_plan) {
     // tasks per group: 16 S, 4 M, 1 L -- all 240 MFMAs.  768 blocks = 3 per CU (156 VGPRs, 21 KB LDS).
     const int groups = (n + 15) / 16, tS = groups * 16, tM = groups * 4, tL = groups;
