@@ -183,9 +183,13 @@ struct ethcnn_ctx {
     int last_parity = 0;     // of the last pass (debug_fetch reads its h1)
     int small_launch = 1;    // 1 = a small pass (one picture) is ONE launch (ethcnn_small.hip); 0 = tile / trunk / FC1 / heads / gate
                              // launches (ethcnn_set_small_pass_launch, env ETHCNN_SMALL=0)
-    bool luma_over_pcie = false;  // set around a call whose luma pointer is page-locked HOST memory used in place (ethcnn_ldp_step):
-                                  // the single-launch pass gathers every pixel three times (S / M / L units) in 8-16 byte pieces --
-                                  // fine in HBM, slow across PCIe -- so such a call keeps the tile stage (one coalesced read)
+    bool luma_over_pcie = false;  // set around a call whose luma pointer is page-locked HOST memory used in place (ethcnn_ldp_step, one
+                                  // picture through ethcnn_predict_luma): the single-launch pass's direct gather reads every pixel three
+                                  // times (S / M / L units) in 8-16 byte pieces -- fine in HBM, slow across PCIe -- so such a call runs the
+                                  // PULL form (one coalesced read by the launch's first blocks: All-Intra pictures) or keeps the
+                                  // tile-stage launch (the LDP front-end)
+    int pull = 1;                 // 1 = single-launch passes over page-locked host luma pull it themselves (env ETHCNN_PULL=0, experiments
+                                  // build: DMA into HBM first / tile-stage launch, the round-3 forms)
     int* d_ssync = nullptr;  // its sync area: zero between launches by construction (every word is reset by its last user)
     int ssync_cap = 0;       // in ints
     bool ssync_clean = false;
@@ -368,6 +372,7 @@ extern "C" int ethcnn_create(ethcnn_ctx** out, const ethcnn_options* opt) {
     if (const char* e = dev_env("ETHCNN_FUSED")) c->fused = std::atoi(e) != 0;      // development knob (A/B runs)
     if (const char* e = dev_env("ETHCNN_GATE_FOLD")) c->gate_fold = std::atoi(e) != 0;  // development knob (A/B runs)
     if (const char* e = dev_env("ETHCNN_DONE_WORD")) c->done_sync = std::atoi(e) != 0;  // development knob (A/B runs)
+    if (const char* e = dev_env("ETHCNN_PULL")) c->pull = std::atoi(e) != 0;            // development knob (A/B runs)
     if (const char* e = dev_env("ETHCNN_LSTM_ONE_LAUNCH")) c->lstm_one_launch = std::atoi(e) != 0;  // development knob (A/B runs)
     if (hipHostMalloc((void**)&c->h_done, 64, hipHostMallocDefault) != hipSuccess) {
         ethcnn_destroy(c);
@@ -811,7 +816,7 @@ static int serial_end(ethcnn_ctx* c) {
 // the single-launch form of a small pass (ethcnn_small.hip); fc1_out: ws.h1 (All-Intra) or the caller's vectors (resi).
 // Asynchronous on the main stream.
 static int run_small_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, bool resi, const Workspace& w,
-                          float* fc1_out, float qn, float* d_probs, int nchunks) {
+                          float* fc1_out, float qn, float* d_probs, int nchunks, bool pull = false) {
     const int words = small_pass_sync_words(n, nchunks);
     c->done_armed = 0;
     if (c->small_epoch >= (1 << 30)) c->ssync_clean = false;  // tags start over on a freshly zeroed area
@@ -832,7 +837,7 @@ static int run_small_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom&
     c->ssync_clean = false;  // until this launch has been enqueued without an error
     (void)hipGetLastError();
     const unsigned seq = resi ? 0u : done_arm(c);
-    { StageTimer t(c, ETHCNN_STAGE_FC1, n); launch_small_pass(d_luma, g, ctu0, n, resi, w, c->dw, fc1_out, qn, c->thr1, c->thr2, d_probs, nchunks, c->d_ssync, c->small_epoch, seq ? c->h_done : nullptr, seq, c->stream); }
+    { StageTimer t(c, ETHCNN_STAGE_FC1, n); launch_small_pass(d_luma, g, ctu0, n, resi, w, c->dw, fc1_out, qn, c->thr1, c->thr2, d_probs, nchunks, c->d_ssync, c->small_epoch, seq ? c->h_done : nullptr, seq, c->stream, pull); }
     const hipError_t le = hipGetLastError();
     if (le != hipSuccess) return set_err(c, ETHCNN_ERR_DEVICE, "launch of the single-launch small pass failed: %s", hipGetErrorString(le));
     c->ssync_clean = true;
@@ -863,7 +868,7 @@ static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, lo
         // as ONE launch instead of five dependent ones
         Workspace wv = w;
         if (!c->debug_capture) wv.h2 = wv.logits = wv.raw = nullptr;
-        rc = run_small_pass(c, d_luma, g, ctu0, n, false, wv, w.h1, qn, d_probs_pass, (int)nchunks);
+        rc = run_small_pass(c, d_luma, g, ctu0, n, false, wv, w.h1, qn, d_probs_pass, (int)nchunks, c->luma_over_pcie);
         if (rc) return rc;
         c->main_dirty = true;  // a later pipelined tile stage must wait for this pass
         c->times.ctus += n;
@@ -1193,8 +1198,14 @@ static int predict_luma_latency(ethcnn_ctx* c, const uint8_t* luma, int w, int h
     if (rc) return rc;
     const bool packed = pitch == w && fstride == (ptrdiff_t)plane;
     const uint8_t* src = luma;
-    const bool banded = nframes == 1 && g.nctu > kSubBatch && c->small_launch && w % 16 == 0;  // (below)
+    // One picture, single-launch pass: the launch PULLS the picture from page-locked memory itself (the caller's, or the staging
+    // buffer) -- no copy-engine launch in front of the kernel, and the trunk / FC1 / heads of the first CTU rows run while the last
+    // rows are still on the bus (ethcnn_small.hip, "PULL form"; profiles/r04_latency_host.txt)
     const bool stage_rows = !(packed && in_pinned(c, luma, in_bytes));
+    // (a big picture in PAGEABLE memory keeps the banded form below: its staging copy -- 8.3 MB, 150 us of memcpy -- overlaps the
+    // copy engine band by band there, while a pull could only start behind all of it: 347 against 367 us)
+    const bool pull = nframes == 1 && c->pull && c->small_launch && w % 16 == 0 && g.nctu <= kSmallPassMaxCtus && !(stage_rows && g.nctu > kSubBatch);
+    const bool banded = !pull && nframes == 1 && g.nctu > kSubBatch && c->small_launch && w % 16 == 0;  // (below)
     if (stage_rows && !banded) {  // tight planes into the pinned staging buffer
         for (int f = 0; f < nframes; ++f) {
             const uint8_t* s = luma + (size_t)f * fstride;
@@ -1204,8 +1215,12 @@ static int predict_luma_latency(ethcnn_ctx* c, const uint8_t* luma, int w, int h
         }
         src = c->h_in[0];
     }
-    if (banded) {
-        // One big picture (3840x2160: 8.3 MB = 151 us of PCIe against ~100 us of kernels, serial until round 4): the picture is
+    if (pull) {
+        c->luma_over_pcie = true;
+        rc = run_pass(c, src, g, 0, g.nctu, qp, c->d_out[0]);
+        c->luma_over_pcie = false;
+    } else if (banded) {
+        // (the round's first form, kept for ETHCNN_PULL=0 A/B runs)  One big picture (3840x2160: 8.3 MB = 151 us of PCIe against ~100 us of kernels, serial until round 4): the picture is
         // cut on its gate sub-batch boundaries (1024 CTUs in raster order: video_to_cu_depth.py:61-73, so gate scope is intact) and
         // the rows the next piece needs travel on the copy stream while the previous piece computes; each piece is one
         // single-launch pass.  Same passes as a small workspace would plan: results are bit-identical.

@@ -67,7 +67,9 @@ bool small_pass_ok(const uint8_t* d_luma, const FrameGeom& g, int n);
 int small_pass_sync_words(int n, int nchunks);
 void launch_small_pass(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, bool resi, const Workspace& ws,
                        const DeviceWeights& w, float* fc1_out, float qn, float thr1, float thr2, float* d_probs, int nchunks,
-                       int* d_sync, int epoch, unsigned* done, unsigned done_seq, hipStream_t s);
+                       int* d_sync, int epoch, unsigned* done, unsigned done_seq, hipStream_t s, bool pull = false);
+// pull: d_luma is page-locked HOST memory; the launch's first blocks read it over PCIe into the workspace's pixel records (xs / xm /
+// xl) and the trunk starts group by group as they land (ethcnn_small.hip, "PULL form")
 // k5: apply the batch gates in place on d_probs
 void launch_gate(const Workspace& ws, int n, int nctu_per_frame, long ctu0, float thr2, float* d_probs,
                  hipStream_t s);

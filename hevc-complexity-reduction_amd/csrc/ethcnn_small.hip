@@ -14,6 +14,12 @@
 //   blocks [.., +3 groups)  one head of a group of 16 CTUs (its waves split the head's FC2 tiles: head_pass_regs); starts when
 //                           the NSPLIT FC1 column blocks of its 64-CTU tile have landed; applies the gates per sub-batch
 //
+// PULL form (round 4; the picture lies in page-locked HOST memory: the encoder hook's own buffer, the LDP daemon's frame): blocks
+// [0, groups) come FIRST and read the picture over PCIe themselves -- one group of 16 CTUs each, 64 KiB requested at once, turned
+// into the trunk's pixel records (tile_group, ethcnn_tile_group.h) -- and the trunk blocks (then ordered group by group) start
+// as their group's records land.  No copy-engine launch in front of the kernel, no stream dependency, and trunk / FC1 / heads of
+// the first CTU rows run while the last rows are still on the bus (3840x2160: 151 us of PCIe, scripts/ubench/row_arrival_probe.hip).
+//
 // Every consumer block has a higher block id than its producers and workgroups are dispatched in id order, so ALONE on the GPU a
 // waiting block can only wait for blocks that are resident or finished, and producers never wait (all blocks of a 1080p pass
 // are co-resident anyway).  When several processes share the GPU that is not enough -- two such launches can fill each other's
@@ -26,22 +32,26 @@
 // Same device functions, same accumulation chains as the multi-launch path: bit-identical results (tests run both).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 
 #include "ethcnn_fc1_regs.h"
 #include "ethcnn_fc1_tile.h"
 #include "ethcnn_heads_pass.h"
 #include "ethcnn_kernels.h"
+#include "ethcnn_tile_group.h"
 #include "ethcnn_trunk_task.h"
 
 namespace ethcnn {
 
 struct SmallParams {
-    DirectSrc src;
+    DirectSrc src;                // PULL form: `luma` is page-locked host memory, read once by the pull blocks ...
+    uint4 *xs, *xm, *xl;          // ... into the pixel records of the pass (the workspace's: ethcnn_tile.hip layouts)
     const float* trunk_w;
     const float* trunk_b;
     float* feat;
     int n, ngroups, ntiles, nchunks;
+    int npull;                    // PULL form: pull blocks of the launch; block b pulls groups b, b + npull, ... (see launch_small_pass)
     int bS, bM, bL;               // trunk blocks per branch (S / M: 4 waves = 4 tasks; L: one task per block)
     const float* wimg;            // FC1 weights as the LDS image of the launch's tile shape ...
     const float* wlane;           // ... and in MFMA-operand order per 16-column tile (fc1_tile_regs)
@@ -84,17 +94,19 @@ struct SmallSync {
     int* fc1_done;     // [ntiles] x kPad      FC1 column blocks finished per tile
     int* heads_flag;   // [3 ngroups] x kPad   "your tile's h1 has landed", one per heads block (16 CTUs x head)
     int* done_cnt;     // [1] x kPad           gate sub-batches completed (nchunks = the launch's outputs are final)
+    int* trunk_flag;   // [6 ngroups] x kPad   PULL form: "your group's pixel records have landed", one per trunk work item
     int words;         // of the part above: every word of it is zero between launches (reset by its last user)
     // claim words (epoch tags, NEVER reset: a stale tag simply differs from the current one) live at FIXED offsets behind the
     // largest possible self-cleaning part, because the layout above moves with the geometry and a stale tag must never be
     // read as a counter or a flag of a later launch
     int* claim_t;      // [trunk blocks] x kPad  claim word per trunk work item
     int* claim_f;      // [fc1_blocks] x kPad    claim word per FC1 work item
+    int* claim_l;      // [ngroups] x kPad       PULL form: claim word per pull work item (= group)
 };
 constexpr int kMaxGroups = (kSmallPassMaxCtus + 15) / 16, kMaxTiles = (kSmallPassMaxCtus + 63) / 64, kMaxFc1Blocks = kMaxTiles * 28;
 constexpr int kClaimBase = 2 * kSmallPassMaxCtus + (kSmallPassMaxCtus + kPad - 1) / kPad * kPad + kPad +
-                           (kMaxGroups + kMaxTiles + kMaxFc1Blocks + kMaxTiles + 3 * kMaxGroups + 1) * kPad;  // >= words for any n, nchunks <= n
-constexpr int kSyncTotalWords = kClaimBase + (6 * kMaxGroups + kMaxFc1Blocks) * kPad;
+                           (kMaxGroups + kMaxTiles + kMaxFc1Blocks + kMaxTiles + 3 * kMaxGroups + 1 + 6 * kMaxGroups) * kPad;  // >= words for any n, nchunks <= n
+constexpr int kSyncTotalWords = kClaimBase + (6 * kMaxGroups + kMaxFc1Blocks + kMaxGroups) * kPad;
 __host__ __device__ inline SmallSync small_sync(int* base, int nchunks, int ngroups, int ntiles, int fc1_blocks) {  // (heads blocks = 3 ngroups)
     SmallSync s;
     s.pred = base;
@@ -105,9 +117,11 @@ __host__ __device__ inline SmallSync small_sync(int* base, int nchunks, int ngro
     s.fc1_done = s.fc1_flag + fc1_blocks * kPad;
     s.heads_flag = s.fc1_done + ntiles * kPad;
     s.done_cnt = s.heads_flag + 3 * ngroups * kPad;
-    s.words = (int)(s.done_cnt + kPad - base);
+    s.trunk_flag = s.done_cnt + kPad;
+    s.words = (int)(s.trunk_flag + 6 * ngroups * kPad - base);
     s.claim_t = base + kClaimBase;
     s.claim_f = s.claim_t + 6 * kMaxGroups * kPad;  // trunk blocks: 4 S + 1 M + 1 L per group
+    s.claim_l = s.claim_f + kMaxFc1Blocks * kPad;
     return s;
 }
 
@@ -161,16 +175,71 @@ struct SmallShared {  // block-uniform scratch of the roles
     GateArrive ga;
 };
 
+// every thread of the block; patience: 0 = wait for the flag, whatever it takes
+__device__ __forceinline__ bool block_wait(int* flag, const SmallParams& P, SmallShared* sh, unsigned long long patience) {
+    if (threadIdx.x == 0) sh->woken = wait_flag(flag, P.exp, patience) ? 1 : 0;
+    __syncthreads();
+    const bool w = sh->woken != 0;
+    __syncthreads();
+    return w;
+}
+
+// ---- a pull work item (PULL form): the pixel records of group `grp`, read from page-locked host memory.  Claims the item; the
+// owner wakes the group's six trunk items.  Called by the block the item was meant for -- or by a trunk item tired of waiting.
+__device__ __forceinline__ void do_pull_item(const SmallParams& P, const SmallSync& Y, int grp, float* smem, SmallShared* sh) {
+    if (threadIdx.x == 0) sh->owned = (__hip_atomic_exchange(Y.claim_l + grp * kPad, P.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != P.epoch);
+    __syncthreads();
+    const bool mine = sh->owned != 0;
+    __syncthreads();
+    if (!mine) return;
+    tile_group<true, true, true>(reinterpret_cast<uint32_t*>(smem), P.src.luma, P.src.width, P.src.height, P.src.pitch, P.src.frame_stride, P.src.cw,
+                                 P.src.nctu, P.src.ctu0, P.src.n_total, grp, P.xs, P.xm, P.xl);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the records (agent-scope stores) have completed before the flags move
+    __syncthreads();
+    if (threadIdx.x < 6) {  // the group's trunk items: 4 S blocks, the M block, the L block
+        const int k = threadIdx.x, item = k < 4 ? 4 * grp + k : (k == 4 ? P.bS + grp : P.bS + P.bM + grp);
+        put(Y.trunk_flag + item * kPad, 1);
+    }
+    __syncthreads();
+}
+
 // ---- a trunk work item (+ CTU gather): items [0, 4 G) = S blocks (four tasks each), [4 G, 5 G) = M blocks, [5 G, 6 G) = L
 // blocks (one task, gathered by the four waves together), G = groups of 16 CTUs; every item belongs to ONE group.  Claims
 // the item (inside Trunk::run, under its first loads); the owner signals the group, the group's finisher the tile, the
 // tile's finisher wakes the FC1 blocks.  Called by the block the item was meant for -- or by a consumer tired of waiting.
-template <int NSPLIT, bool RESI>
+template <int NSPLIT, bool RESI, bool PULL>
 __device__ __forceinline__ void do_trunk_item(const SmallParams& P, const SmallSync& Y, int item, float* smem, SmallShared* sh) {
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     int* const claim = Y.claim_t + item * kPad;
     int grp, ntask;
-    if (item < P.bS) {
+    if (PULL) {
+        // the item is claimed HERE (its flag has one poller: the owner), then waits for its group's records -- pulling them
+        // itself if the pull block has not come by (claim or execute) -- and runs the trunk on the records as the
+        // multi-launch path does
+        if (threadIdx.x == 0) sh->owned = (__hip_atomic_exchange(claim, P.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != P.epoch);
+        __syncthreads();
+        const bool mine = sh->owned != 0;
+        __syncthreads();
+        if (!mine) return;
+        grp = item < P.bS ? item >> 2 : (item < P.bS + P.bM ? item - P.bS : item - P.bS - P.bM);
+        if (!block_wait(Y.trunk_flag + item * kPad, P, sh, P.steal_test ? 1 : kPatience)) {
+            do_pull_item(P, Y, grp, smem, sh);
+            (void)block_wait(Y.trunk_flag + item * kPad, P, sh, 0);  // the group is claimed by a resident block now
+        }
+        SMALL_STAMP(1);
+        if (threadIdx.x == 0) sh->owned = 1;
+        __syncthreads();
+        if (item < P.bS) {
+            ntask = 4;
+            Trunk<0, RESI, false, true>::run(P.xs, P.ngroups * 16, item * 4 + wv, P.bS * 4, P.trunk_w, P.trunk_b, P.feat, P.n, smem);
+        } else if (item < P.bS + P.bM) {
+            ntask = 4;
+            Trunk<1, RESI, false, true>::run(P.xm, P.ngroups * 4, (item - P.bS) * 4 + wv, P.bM * 4, P.trunk_w, P.trunk_b, P.feat, P.n, smem);
+        } else {
+            ntask = 1;  // (one task: wave 0's; the others help with the weight staging and leave)
+            Trunk<2, RESI, false, true>::run(P.xl, wv == 0 ? P.ngroups : 0, grp, P.bL, P.trunk_w, P.trunk_b, P.feat, P.n, smem);
+        }
+    } else if (item < P.bS) {
         grp = item >> 2; ntask = 4;
         Trunk<0, RESI, true, true>::run(nullptr, P.ngroups * 16, item * 4 + wv, P.bS * 4, P.trunk_w, P.trunk_b, P.feat, P.n, smem, &P.src, claim, P.epoch, &sh->owned);
     } else if (item < P.bS + P.bM) {
@@ -194,15 +263,6 @@ __device__ __forceinline__ void do_trunk_item(const SmallParams& P, const SmallS
     __syncthreads();  // (smem and sh are free for the caller's next item)
 }
 
-// every thread of the block; patience: 0 = wait for the flag, whatever it takes
-__device__ __forceinline__ bool block_wait(int* flag, const SmallParams& P, SmallShared* sh, unsigned long long patience) {
-    if (threadIdx.x == 0) sh->woken = wait_flag(flag, P.exp, patience) ? 1 : 0;
-    __syncthreads();
-    const bool w = sh->woken != 0;
-    __syncthreads();
-    return w;
-}
-
 // ---- an FC1 work item: column block nb of 64-CTU tile mt.  Claims it, waits for the tile's features (executing the tile's
 // unclaimed trunk items itself when that takes too long), computes, signals the tile; the tile's finisher wakes its heads.
 #ifndef SMALL_D2
@@ -220,7 +280,7 @@ __device__ __forceinline__ bool block_wait(int* flag, const SmallParams& P, Smal
 template <int NS, bool RESI>
 __device__ __host__ constexpr bool fc1_regs() { return SMALL_FC1_REGS != 0 && (NS == 1 || RESI); }
 
-template <int NS, int NSUB, bool RESI>
+template <int NS, int NSUB, bool RESI, bool PULL>
 __device__ __forceinline__ void do_fc1_item(const SmallParams& P, const SmallSync& Y, int fb, float* smem, SmallShared* sh) {
     constexpr int NSPLIT = kNVec / (16 * NS);
     if (threadIdx.x == 0) sh->owned = (__hip_atomic_exchange(Y.claim_f + fb * kPad, P.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != P.epoch);
@@ -229,7 +289,7 @@ __device__ __forceinline__ void do_fc1_item(const SmallParams& P, const SmallSyn
     __syncthreads();
     if (!mine) return;
     const int nb = fb % NSPLIT, mt = fb / NSPLIT;
-    if (!block_wait(Y.fc1_flag + fb * kPad, P, sh, P.steal_test ? 1 : kPatience)) {
+    if (!block_wait(Y.fc1_flag + fb * kPad, P, sh, P.steal_test ? 1 : (PULL ? 5 : 1) * kPatience)) {  // (PULL: the last rows of a 2160p picture are 150 us away)
         // claim or execute: the trunk items of this tile's groups that nobody has claimed yet (an item that already carries
         // this launch's tag needs no second look: the claim inside Trunk::run is only answered after its first loads)
         const int g0 = 4 * mt, g1 = min(4 * mt + 4, P.ngroups);
@@ -244,7 +304,7 @@ __device__ __forceinline__ void do_fc1_item(const SmallParams& P, const SmallSyn
                 __syncthreads();
                 const bool unclaimed = __builtin_amdgcn_readfirstlane(sh->woken) != 0;
                 __syncthreads();
-                if (unclaimed) do_trunk_item<NSPLIT, RESI>(P, Y, item, smem, sh);
+                if (unclaimed) do_trunk_item<NSPLIT, RESI, PULL>(P, Y, item, smem, sh);
             }
         (void)block_wait(Y.fc1_flag + fb * kPad, P, sh, 0);  // every item of the tile is claimed by a resident block now
     }
@@ -264,28 +324,39 @@ __device__ __forceinline__ void do_fc1_item(const SmallParams& P, const SmallSyn
     __syncthreads();
 }
 
-template <int NS, int NSUB, bool RESI>
+template <int NS, int NSUB, bool RESI, bool PULL>
 __global__ __launch_bounds__(256, 2) void k_small_pass(SmallParams P) {  // <= 256 registers: two blocks per CU
     constexpr int NSPLIT = kNVec / (16 * NS);
-    constexpr int LDS_FLOATS = MaxOf<MaxOf<(fc1_regs<NS, RESI>() ? 0 : Fc1Shape<1, NS, 4, NSUB, 3>::LDS_FLOATS), (RESI ? kTrunkResiLds : kTrunkWFrags * 64 + 8 * 64 * 4)>::value, (RESI ? 0 : (NS == 1 ? 12 * 256 : kHeadsLatStages * kHeadsStage + 12 * 256))>::value;
+    constexpr int LDS_FLOATS = MaxOf<MaxOf<(fc1_regs<NS, RESI>() ? 0 : Fc1Shape<1, NS, 4, NSUB, 3>::LDS_FLOATS), (RESI ? kTrunkResiLds : kTrunkWFrags * 64 + 8 * 64 * 4)>::value, (RESI ? (PULL ? 16 * kSlabCtuPitch : 0) : (NS == 1 ? 12 * 256 : kHeadsLatStages * kHeadsStage + 12 * 256))>::value;
     __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
     __shared__ SmallShared sh;
-    const int bid = (int)blockIdx.x;
+    const int nL = PULL ? P.npull : 0;  // pull blocks come first: they wait for nobody
+    const int bid = (int)blockIdx.x - nL;
     const int nT = P.bS + P.bM + P.bL;
     const SmallSync Y = small_sync(P.sync, P.nchunks, P.ngroups, P.ntiles, (int)P.fc1_blocks);
     SMALL_STAMP(0);
     const bool is_producer = bid < nT + (int)P.fc1_blocks;
     // tests: "this producer block never got a slot" -- only blocks somebody in this launch waits for (nobody waits for the FC1
     // blocks of the LDP front-end: a late one of those simply runs late)
-    if (P.steal_test > 0 && (RESI ? bid < nT : is_producer) && bid % P.steal_test == 1) return;
+    if (P.steal_test > 0 && (RESI ? bid < nT : is_producer) && (int)blockIdx.x % P.steal_test == 1) return;
 
+    if (PULL && bid < 0) {
+#pragma unroll 1
+        for (int grp = (int)blockIdx.x; grp < P.ngroups; grp += nL) do_pull_item(P, Y, grp, smem, &sh);
+        SMALL_STAMP(3);
+        return;
+    }
     if (bid < nT) {
-        do_trunk_item<NSPLIT, RESI>(P, Y, bid, smem, &sh);
+        // PULL form: the six trunk items of a group are neighbours in block order (the groups' records arrive one after the
+        // other: a group's M and L blocks must not queue behind the S blocks of groups that are still on the bus)
+        const int k6 = bid % 6, g6 = bid / 6;
+        const int item = !PULL ? bid : (k6 < 4 ? 4 * g6 + k6 : (k6 == 4 ? P.bS + g6 : P.bS + P.bM + g6));
+        do_trunk_item<NSPLIT, RESI, PULL>(P, Y, item, smem, &sh);
         SMALL_STAMP(3);
         return;
     }
     if (is_producer) {
-        do_fc1_item<NS, NSUB, RESI>(P, Y, bid - nT, smem, &sh);
+        do_fc1_item<NS, NSUB, RESI, PULL>(P, Y, bid - nT, smem, &sh);
         SMALL_STAMP(3);
         return;
     }
@@ -293,11 +364,11 @@ __global__ __launch_bounds__(256, 2) void k_small_pass(SmallParams P) {  // <= 2
     // ---- one head of one group of 16 CTUs (the block's waves split the head's FC2 tiles: head_pass_regs)
     const int hb = bid - nT - (int)P.fc1_blocks;
     const int grp = hb / 3, head_ = hb % 3;
-    if (!block_wait(Y.heads_flag + hb * kPad, P, &sh, P.steal_test ? 1 : kPatience)) {
+    if (!block_wait(Y.heads_flag + hb * kPad, P, &sh, P.steal_test ? 1 : (PULL ? 5 : 1) * kPatience)) {
         // claim or execute: the FC1 items of this group's tile (each of which does the same for its trunk items)
         const int mt = grp >> 2;
 #pragma unroll 1
-        for (int nb = 0; nb < NSPLIT; ++nb) do_fc1_item<NS, NSUB, RESI>(P, Y, mt * NSPLIT + nb, smem, &sh);
+        for (int nb = 0; nb < NSPLIT; ++nb) do_fc1_item<NS, NSUB, RESI, PULL>(P, Y, mt * NSPLIT + nb, smem, &sh);
         (void)block_wait(Y.heads_flag + hb * kPad, P, &sh, 0);
     }
     SMALL_STAMP(1);
@@ -350,18 +421,24 @@ bool small_pass_ok(const uint8_t* d_luma, const FrameGeom& g, int n) {
            (reinterpret_cast<uintptr_t>(d_luma) % 16 == 0);
 }
 
-template <bool RESI>
+template <bool RESI, bool PULL>
 static void launch_small_t(const SmallParams& P, int shape, unsigned blocks, hipStream_t s) {
     // FC1 shape by row count, as fc1_short_variant (ethcnn_dense.hip): narrow tiles = short per-chunk chains for few rows
-    if (shape == 0) hipLaunchKernelGGL((k_small_pass<1, 4, RESI>), dim3(blocks), dim3(256), 0, s, P);       // 64 x 16, BK 64
-    else if (shape == 1) hipLaunchKernelGGL((k_small_pass<2, 2, RESI>), dim3(blocks), dim3(256), 0, s, P);  // 64 x 32, BK 32
-    else hipLaunchKernelGGL((k_small_pass<4, 2, RESI>), dim3(blocks), dim3(256), 0, s, P);                  // 64 x 64, BK 32
+    if (shape == 0) hipLaunchKernelGGL((k_small_pass<1, 4, RESI, PULL>), dim3(blocks), dim3(256), 0, s, P);       // 64 x 16, BK 64
+    else if (shape == 1) hipLaunchKernelGGL((k_small_pass<2, 2, RESI, PULL>), dim3(blocks), dim3(256), 0, s, P);  // 64 x 32, BK 32
+    else hipLaunchKernelGGL((k_small_pass<4, 2, RESI, PULL>), dim3(blocks), dim3(256), 0, s, P);                  // 64 x 64, BK 32
 }
 
 void launch_small_pass(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, bool resi, const Workspace& ws,
                        const DeviceWeights& w, float* fc1_out, float qn, float thr1, float thr2, float* d_probs, int nchunks,
-                       int* d_sync, int epoch, unsigned* done, unsigned done_seq, hipStream_t s) {
+                       int* d_sync, int epoch, unsigned* done, unsigned done_seq, hipStream_t s, bool pull) {
+    // (the LDP front-end keeps the tile-stage launch for page-locked luma: measured equal to slower in PULL form -- 1080p 116 against
+    // 105 us per resident-state call, 2160p 313 against 317 -- its launch ends with FC1 and has no long tail to hide the bus under)
+    if (resi) pull = false;
     SmallParams P;
+    P.xs = ws.xs;
+    P.xm = ws.xm;
+    P.xl = ws.xl;
     P.done = resi ? nullptr : done;  // (the LDP front-end is not the end of its call)
     P.done_seq = done_seq;
     P.src.luma = d_luma;
@@ -386,7 +463,10 @@ void launch_small_pass(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int
     static const int force = [] { const char* e = dev_env("ETHCNN_SMALL_SHAPE"); return e ? atoi(e) : -1; }();  // development knob
     // 64 x 16 tiles (register-fed FC1 and heads) up to 1536 CTUs, 64 x 32 above (scripts/latency_mid.py, profiles/r03_latency_mid.txt:
     // 920 CTUs 61.8 vs 81.5 us, 1536 CTUs 82.9 vs 89.9, 1800 CTUs 101.2 vs 99.6)
-    int shape = n <= 1536 ? 0 : (n <= 2304 ? 1 : 2);
+    // PULL form: 64 x 16 tiles at every size -- the CTUs arrive at the bus's pace (3840x2160: 150 us), the GPU is never full, and what
+    // counts is how soon the LAST tile is done after its rows have landed (11 us register-fed against 38 us for the 64 x 32 tile
+    // among 448 of its kind: scripts/ubench/small_probe.hip, profiles/r04_pull_timeline.txt; launch 229 -> 209 us)
+    int shape = (n <= 1536 || pull) ? 0 : (n <= 2304 ? 1 : 2);
     if (force >= 0 && force <= 2) shape = force;
     const int nsplit = shape == 0 ? 28 : (shape == 1 ? 14 : 7);
     P.wimg = shape == 0 ? w.fc1_img16 : (shape == 1 ? w.fc1_img32 : w.fc1_img64);
@@ -422,8 +502,17 @@ void launch_small_pass(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int
     if (exp_mode == 2) blocks = (unsigned)(P.bS + P.bM + P.bL);                  // trunk part alone
     if (exp_mode == 3) blocks = (unsigned)(P.bS + P.bM + P.bL) + P.fc1_blocks;   // trunk + FC1
 #endif
-    if (resi) launch_small_t<true>(P, shape, blocks, s);
-    else launch_small_t<false>(P, shape, blocks, s);
+    // Pull blocks: FEW above 1080p, each walking its groups in order.  The bus serves the requests of all resident blocks evenly: with
+    // one block per group every group of a 2160p picture completes in the last third of the transfer and nothing overlaps (launch
+    // 287 us); 16 blocks x 64 KiB in flight cover the bus's bandwidth-delay product several times -- the transfer runs at the copy
+    // engine's rate, 8.3 MB in 155 us -- and the groups land in raster order, 1 MiB apart (launch 209 us).  Up to 32 groups (1080p)
+    // one block per group: the whole picture is 2 MiB, and a block's second group would wait for its first (84 against 87-92 us).
+    // (scripts/ubench/small_probe.hip W H 0 1, profiles/r04_pull_timeline.txt)
+    static const int npull_env = [] { const char* e = dev_env("ETHCNN_PULL_BLOCKS"); return e ? atoi(e) : 0; }();  // development knob
+    P.npull = !pull ? 0 : std::min(P.ngroups, npull_env > 0 ? npull_env : (P.ngroups <= 32 ? 32 : 16));
+    blocks += (unsigned)P.npull;
+    if (resi) launch_small_t<true, false>(P, shape, blocks, s);  // (pull == false: see above)
+    else pull ? launch_small_t<false, true>(P, shape, blocks, s) : launch_small_t<false, false>(P, shape, blocks, s);
 }
 
 }  // namespace ethcnn

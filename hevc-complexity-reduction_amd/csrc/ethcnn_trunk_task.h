@@ -259,7 +259,10 @@ struct Trunk {
                                                const float* __restrict__ wfrag, const float* __restrict__ bfrag,
                                                float* __restrict__ F, int N, float* wl, const DirectSrc* src = nullptr,
                                                int* claim = nullptr, int tag = 0, int* s_owned = nullptr, float fscale = 1.0f) {
-        const int lane = threadIdx.x & 63;
+        int lane = threadIdx.x & 63;
+        // (single-launch forms inline this function into several roles: an opaque copy of the lane index keeps the compiler from
+        // computing the lane geometry once at kernel entry and carrying it through all of them -- VGPRs the register-fed heads need)
+        if (SC1) asm volatile("" : "+v"(lane));
         const int col = lane & 15, g = lane >> 4;
         // single-launch pass: the block CLAIMS its work item (one exchange on the item's own word; `tag` = this launch's epoch).
         // The answer is needed only after the weight-staging barrier below, so its round trip hides under the gather.  A block
@@ -319,8 +322,8 @@ struct Trunk {
         if (!DIRECT) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
-                raw[j] = TRUNK_BUF_LOADS ? __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rX, lane16, (wave * NJ + j) * 1024, 0))
-                                         : X[((size_t)wave * NJ + j) * 64 + lane];
+                raw[j] = (TRUNK_BUF_LOADS || SC1) ? __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rX, lane16, (wave * NJ + j) * 1024, SC1 ? kAuxSc1 : 0))
+                                         : X[((size_t)wave * NJ + j) * 64 + lane];  // (SC1: records written inside this launch, by its PULL role)
         }
 
         for (int task = wave; task < ntasks; task += nwaves) {
@@ -409,7 +412,7 @@ struct Trunk {
                 } else {
 #pragma unroll
                     for (int j = 0; j < NJ; ++j)
-                        raw[j] = TRUNK_BUF_LOADS ? __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rX, lane16, ((task + nwaves) * NJ + j) * 1024, 0))
+                        raw[j] = (TRUNK_BUF_LOADS || SC1) ? __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rX, lane16, ((task + nwaves) * NJ + j) * 1024, SC1 ? kAuxSc1 : 0))
                                                  : X[((size_t)(task + nwaves) * NJ + j) * 64 + lane];
                 }
             }

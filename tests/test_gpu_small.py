@@ -139,6 +139,43 @@ def test_long_sequences_of_single_launch_passes(pkg, oracle):
         c.close()
 
 
+def test_pull_form_page_locked_pictures(pkg, oracle):
+    """One picture in page-locked host memory (the encoder hook's buffer): the single-launch pass PULLS it over PCIe itself
+    (ethcnn_small.hip, "PULL form": pull blocks -> pixel records -> trunk group by group) -- one block per group up to 1080p, 16
+    blocks walking the groups above, 64 x 16 FC1 tiles at every size.  Bit-exact against the oracle, repeatedly (the sync area
+    cleans itself), alternating with the direct-gather form of the same launch (a device-resident picture) on the same context,
+    and with a pageable source (small: staged, then pulled; above 1024 CTUs: the banded copy)."""
+    rng = np.random.default_rng(44)
+    blob = oracle.synth_blob(9, 4.0)
+    c = pkg.EthCnn(0)
+    try:
+        c.load_blob(blob)
+        for (w, h) in ((64, 64), (416, 240), (1280, 720), (1920, 1080), (2560, 1600), (2576, 1600), (3840, 2160), (1024, 2304), (48, 4096)):
+            luma = rng.integers(0, 256, size=(1, h, w), dtype=np.uint8)
+            nctu = pkg.ethcnn.ctus_per_frame(w, h)
+            pin = c.host_buffer(w * h)
+            pin[:] = luma.reshape(-1)
+            d_in, d_out = c.alloc(luma.nbytes), c.alloc(nctu * 84)
+            d_in.upload(luma)
+            for thr in ((0.5, 0.5), (0.9, 0.2)):
+                c.set_thresholds(*thr)
+                want = oracle.predict_frames(blob, luma, w, h, 1, 27, thr[0], thr[1], mode=0)
+                for rep in range(3):
+                    got = c.predict_luma(pin.reshape(1, h, w), w, h, 1, 27)
+                    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (w, h, thr, rep, "page-locked")
+                    c.predict_luma_device(d_in, w, h, 1, 27, d_out)
+                    c.synchronize()
+                    got = d_out.download(np.float32, nctu * 21).reshape(-1, 21)
+                    assert np.array_equal(_bits(got), _bits(want.reshape(-1, 21))), (w, h, thr, rep, "device")
+                got = c.predict_luma(luma, w, h, 1, 27)
+                assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (w, h, thr, "pageable")
+            d_in.free()
+            d_out.free()
+            c.free_host_buffers()
+    finally:
+        c.close()
+
+
 def test_claim_or_execute_when_producer_blocks_never_run(pkg, oracle):
     """FORWARD PROGRESS of the dataflow launch when the GPU is shared: a consumer that has waited too long executes
     the unclaimed work items it depends on itself.  ETHCNN_SMALL_STEAL_TEST=k makes every k-th producer block (trunk and FC1
@@ -167,6 +204,12 @@ def test_claim_or_execute_when_producer_blocks_never_run(pkg, oracle):
                 for rep in range(3):
                     got = c.predict_luma(luma, w, h, frames, 30)
                     assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (w, h, thr, rep)
+                if frames == 1:  # page-locked picture: the PULL form at every size (its pull blocks are producers too)
+                    pin = c.host_buffer(w * h)
+                    pin[:] = luma.reshape(-1)
+                    got = c.predict_luma(pin.reshape(1, h, w), w, h, 1, 30)
+                    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (w, h, thr, "pull")
+                    c.free_host_buffers()
             want_vec = oracle.resi_vectors(blob, luma[0], w, h, mode=0)
             assert np.array_equal(c.resi_vectors(luma[0], w, h).view(np.uint32), want_vec.view(np.uint32)), (w, h)
         print("steal ok")
