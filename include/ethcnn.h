@@ -153,7 +153,8 @@ int ethcnn_ldp_step(ethcnn_ctx* ctx, const uint8_t* luma, int width, int height,
 int ethcnn_ldp_get_state(ethcnn_ctx* ctx, float* state_out, size_t nfloats /* nctu * 896 */);
 /* Pinned (page-locked) host memory: buffers a caller fills itself (file reads) and hands to the host entry points are
  * DMA-able directly, without the runtime's pageable staging copy.  ethcnn_ldp_step goes further: a luma / probs pointer that
- * lies inside such a buffer is read / written by the kernels IN PLACE (no copy launch at all).  Buffers still allocated when
+ * lies inside such a buffer is read / written by the kernels IN PLACE (no copy launch at all); so does ethcnn_predict_luma for ONE
+ * tightly packed picture (width % 16 == 0, up to 2304 CTUs): the launch pulls it over PCIe itself while it computes.  Buffers still allocated when
  * the context is destroyed are freed with it. */
 int ethcnn_host_alloc(ethcnn_ctx* ctx, size_t bytes, void** out);
 int ethcnn_host_free(ethcnn_ctx* ctx, void* p);
