@@ -203,7 +203,14 @@ struct ethcnn_ctx {
                              // Off by default: measured equal-to-1 % slower than the separate launches
     // completion word (page-locked host memory): the last block of a latency-path launch stores the launch's sequence number
     // there and the host spins on it instead of calling hipStreamSynchronize (~5 us sooner, scripts/ubench/launch_rtt.hip)
-    unsigned* h_done = nullptr;
+    unsigned* h_done = nullptr;  // (word 1: "a tile block of streamed picture <seq> gave up waiting for its rows", ethcnn_tile.hip)
+    // streamed input (ethcnn_ldp_step_begin / ethcnn_ldp_rows_ready / ethcnn_ldp_step_end): one page-locked word per CTU row, holding the
+    // number of the streamed picture whose rows are in the caller's buffer; the number of the NEXT streamed picture is fixed when
+    // the previous one ends, so filling threads may report rows before begin has been called
+    unsigned* h_rows = nullptr;
+    unsigned rows_seq = 1;
+    const unsigned* tile_wait_rows = nullptr;  // set around the tile launch of a streamed step
+    struct LdpPending { bool open = false, streamed = false; float* probs = nullptr; float* d_probs = nullptr; size_t pbytes = 0; int out = 0, nctu = 0; } ldp;
     unsigned done_seq = 0;     // last number handed out
     unsigned done_armed = 0;   // != 0: the LAST operation enqueued on the main stream stores this number when all its outputs are final
     int done_sync = 1;         // env ETHCNN_DONE_WORD=0: always hipStreamSynchronize (A/B runs)
@@ -237,6 +244,8 @@ struct ethcnn_ctx {
     HostPool* pool = nullptr;  // created on first use by the host / file entry points
     NumaCpus numa;             // the GPU's host NUMA node (staging buffers + fill threads are placed there)
 };
+
+constexpr int kStreamCtuRows = 1024;  // row words of a streamed picture (65,536 luma rows)
 
 static thread_local std::string g_create_err;
 
@@ -379,6 +388,10 @@ extern "C" int ethcnn_create(ethcnn_ctx** out, const ethcnn_options* opt) {
         return set_err(nullptr, ETHCNN_ERR_DEVICE, "cannot allocate the completion word on device %d", dev);
     }
     *c->h_done = 0;
+    c->h_done[1] = 0;
+    if (hipHostMalloc((void**)&c->h_rows, kStreamCtuRows * sizeof(unsigned), hipHostMallocDefault) != hipSuccess) c->h_rows = nullptr;  // (streamed
+    // steps then report ETHCNN_ERR_DEVICE; everything else works)
+    if (c->h_rows) std::memset(c->h_rows, 0, kStreamCtuRows * sizeof(unsigned));
     c->tile_blocks = c->cus = prop.multiProcessorCount;
     {   // the GPU's NUMA node -> its CPU list (/sys/devices/system/node/nodeN/cpulist: "64-127,192-255"); ETHCNN_NUMA_BIND=0 opts out
         int node = -1;
@@ -455,6 +468,7 @@ extern "C" void ethcnn_destroy(ethcnn_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();  // on THIS context's device: a launch still in flight may store the completion word
     if (c->h_done) { (void)hipHostFree(c->h_done); c->h_done = nullptr; }
+    if (c->h_rows) { (void)hipHostFree(c->h_rows); c->h_rows = nullptr; }
     for (auto& p : c->pending) { c->ev_pool.push_back(p.a); c->ev_pool.push_back(p.b); }
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     free_workspace(c);
@@ -816,7 +830,7 @@ static int serial_end(ethcnn_ctx* c) {
 // the single-launch form of a small pass (ethcnn_small.hip); fc1_out: ws.h1 (All-Intra) or the caller's vectors (resi).
 // Asynchronous on the main stream.
 static int run_small_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, bool resi, const Workspace& w,
-                          float* fc1_out, float qn, float* d_probs, int nchunks, bool pull = false) {
+                          float* fc1_out, float qn, float* d_probs, int nchunks, bool pull = false, const unsigned* wait_rows = nullptr) {
     const int words = small_pass_sync_words(n, nchunks);
     c->done_armed = 0;
     if (c->small_epoch >= (1 << 30)) c->ssync_clean = false;  // tags start over on a freshly zeroed area
@@ -837,7 +851,7 @@ static int run_small_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom&
     c->ssync_clean = false;  // until this launch has been enqueued without an error
     (void)hipGetLastError();
     const unsigned seq = resi ? 0u : done_arm(c);
-    { StageTimer t(c, ETHCNN_STAGE_FC1, n); launch_small_pass(d_luma, g, ctu0, n, resi, w, c->dw, fc1_out, qn, c->thr1, c->thr2, d_probs, nchunks, c->d_ssync, c->small_epoch, seq ? c->h_done : nullptr, seq, c->stream, pull); }
+    { StageTimer t(c, ETHCNN_STAGE_FC1, n); launch_small_pass(d_luma, g, ctu0, n, resi, w, c->dw, fc1_out, qn, c->thr1, c->thr2, d_probs, nchunks, c->d_ssync, c->small_epoch, seq ? c->h_done : nullptr, seq, c->stream, pull, wait_rows, c->rows_seq, c->h_done + 1); }
     const hipError_t le = hipGetLastError();
     if (le != hipSuccess) return set_err(c, ETHCNN_ERR_DEVICE, "launch of the single-launch small pass failed: %s", hipGetErrorString(le));
     c->ssync_clean = true;
@@ -1401,15 +1415,19 @@ extern "C" int ethcnn_resi_vectors_device(ethcnn_ctx* c, const uint8_t* d_luma, 
         const int n = std::min(c->max_ctus, g.nctu - o);
         rc = ensure_workspace(c, n, 1);
         if (rc) return rc;
-        if (c->small_launch && !c->luma_over_pcie && small_pass_ok(d_luma, g, n)) {  // one LDP frame: CTU load + trunk -> FC1 as one launch
-            rc = run_small_pass(c, d_luma, g, o, n, true, c->ws, d_vec + (size_t)o * kNVec, 0.0f, nullptr, 1);
+        // one LDP frame: CTU load + trunk -> FC1 as one launch -- for a picture in HBM, and (PULL form) for a page-locked one the
+        // caller is still filling (streamed input); a complete page-locked picture keeps the tile-stage launch (launch_small_pass)
+        const bool streamed = c->tile_wait_rows != nullptr && c->luma_over_pcie;
+        if (c->small_launch && (!c->luma_over_pcie || (streamed && c->pull)) && small_pass_ok(d_luma, g, n)) {
+            // (the sync area is laid out before anything is queued: run_small_pass may wait for the stream when it has to be re-zeroed)
+            rc = run_small_pass(c, d_luma, g, o, n, true, c->ws, d_vec + (size_t)o * kNVec, 0.0f, nullptr, 1, streamed, streamed ? c->tile_wait_rows : nullptr);
             if (rc) return rc;
             c->times.ctus += n;
             c->last_n = n;
             c->last_parity = 0;
             continue;
         }
-        { StageTimer t(c, ETHCNN_STAGE_TILE, n); launch_tile(d_luma, g, o, n, c->ws, 0, c->stream); }
+        { StageTimer t(c, ETHCNN_STAGE_TILE, n); launch_tile(d_luma, g, o, n, c->ws, 0, c->stream, 0, c->tile_wait_rows, c->rows_seq, c->h_done + 1); }
         { StageTimer t(c, ETHCNN_STAGE_TRUNK); launch_trunk(c->ws, c->dw, n, true, c->stream); }
         { StageTimer t(c, ETHCNN_STAGE_FC1, n); launch_fc1(c->ws, c->dw, n, d_vec + (size_t)o * kNVec, c->stream); }
         HIPCHK(c, hipGetLastError());
@@ -1501,6 +1519,28 @@ static int ensure_lstm_buffers(ethcnn_ctx* c, int n) {
 }
 
 // lstm() x3 + heads + gates on resident vectors: the part of sess.run after resi_cnn
+// the sync area of the LSTM launch for frames of n CTUs, zeroed where it has to be (see ethcnn_lstm_step_device).  May WAIT for the
+// stream (allocation, re-zeroing): a streamed step calls it before it queues kernels that wait for the caller.
+static int ensure_lgate(ethcnn_ctx* c, int n) {
+    const int gwords = lstm_frame_words(n);
+    if (c->lgate_n != n || c->lstm_epoch >= (1 << 30)) c->lgate_clean = false;
+    if (gwords > c->lgate_chunks || !c->lgate_clean) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (gwords > c->lgate_chunks) {
+            if (c->d_lgate) (void)hipFree(c->d_lgate);
+            c->d_lgate = nullptr;
+            c->lgate_chunks = 0;
+            HIPCHK(c, hipMalloc((void**)&c->d_lgate, (size_t)gwords * sizeof(int)));
+            c->lgate_chunks = gwords;
+        }
+        HIPCHK(c, hipMemsetAsync(c->d_lgate, 0, (size_t)c->lgate_chunks * sizeof(int), c->stream));  // stream-ordered
+        c->lstm_epoch = 0;
+        c->lgate_n = n;
+        c->lgate_clean = true;  // (zero and laid out for n: the launch below marks it dirty until it has been enqueued)
+    }
+    return 0;
+}
+
 extern "C" int ethcnn_lstm_step_device(ethcnn_ctx* c, const float* d_vec, const float* d_state_in, int n, int qp,
                                        int i_frame, float* d_state_out, float* d_probs) {
     if (!c || !d_vec || !d_state_out || !d_probs) return c ? set_err(c, ETHCNN_ERR_ARG, "null pointer") : ETHCNN_ERR_ARG;
@@ -1517,21 +1557,8 @@ extern "C" int ethcnn_lstm_step_device(ethcnn_ctx* c, const float* d_vec, const 
     // (the one-launch frame kernel keeps its counters, flags and claim words behind them; a claim word holds the tag of the last
     // launch that claimed it, so the area is zeroed again whenever the frame size -- and with it the layout -- changes, and
     // before the tags wrap)
-    const int gwords = lstm_frame_words(n);
-    if (c->lgate_n != n || c->lstm_epoch >= (1 << 30)) c->lgate_clean = false;
-    if (gwords > c->lgate_chunks || !c->lgate_clean) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (gwords > c->lgate_chunks) {
-            if (c->d_lgate) (void)hipFree(c->d_lgate);
-            c->d_lgate = nullptr;
-            c->lgate_chunks = 0;
-            HIPCHK(c, hipMalloc((void**)&c->d_lgate, (size_t)gwords * sizeof(int)));
-            c->lgate_chunks = gwords;
-        }
-        HIPCHK(c, hipMemsetAsync(c->d_lgate, 0, (size_t)c->lgate_chunks * sizeof(int), c->stream));  // stream-ordered
-        c->lstm_epoch = 0;
-        c->lgate_n = n;
-    }
+    rc = ensure_lgate(c, n);
+    if (rc) return rc;
     ++c->lstm_epoch;
     c->lgate_clean = false;  // until this launch has been enqueued without an error
     const unsigned seq = done_arm(c);
@@ -1556,15 +1583,24 @@ static bool in_pinned(const ethcnn_ctx* c, const void* p, size_t bytes) {
 }
 
 // predict_cu_depth() of resi_to_cu_depth_LDP.py:108-129 for one frame; the new state stays in HBM.
-// state source: host `state_in` when given, else zeros (resident == false) or the previous step's state in HBM
-static int ldp_step_impl(ethcnn_ctx* c, const uint8_t* luma, int w, int h, ptrdiff_t pitch, int qp, int i_frame,
-                         const float* state_in, bool resident, float* probs) {
+// state source: host `state_in` when given, else zeros (resident == false) or the previous step's state in HBM.
+// Two halves: ldp_step_begin enqueues everything, ldp_step_end waits and finishes the bookkeeping.  streamed: the caller is still
+// FILLING the page-locked luma buffer (ethcnn_ldp_rows_ready reports its CTU rows); the tile stage waits for them row by row.
+static int ldp_step_begin(ethcnn_ctx* c, const uint8_t* luma, int w, int h, ptrdiff_t pitch, int qp, int i_frame,
+                          const float* state_in, bool resident, float* probs, bool streamed) {
     if (!c || !luma || !probs) return c ? set_err(c, ETHCNN_ERR_ARG, "null pointer") : ETHCNN_ERR_ARG;
+    if (c->ldp.open) return set_err(c, ETHCNN_ERR_ARG, "ethcnn_ldp_step_begin: the previous streamed step has not been ended (ethcnn_ldp_step_end)");
     if (w <= 0 || h <= 0 || pitch < w) return set_err(c, ETHCNN_ERR_ARG, "bad geometry");
     if (!c->have_weights) return set_err(c, ETHCNN_ERR_NOWEIGHTS, "no CNN weights loaded");
     if (!c->have_lstm) return set_err(c, ETHCNN_ERR_NOWEIGHTS, "no LSTM weights loaded");
     const int nctu = ((w + 63) / 64) * ((h + 63) / 64);
     const size_t lbytes = (size_t)(h - 1) * pitch + w;  // the meaningful bytes of a pitched plane
+    if (streamed) {
+        if (!c->h_rows) return set_err(c, ETHCNN_ERR_DEVICE, "ethcnn_ldp_step_begin: no page-locked memory for the row words");
+        if ((h + 63) / 64 > kStreamCtuRows) return set_err(c, ETHCNN_ERR_ARG, "ethcnn_ldp_step_begin: more than %d CTU rows", kStreamCtuRows);
+        if (!in_pinned(c, luma, lbytes))
+            return set_err(c, ETHCNN_ERR_ARG, "ethcnn_ldp_step_begin: the luma buffer must come from ethcnn_host_alloc (the kernels read it in place while it is filled)");
+    }
     int rc = ensure_staging(c, lbytes, (size_t)nctu * kNVec * 4);
     if (rc) return rc;
     if (nctu > c->lstm_cap) c->state_cur = -1;  // the buffers are about to be reallocated
@@ -1590,34 +1626,93 @@ static int ldp_step_impl(ethcnn_ctx* c, const uint8_t* luma, int w, int h, ptrdi
     // 1080p call against 128.3 us for "DMA it into HBM first, then the single-launch pass" (profiles/r03_latency_ldp.txt;
     // ETHCNN_LDP_INPLACE=0 selects the latter for A/B runs)
     static const bool copy_first = [] { const char* e = dev_env("ETHCNN_LDP_INPLACE"); return e && std::atoi(e) == 0; }();
-    const bool in_place = in_pinned(c, luma, lbytes) && !copy_first;
+    const bool in_place = in_pinned(c, luma, lbytes) && (streamed || !copy_first);
     if (in_place) d_luma = luma;
     else HIPCHK(c, hipMemcpyAsync(c->d_in[0], luma, lbytes, hipMemcpyHostToDevice, c->stream));
     const size_t pbytes = (size_t)nctu * kNOut * 4;
     // probabilities: straight into page-locked host memory (the caller's, else the staging buffer + one memcpy), the launch's
     // last block reports through the completion word
     float* d_probs = in_pinned(c, probs, pbytes) ? probs : (c->done_sync ? c->h_out[0] : c->d_lprobs);
+    if (streamed) {
+        // everything that may wait for the stream (allocations, re-zeroing of sync areas) happens BEFORE kernels are queued that wait
+        // for the caller -- who may be this very thread, about to fill the buffer when the call returns
+        HIPCHK(c, hipSetDevice(c->device));
+        rc = ensure_workspace(c, std::min(nctu, c->max_ctus), (nctu + kSubBatch - 1) / kSubBatch);
+        if (rc == 0) rc = ensure_lgate(c, nctu);
+        if (rc) return rc;
+    }
     c->luma_over_pcie = (d_luma == luma);
+    c->tile_wait_rows = streamed ? c->h_rows : nullptr;
     rc = ethcnn_resi_vectors_device(c, d_luma, w, h, pitch, c->d_vec);
     c->luma_over_pcie = false;
-    if (rc) return rc;
-    rc = ethcnn_lstm_step_device(c, c->d_vec, in >= 0 ? c->d_state[in] : nullptr, nctu, qp, i_frame, c->d_state[out], d_probs);
-    if (rc) return rc;
-    if (d_probs == c->d_lprobs) {
+    c->tile_wait_rows = nullptr;
+    if (rc == 0) rc = ethcnn_lstm_step_device(c, c->d_vec, in >= 0 ? c->d_state[in] : nullptr, nctu, qp, i_frame, c->d_state[out], d_probs);
+    if (rc) {
+        // (streamed: kernels already queued may be waiting for rows the caller will now never report: release them -- the result is
+        // discarded -- so that the stream drains)
+        if (streamed) { for (int cy = 0; cy < (h + 63) / 64; ++cy) __atomic_store_n(c->h_rows + cy, c->rows_seq, __ATOMIC_RELEASE); ++c->rows_seq; if (c->rows_seq == 0) c->rows_seq = 1; }
+        return rc;
+    }
+    c->ldp.open = true;
+    c->ldp.streamed = streamed;
+    c->ldp.probs = probs;
+    c->ldp.d_probs = d_probs;
+    c->ldp.pbytes = pbytes;
+    c->ldp.out = out;
+    c->ldp.nctu = nctu;
+    return ETHCNN_OK;
+}
+
+static int ldp_step_end(ethcnn_ctx* c) {
+    if (!c) return ETHCNN_ERR_ARG;
+    if (!c->ldp.open) return set_err(c, ETHCNN_ERR_ARG, "ethcnn_ldp_step_end: no step has been begun");
+    c->ldp.open = false;
+    const unsigned seq = c->rows_seq;
+    if (c->ldp.streamed) {  // the next streamed picture's number is fixed from here on (ethcnn_ldp_rows_ready may run before its begin)
+        ++c->rows_seq;
+        if (c->rows_seq == 0) c->rows_seq = 1;
+    }
+    if (c->ldp.d_probs == c->d_lprobs) {
         c->done_armed = 0;
-        HIPCHK(c, hipMemcpyAsync(probs, c->d_lprobs, pbytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->ldp.probs, c->d_lprobs, c->ldp.pbytes, hipMemcpyDeviceToHost, c->stream));
     }
     HIPCHK(c, stream_sync(c));
-    if (d_probs == c->h_out[0]) std::memcpy(probs, d_probs, pbytes);
-    c->state_cur = out;
-    c->state_nctu = nctu;
+    if (c->ldp.streamed && __atomic_load_n(c->h_done + 1, __ATOMIC_ACQUIRE) == seq) {
+        c->state_cur = -1;  // computed on rows that never arrived
+        return set_err(c, ETHCNN_ERR_DEVICE, "ethcnn_ldp_step_end: the kernels waited 1 s for luma rows that were never reported (ethcnn_ldp_rows_ready)");
+    }
+    if (c->ldp.d_probs == c->h_out[0]) std::memcpy(c->ldp.probs, c->ldp.d_probs, c->ldp.pbytes);
+    c->state_cur = c->ldp.out;
+    c->state_nctu = c->ldp.nctu;
     return ETHCNN_OK;
+}
+
+static int ldp_step_impl(ethcnn_ctx* c, const uint8_t* luma, int w, int h, ptrdiff_t pitch, int qp, int i_frame,
+                         const float* state_in, bool resident, float* probs) {
+    const int rc = ldp_step_begin(c, luma, w, h, pitch, qp, i_frame, state_in, resident, probs, false);
+    return rc ? rc : ldp_step_end(c);
 }
 
 extern "C" int ethcnn_ldp_step(ethcnn_ctx* c, const uint8_t* luma, int w, int h, ptrdiff_t pitch, int qp, int i_frame,
                                const float* state_in, float* probs) {
     return ldp_step_impl(c, luma, w, h, pitch, qp, i_frame, state_in, /*resident=*/!state_in && i_frame > 1, probs);
 }
+
+// ---- streamed input: begin (kernels queued, waiting for rows) | rows_ready (any thread, as the buffer fills) | end
+extern "C" int ethcnn_ldp_step_begin(ethcnn_ctx* c, const uint8_t* luma, int w, int h, ptrdiff_t pitch, int qp, int i_frame,
+                                     const float* state_in, float* probs) {
+    return ldp_step_begin(c, luma, w, h, pitch, qp, i_frame, state_in, /*resident=*/!state_in && i_frame > 1, probs, true);
+}
+
+extern "C" int ethcnn_ldp_rows_ready(ethcnn_ctx* c, int ctu_row_begin, int ctu_row_end) {
+    // (thread-safe: touches nothing but the row words; no error text -- another thread may be inside a call on this context)
+    if (!c || !c->h_rows || ctu_row_begin < 0 || ctu_row_end > kStreamCtuRows || ctu_row_begin > ctu_row_end) return ETHCNN_ERR_ARG;
+    const unsigned seq = __atomic_load_n(&c->rows_seq, __ATOMIC_RELAXED);
+    for (int cy = ctu_row_begin; cy < ctu_row_end; ++cy) __atomic_store_n(c->h_rows + cy, seq, __ATOMIC_RELEASE);
+    return ETHCNN_OK;
+}
+
+extern "C" int ethcnn_ldp_step_end(ethcnn_ctx* c) { return ldp_step_end(c); }
 
 extern "C" int ethcnn_ldp_get_state(ethcnn_ctx* c, float* state_out, size_t nfloats) {
     if (!c || !state_out) return c ? set_err(c, ETHCNN_ERR_ARG, "null pointer") : ETHCNN_ERR_ARG;

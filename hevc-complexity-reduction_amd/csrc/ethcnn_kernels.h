@@ -31,8 +31,10 @@ struct FrameGeom {
 // k0: luma frames -> xs/xm/xl for CTUs [ctu0, ctu0 + n) of the frame sequence; also clears the first
 // n_flags ints of ws.flags (the pass's gate predicates; 0 = leave them alone)
 // max_blocks > 0: slab-staged persistent form with at most that many blocks (one per CU when it runs beside FC1)
+// wait_rows != null (streamed input, one frame): page-locked host words, one per CTU row; a group is loaded once the words of its
+// CTU rows hold wait_seq (ethcnn_tile.hip, TileWait); *gave_up = wait_seq if a block waited ~1 s in vain
 void launch_tile(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, const Workspace& ws, int n_flags,
-                 hipStream_t s, int max_blocks = 0);
+                 hipStream_t s, int max_blocks = 0, const unsigned* wait_rows = nullptr, unsigned wait_seq = 0, unsigned* gave_up = nullptr);
 // k1: xs/xm/xl -> feat (fc1_plan 1 / 2: -> featb, every feature as three bf16 / two fp16 pieces in the 16-bit MFMA's operand order)
 void launch_trunk(const Workspace& ws, const DeviceWeights& w, int n, bool resi, hipStream_t s, int fc1_plan = 0);
 // k1 with the CTU-load stage folded in (A/B form, experiments build: ethcnn_trunk.hip); needs small_pass_ok-style 16-byte alignment
@@ -67,7 +69,9 @@ bool small_pass_ok(const uint8_t* d_luma, const FrameGeom& g, int n);
 int small_pass_sync_words(int n, int nchunks);
 void launch_small_pass(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, bool resi, const Workspace& ws,
                        const DeviceWeights& w, float* fc1_out, float qn, float thr1, float thr2, float* d_probs, int nchunks,
-                       int* d_sync, int epoch, unsigned* done, unsigned done_seq, hipStream_t s, bool pull = false);
+                       int* d_sync, int epoch, unsigned* done, unsigned done_seq, hipStream_t s, bool pull = false,
+                       const unsigned* wait_rows = nullptr, unsigned wait_seq = 0, unsigned* gave_up = nullptr);
+// wait_rows (with pull; streamed input, as launch_tile's): a group is pulled once the caller has reported its CTU rows
 // pull: d_luma is page-locked HOST memory; the launch's first blocks read it over PCIe into the workspace's pixel records (xs / xm /
 // xl) and the trunk starts group by group as they land (ethcnn_small.hip, "PULL form")
 // k5: apply the batch gates in place on d_probs

@@ -47,6 +47,7 @@ namespace ethcnn {
 struct SmallParams {
     DirectSrc src;                // PULL form: `luma` is page-locked host memory, read once by the pull blocks ...
     uint4 *xs, *xm, *xl;          // ... into the pixel records of the pass (the workspace's: ethcnn_tile.hip layouts)
+    TileWait tw;                  // streamed input (rows != null): a pull item first waits for the caller to report its CTU rows
     const float* trunk_w;
     const float* trunk_b;
     float* feat;
@@ -192,6 +193,7 @@ __device__ __forceinline__ void do_pull_item(const SmallParams& P, const SmallSy
     const bool mine = sh->owned != 0;
     __syncthreads();
     if (!mine) return;
+    if (P.tw.rows != nullptr) tile_wait_rows(P.tw, P.src.ctu0, grp, P.src.n_total, P.src.nctu, P.src.cw);
     tile_group<true, true, true>(reinterpret_cast<uint32_t*>(smem), P.src.luma, P.src.width, P.src.height, P.src.pitch, P.src.frame_stride, P.src.cw,
                                  P.src.nctu, P.src.ctu0, P.src.n_total, grp, P.xs, P.xm, P.xl);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the records (agent-scope stores) have completed before the flags move
@@ -431,11 +433,16 @@ static void launch_small_t(const SmallParams& P, int shape, unsigned blocks, hip
 
 void launch_small_pass(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, bool resi, const Workspace& ws,
                        const DeviceWeights& w, float* fc1_out, float qn, float thr1, float thr2, float* d_probs, int nchunks,
-                       int* d_sync, int epoch, unsigned* done, unsigned done_seq, hipStream_t s, bool pull) {
-    // (the LDP front-end keeps the tile-stage launch for page-locked luma: measured equal to slower in PULL form -- 1080p 116 against
-    // 105 us per resident-state call, 2160p 313 against 317 -- its launch ends with FC1 and has no long tail to hide the bus under)
-    if (resi) pull = false;
+                       int* d_sync, int epoch, unsigned* done, unsigned done_seq, hipStream_t s, bool pull, const unsigned* wait_rows,
+                       unsigned wait_seq, unsigned* gave_up) {
+    // (the LDP front-end keeps the tile-stage launch for a COMPLETE page-locked picture: measured equal to slower in PULL form -- 1080p
+    // 116 against 105 us per resident-state call, 2160p 313 against 317 -- its launch ends with FC1 and has no long tail to hide the
+    // bus under.  Streamed input is another matter: the rows arrive at the caller's pace, and trunk + FC1 of the first rows run
+    // while the caller is still copying the last ones.)
+    if (resi && wait_rows == nullptr) pull = false;
+    if (!pull) wait_rows = nullptr;
     SmallParams P;
+    P.tw = TileWait{wait_rows, wait_seq, gave_up};
     P.xs = ws.xs;
     P.xm = ws.xm;
     P.xl = ws.xl;
@@ -509,9 +516,10 @@ void launch_small_pass(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int
     // one block per group: the whole picture is 2 MiB, and a block's second group would wait for its first (84 against 87-92 us).
     // (scripts/ubench/small_probe.hip W H 0 1, profiles/r04_pull_timeline.txt)
     static const int npull_env = [] { const char* e = dev_env("ETHCNN_PULL_BLOCKS"); return e ? atoi(e) : 0; }();  // development knob
-    P.npull = !pull ? 0 : std::min(P.ngroups, npull_env > 0 ? npull_env : (P.ngroups <= 32 ? 32 : 16));
+    // (streamed input: one pull block per group -- each sleeps until the caller has reported its rows, so the caller sets the order)
+    P.npull = !pull ? 0 : (wait_rows ? P.ngroups : std::min(P.ngroups, npull_env > 0 ? npull_env : (P.ngroups <= 32 ? 32 : 16)));
     blocks += (unsigned)P.npull;
-    if (resi) launch_small_t<true, false>(P, shape, blocks, s);  // (pull == false: see above)
+    if (resi) pull ? launch_small_t<true, true>(P, shape, blocks, s) : launch_small_t<true, false>(P, shape, blocks, s);
     else pull ? launch_small_t<false, true>(P, shape, blocks, s) : launch_small_t<false, false>(P, shape, blocks, s);
 }
 

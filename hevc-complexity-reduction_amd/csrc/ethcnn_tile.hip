@@ -20,11 +20,11 @@
 
 namespace ethcnn {
 
-template <bool FAST>
+template <bool FAST, bool WAIT>
 __global__ __launch_bounds__(256) void k0_tile_slab(const uint8_t* __restrict__ luma, int width, int height, long pitch,
                                                     long frame_stride, int cw, int nctu, long ctu0, int n_total,
                                                     uint4* __restrict__ XS, uint4* __restrict__ XM,
-                                                    uint4* __restrict__ XL, int* __restrict__ gate_flags, int n_flags) {
+                                                    uint4* __restrict__ XL, int* __restrict__ gate_flags, int n_flags, TileWait tw) {
     __shared__ uint32_t tile[16 * kSlabCtuPitch];
     if (blockIdx.x == 0)
         for (int i = threadIdx.x; i < n_flags; i += 256) gate_flags[i] = 0;
@@ -33,22 +33,30 @@ __global__ __launch_bounds__(256) void k0_tile_slab(const uint8_t* __restrict__ 
     const int ngroups = (n_total + 15) >> 4;
 #pragma unroll 1
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        if (WAIT) tile_wait_rows(tw, ctu0, grp, n_total, nctu, cw);
         tile_group<FAST, false, false>(tile, luma, width, height, pitch, frame_stride, cw, nctu, ctu0, n_total, grp, XS, XM, XL);
     }  // groups of this block
 }
 
 void launch_tile(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, const Workspace& ws, int n_flags,
-                 hipStream_t s, int max_blocks) {
+                 hipStream_t s, int max_blocks, const unsigned* wait_rows, unsigned wait_seq, unsigned* gave_up) {
     const int blocks = (n + 15) / 16;
     const bool fast = (g.width % 16 == 0) && (g.pitch % 16 == 0) && (g.frame_stride % 16 == 0) &&
                       (reinterpret_cast<uintptr_t>(d_luma) % 16 == 0);
     const int sb = max_blocks > 0 ? (blocks < max_blocks ? blocks : max_blocks) : blocks;
-    if (fast)
-        hipLaunchKernelGGL(k0_tile_slab<true>, dim3(sb), dim3(256), 0, s, d_luma, g.width, g.height, g.pitch,
-                           g.frame_stride, g.cw, g.nctu, ctu0, n, ws.xs, ws.xm, ws.xl, ws.flags, n_flags);
+    const TileWait tw{wait_rows, wait_seq, gave_up};
+    if (wait_rows && fast)
+        hipLaunchKernelGGL((k0_tile_slab<true, true>), dim3(sb), dim3(256), 0, s, d_luma, g.width, g.height, g.pitch,
+                           g.frame_stride, g.cw, g.nctu, ctu0, n, ws.xs, ws.xm, ws.xl, ws.flags, n_flags, tw);
+    else if (wait_rows)
+        hipLaunchKernelGGL((k0_tile_slab<false, true>), dim3(sb), dim3(256), 0, s, d_luma, g.width, g.height, g.pitch,
+                           g.frame_stride, g.cw, g.nctu, ctu0, n, ws.xs, ws.xm, ws.xl, ws.flags, n_flags, tw);
+    else if (fast)
+        hipLaunchKernelGGL((k0_tile_slab<true, false>), dim3(sb), dim3(256), 0, s, d_luma, g.width, g.height, g.pitch,
+                           g.frame_stride, g.cw, g.nctu, ctu0, n, ws.xs, ws.xm, ws.xl, ws.flags, n_flags, tw);
     else
-        hipLaunchKernelGGL(k0_tile_slab<false>, dim3(sb), dim3(256), 0, s, d_luma, g.width, g.height, g.pitch,
-                           g.frame_stride, g.cw, g.nctu, ctu0, n, ws.xs, ws.xm, ws.xl, ws.flags, n_flags);
+        hipLaunchKernelGGL((k0_tile_slab<false, false>), dim3(sb), dim3(256), 0, s, d_luma, g.width, g.height, g.pitch,
+                           g.frame_stride, g.cw, g.nctu, ctu0, n, ws.xs, ws.xm, ws.xl, ws.flags, n_flags, tw);
 }
 
 }  // namespace ethcnn

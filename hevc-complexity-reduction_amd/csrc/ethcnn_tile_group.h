@@ -33,6 +33,39 @@ __device__ __forceinline__ uint4 nt_load(const uint4* p) {
     return make_uint4(v[0], v[1], v[2], v[3]);
 }
 
+// WAIT (streamed input, ethcnn_ldp_step_begin): the picture lies in page-locked HOST memory that the caller is STILL FILLING when the
+// kernel starts -- an encoder-side reader copying resi.yuv out of the page cache, CTU row by CTU row.  rows[cy] == seq says "the 64
+// luma rows of CTU row cy of picture `seq` are in the buffer" (ethcnn_ldp_rows_ready: a release store by the filling thread; the
+// device's reads of host memory snoop the CPU caches and x86 makes the stores visible in order, so data read AFTER the flag is the
+// new picture's).  One thread per block polls the flags of its group's one or two CTU rows with system-scope loads.  A caller
+// that dies between begin and end must not hang the GPU: after ~1 s of wall clock the block gives up, stores `seq` to *gave_up (the
+// call then fails in ethcnn_ldp_step_end) and goes on with whatever is in the buffer.
+struct TileWait {
+    const unsigned* rows;  // page-locked host memory, one word per CTU row; null: no waiting (WAIT == false)
+    unsigned seq;
+    unsigned* gave_up;     // page-locked host memory
+};
+
+// every thread of the block; returns behind a barrier
+__device__ __forceinline__ void tile_wait_rows(const TileWait& tw, long ctu0, int grp, int n_total, int nctu, int cw) {
+    if (threadIdx.x == 0) {
+        const int r0 = (int)((ctu0 + grp * 16) % nctu), r1 = (int)((ctu0 + min(grp * 16 + 15, n_total - 1)) % nctu);
+        unsigned long long t0;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+        for (int cy = r0 / cw; cy <= r1 / cw; ++cy)
+            while (__hip_atomic_load(tw.rows + cy, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != tw.seq) {
+                __builtin_amdgcn_s_sleep(16);
+                unsigned long long t;
+                asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+                if (t - t0 > 100000000ull) {  // 1 s at 100 MHz
+                    __hip_atomic_store(tw.gave_up, tw.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+            }
+    }
+    __syncthreads();
+}
+
 // One group.  `tile`: 16 * kSlabCtuPitch dwords of LDS.  FAST: rows are 16-byte aligned (width, pitch, frame stride, base).
 // SC1: the records are consumed INSIDE this launch (agent-scope stores; the caller completes them -- s_waitcnt vmcnt(0) --
 // before it signals); otherwise streaming stores for the next launch.  ALL: the four slabs' loads are requested at once

@@ -151,6 +151,24 @@ int ethcnn_ldp_predict_frame(ethcnn_ctx* ctx, const uint8_t* luma, int width, in
 int ethcnn_ldp_step(ethcnn_ctx* ctx, const uint8_t* luma, int width, int height, ptrdiff_t pitch, int qp, int i_frame,
                     const float* state_in /* may be NULL */, float* probs);
 int ethcnn_ldp_get_state(ethcnn_ctx* ctx, float* state_out, size_t nfloats /* nctu * 896 */);
+/* ethcnn_ldp_step with STREAMED INPUT: the frame's kernels are queued BEFORE its luma is in memory, and consume it CTU row by CTU row
+ * while the caller is still filling the buffer -- the daemon's threads copying resi.yuv out of the page cache
+ * (resi_to_cu_depth_LDP.py:116-118 reads the file, THEN predicts: 52 us + 115 us at 1920x1080; streamed, the transfer over PCIe
+ * and the launch overheads run under the read).
+ *   ethcnn_ldp_step_begin   arguments as ethcnn_ldp_step; luma MUST lie in a buffer from ethcnn_host_alloc (read in place).  Returns
+ *                           once everything is queued.  Until ethcnn_ldp_step_end no other call may be made on this context
+ *                           except ethcnn_ldp_rows_ready.
+ *   ethcnn_ldp_rows_ready   "luma rows [64 ctu_row_begin, 64 ctu_row_end) are in the buffer" (the last CTU row may be short).  Any
+ *                           thread, any order, each CTU row once; may be called BEFORE ethcnn_ldp_step_begin of the same frame, but
+ *                           not before the previous streamed step has ended.  Every CTU row [0, ceil(height / 64)) must be
+ *                           reported: kernels that wait ~1 s for a row give up, and ethcnn_ldp_step_end then fails with
+ *                           ETHCNN_ERR_DEVICE (the resident state is dropped; the GPU is not left hanging).
+ *   ethcnn_ldp_step_end     waits; probs (the pointer given to begin) and the resident state are final when it returns ETHCNN_OK.
+ * Results are bit-identical to ethcnn_ldp_step's. */
+int ethcnn_ldp_step_begin(ethcnn_ctx* ctx, const uint8_t* luma, int width, int height, ptrdiff_t pitch, int qp, int i_frame,
+                          const float* state_in /* may be NULL */, float* probs);
+int ethcnn_ldp_rows_ready(ethcnn_ctx* ctx, int ctu_row_begin, int ctu_row_end);
+int ethcnn_ldp_step_end(ethcnn_ctx* ctx);
 /* Pinned (page-locked) host memory: buffers a caller fills itself (file reads) and hands to the host entry points are
  * DMA-able directly, without the runtime's pageable staging copy.  ethcnn_ldp_step goes further: a luma / probs pointer that
  * lies inside such a buffer is read / written by the kernels IN PLACE (no copy launch at all); so does ethcnn_predict_luma for ONE

@@ -3,7 +3,9 @@
 as TEncGOP.cpp:1466-1506 does (command.dat, pred_start.sig, busy wait on pred_end.sig, fread cu_depth.dat) against
 
     python   the Python daemon   (hevc-complexity-reduction_amd/resi_to_cu_depth_LDP.py through the root launcher)
-    native   the C daemon        (tools/resi_to_cu_depth_ldp.c over the C ABI; inotify wake-up)
+    native   the C daemon        (tools/resi_to_cu_depth_ldp.c over the C ABI; inotify wake-up; resi.yuv streamed into the running
+             prediction: ethcnn_ldp_step_begin / rows_ready / end;  native-spin: + --spin, the reference daemon's busy wait for
+             pred_start.sig;  native-nostream: --no-stream, read first, then predict)
 
 for 1920x1080 and 416x240, frames back to back and with a 5 ms gap (an encoder encodes between two requests), working directory
 on tmpfs (/dev/shm) and on the box's disk (/tmp).  Per run: handshake p50 / p90 / p99 in us, and that the two daemons answered
@@ -37,6 +39,10 @@ def run(kind, base, w, h, frames, gap_us, qp=32):
             cmd = [sys.executable, "resi_to_cu_depth_LDP.py", "--max-frames", str(frames), "--idle-timeout", "120"]
         else:
             cmd = [os.path.join(BIN, "resi_to_cu_depth_ldp"), "--max-frames", str(frames), "--idle-timeout", "120", "--quiet", "--trace"]
+            if kind == "native-nostream":  # A/B: read resi.yuv first, then predict (the round's first form of the daemon)
+                cmd.append("--no-stream")
+            if kind == "native-spin":      # busy-wait for pred_start.sig, as the reference's daemon does
+                cmd.append("--spin")
         d = subprocess.Popen(cmd, cwd=work, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
         time.sleep(6.0 if kind == "python" else 2.5)  # the daemon is started before the encoder, as with the reference
         c = subprocess.run([os.path.join(BIN, "ldp_client"), work, str(w), str(h), str(qp), str(frames), "--gap-us", str(gap_us),
@@ -66,13 +72,13 @@ def main():
         for (w, h) in ((1920, 1080), (416, 240)):
             for gap in (0, 5000):
                 res = {}
-                for kind in ("python", "native"):
+                for kind in ("python", "native", "native-spin", "native-nostream"):
                     line, digest, state = run(kind, base, w, h, frames if gap == 0 else max(100, frames // 5), gap)
                     res[kind] = (digest, state)
-                    print("%-8s %-8s %s" % (base, kind, line))
-                same = res["python"] == res["native"]
+                    print("%-8s %-15s %s" % (base, kind, line))
+                same = res["python"] == res["native"] == res["native-nostream"] == res["native-spin"]
                 ok &= same
-                print("         -> per-frame cu_depth.dat digests and the final state.dat of the two daemons: %s" % ("IDENTICAL" if same else "DIFFER"))
+                print("         -> per-frame cu_depth.dat digests and the final state.dat of the four runs: %s" % ("IDENTICAL" if same else "DIFFER"))
     return 0 if ok else 1
 
 

@@ -46,9 +46,11 @@ def _client(work, w, h, frames, seed=7):
 @pytest.mark.parametrize("w,h,frames", [(1920, 1080, 40), (416, 240, 60), (200, 136, 12)])
 def test_native_daemon_matches_the_python_daemon(tmp_path, w, h, frames):
     out = {}
-    for kind in ("python", "native"):
+    # native: resi.yuv streamed into the running prediction (pictures of >= 512 KiB: ethcnn_ldp_step_begin / rows_ready / end, eight
+    # reader threads); native-plain: --no-stream --spin (read first, then ethcnn_ldp_step; the reference daemon's busy wait)
+    for kind in ("python", "native", "native-plain"):
         work = _workdir(str(tmp_path / kind))
-        d = _serve(kind, work, frames)
+        d = _serve(kind, work, frames, extra=("--no-stream", "--spin") if kind == "native-plain" else ())
         c = _client(work, w, h, frames)
         d.wait(timeout=60)
         assert c.returncode == 0 and d.returncode == 0, (kind, c.stderr[-500:], d.stderr.read()[-800:])
@@ -56,7 +58,8 @@ def test_native_daemon_matches_the_python_daemon(tmp_path, w, h, frames):
         out[kind] = (open(os.path.join(work, "digest.txt")).read(), hashlib.md5(open(os.path.join(work, "state.dat"), "rb").read()).hexdigest(),
                      open(os.path.join(work, "state.dat.idx")).read().split())
         assert not [f for f in os.listdir(work) if ".tmp." in f]
-    assert out["python"][0] == out["native"][0], "per-frame cu_depth.dat digests differ"
+    assert out["python"][0] == out["native"][0] == out["native-plain"][0], "per-frame cu_depth.dat digests differ"
+    assert out["python"][1] == out["native-plain"][1]
     assert len(out["native"][0].splitlines()) == frames
     assert out["python"][1] == out["native"][1], "state.dat differs"
     assert out["python"][2] == out["native"][2] == [str(frames), str(w), str(h)]

@@ -247,6 +247,92 @@ def test_ldp_step_keeps_the_state_resident(pkg, oracle, lstm):
         b.close()
 
 
+def test_ldp_step_streamed_input(pkg, oracle, lstm):
+    """ethcnn_ldp_step_begin / ethcnn_ldp_rows_ready / ethcnn_ldp_step_end: the frame's kernels are queued on a page-locked buffer that
+    a filling thread is still writing, CTU row by CTU row in a scrambled order, some rows reported before begin was even called --
+    bit-identical to ethcnn_ldp_step (probabilities and resident state) over a recurrence, for frame widths with and without
+    16-byte rows and a height that ends in a short CTU row.  Misuse: luma outside page-locked memory, a second begin, end without
+    begin -> ETHCNN_ERR_ARG.  A row that is never reported: the kernels give up after ~1 s, ethcnn_ldp_step_end fails, the GPU is not
+    left hanging and the context keeps working."""
+    import threading
+    import time
+    e = pkg.ethcnn
+    rng = np.random.default_rng(77)
+    cblob, lblob = oracle.synth_blob(23, 1.0), lstm.synth_lstm_blob(24, 3.0)
+    a, b = pkg.EthCnn(device=0), pkg.EthCnn(device=0)
+    try:
+        for c in (a, b):
+            c.load_blob(cblob)
+            c.load_lstm_blob(lblob)
+            c.set_thresholds(0.5, 0.5)
+        for (w, h) in ((1920, 1080), (424, 240), (832, 480)):
+            nctu, nrows = e.ctus_per_frame(w, h), (h + 63) // 64
+            pin = a.host_buffer(w * h)
+            pprobs = a.host_buffer(nctu * 21 * 4).view(np.float32)
+            for i_frame in (1, 2, 3, 4):
+                luma = rng.integers(0, 256, size=(h, w), dtype=np.uint8)
+                want = b.ldp_step(luma, w, h, 27, i_frame)
+                order = rng.permutation(nrows)
+                early = order[:2] if i_frame % 2 == 0 else order[:0]  # reported BEFORE begin (allowed once the previous step has ended)
+                pin[:] = 0xAA                                          # (the previous frame's pixels must not be what is read)
+                def put(cy):
+                    pin[cy * 64 * w:min(h, cy * 64 + 64) * w] = luma[cy * 64:cy * 64 + 64].reshape(-1)
+                    a.ldp_rows_ready(cy, cy + 1)
+                for cy in early:
+                    put(int(cy))
+                def filler():
+                    time.sleep(0.002)
+                    for cy in order[len(early):]:
+                        put(int(cy))
+                        time.sleep(0.0002)
+                t = threading.Thread(target=filler)
+                t.start()
+                a.ldp_step_begin(pin, w, h, 27, i_frame, pprobs)
+                t.join()
+                a.ldp_step_end()
+                assert np.array_equal(_bits(pprobs.reshape(nctu, 21)), _bits(want)), (w, h, i_frame)
+                assert np.array_equal(_bits(a.ldp_get_state(w, h)), _bits(b.ldp_get_state(w, h))), (w, h, i_frame)
+            # the plain call still works on the same context and the same resident state
+            luma = rng.integers(0, 256, size=(h, w), dtype=np.uint8)
+            assert np.array_equal(_bits(a.ldp_step(luma, w, h, 27, 5)), _bits(b.ldp_step(luma, w, h, 27, 5))), (w, h)
+            a.free_host_buffers()
+        # misuse
+        w, h = 416, 240
+        nctu = e.ctus_per_frame(w, h)
+        pin = a.host_buffer(w * h)
+        pprobs = a.host_buffer(nctu * 21 * 4).view(np.float32)
+        with pytest.raises(e.EthCnnError):
+            a.ldp_step_begin(np.zeros(w * h, np.uint8), w, h, 27, 1, pprobs)  # pageable luma
+        with pytest.raises(e.EthCnnError):
+            a.ldp_step_end()                                                   # nothing begun
+        with pytest.raises(ValueError):
+            a.ldp_rows_ready(3, 2)
+        a.ldp_step_begin(pin, w, h, 27, 1, pprobs)
+        with pytest.raises(e.EthCnnError):
+            a.ldp_step_begin(pin, w, h, 27, 1, pprobs)                         # still open
+        a.ldp_rows_ready(0, (h + 63) // 64)
+        a.ldp_step_end()
+        # a row that never comes
+        luma = rng.integers(0, 256, size=(h, w), dtype=np.uint8)
+        pin[:] = luma.reshape(-1)
+        a.ldp_step_begin(pin, w, h, 27, 1, pprobs)
+        a.ldp_rows_ready(0, (h + 63) // 64 - 1)
+        t0 = time.time()
+        with pytest.raises(e.EthCnnError, match="never reported"):
+            a.ldp_step_end()
+        assert 0.5 < time.time() - t0 < 10.0
+        with pytest.raises(e.EthCnnError):
+            a.ldp_step(luma, w, h, 27, 2)                                      # the state of that frame was dropped
+        assert np.array_equal(_bits(a.ldp_step(luma, w, h, 27, 1)), _bits(b.ldp_step(luma, w, h, 27, 1)))
+        a.ldp_rows_ready(0, (h + 63) // 64)                                    # streamed again, right behind the failure
+        a.ldp_step_begin(pin, w, h, 27, 2, pprobs)
+        a.ldp_step_end()
+        assert np.array_equal(_bits(pprobs.reshape(nctu, 21)), _bits(b.ldp_step(luma, w, h, 27, 2)))
+    finally:
+        a.close()
+        b.close()
+
+
 def test_one_launch_frame_kernel_both_forms_and_forced_claim_or_execute(pkg, oracle, lstm):
     """An LDP frame's LSTM cells and heads run as ONE dataflow launch up to 640 CTUs (k_lstm_frame: heads blocks wait for the cells
     of their group and level inside the grid) and as two launches above, or with ETHCNN_LSTM_ONE_LAUNCH=0.  Both forms, frame

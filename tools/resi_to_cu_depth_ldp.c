@@ -15,10 +15,13 @@
  * marshalling.  Here the loop is a dozen system calls around ethcnn_ldp_step:
  *   * wake-up by inotify on the working directory (IN_CREATE / IN_MOVED_TO / IN_CLOSE_WRITE), confirmed by access() -- no
  *     poll interval, no busy core while the encoder encodes; a short spin right after a frame catches back-to-back frames;
- *   * resi.yuv is read by four threads straight into a page-locked buffer the kernels use in place (ethcnn_host_alloc), the
- *     probabilities land in a second one and go to cu_depth.dat with one write().  (A library entry that read the file in 16
- *     bands on its worker pool and DMA'd each band as it arrived -- kernels on device-resident pixels -- was built and measured:
- *     276 us per 1080p call against 64 + 114 here; sixteen small async copies from a pool cost more than the overlap wins.)
+ *   * resi.yuv is read by eight threads straight into a page-locked buffer the kernels use in place (ethcnn_host_alloc) WHILE the
+ *     frame's kernels are already queued and take the plane CTU row by CTU row as the threads report it (ethcnn_ldp_step_begin /
+ *     ethcnn_ldp_rows_ready / ethcnn_ldp_step_end, see read_luma_start); the probabilities land in a second page-locked buffer and
+ *     go to cu_depth.dat with one write().  (A library entry that read the file in 16 bands on its worker pool and DMA'd each band
+ *     as it arrived -- kernels on device-resident pixels -- was built first and measured 276 us per 1080p call against 64 + 114
+ *     for read-then-predict: sixteen small async copies from a pool cost more than the overlap wins.  Kernels that WAIT for the
+ *     rows do not have that cost.)
  *   * state handling as in the Python daemon: resident in HBM while this daemon produced the previous frame of the same
  *     geometry and the state.dat it wrote is still the one on disk (inode / size / mtime), else read from state.dat; the
  *     sidecar state.dat.idx says "pending <i> <w> <h>" from before the ending signal until state.dat holds that frame.
@@ -26,7 +29,7 @@
  *     ONLY when --accept-stale is given; otherwise the daemon reports the error, answers nothing and exits non-zero
  *     (the Python daemon does the same: a silently wrong recurrence is worse than a stopped encode).
  *
- *   resi_to_cu_depth_ldp [--max-frames N] [--idle-timeout SECONDS] [--quiet] [--accept-stale] [--trace]   (cwd = HM-LDP's bin/)
+ *   resi_to_cu_depth_ldp [--max-frames N] [--idle-timeout SECONDS] [--quiet] [--accept-stale] [--trace] [--spin] [--no-stream]   (cwd = HM-LDP's bin/)
  *
  * Environment as the Python daemon: ETHCNN_SYNTHETIC_SEED / ETHCNN_HEAD_GAIN (seeded weights when a trained blob is absent:
  * model_LDP_2000000_qp22~37.dat.data is not in the reference repository), ETHCNN_DEVICE.
@@ -99,18 +102,24 @@ static int read_exact(const char* path, void* dst, size_t bytes) {
     return got == bytes ? 0 : -1;
 }
 
-/* resi.yuv's luma -> the page-locked buffer.  One read() of a 1920x1080 plane is a 2 MB single-threaded copy out of the page cache:
- * ~180 us of the ~320 us the encoder waited.  Pictures of >= 512 KiB are read by four threads (three persistent helpers + the
- * caller), a quarter each with pread(): ~50 us.  The helpers sleep on a condition variable between frames. */
-#define NHELP 3
+/* resi.yuv's luma -> the page-locked buffer, STREAMED into the running prediction.  One read() of a 1920x1080 plane is a 2 MB
+ * single-threaded copy out of the page cache: ~180 us of the ~320 us the encoder waited in round 3's first daemon; four threads (three
+ * persistent helpers + the caller) brought it to ~50 us -- followed by the 115 us of ethcnn_ldp_step.  Now the frame's kernels are queued
+ * FIRST (ethcnn_ldp_step_begin) and the threads copy the plane one CTU row (64 luma rows) at a time, drawing row numbers from a shared
+ * counter and reporting each (ethcnn_ldp_rows_ready): the tile stage pulls a row over PCIe as soon as it is there, so the transfer and
+ * the launch overheads run under the read: 1920x1080, handshake p50 249 -> 214 us with three helpers, and with seven the copy itself
+ * drops under the 38 us the plane needs on the bus (profiles/r04_ldp_handshake.txt).  The helpers sleep on a condition variable between
+ * frames.  Pictures under 512 KiB are read by the caller alone, then predicted (nothing to hide a launch under: 416x240 is 100 KB). */
+#define NHELP 7
 static struct {
     pthread_mutex_t mu;
     pthread_cond_t go, done;
     pthread_t th[NHELP];
     int started, gen, pending, fd, failed, quit;
     char* dst;
-    size_t bytes;
-} g_rd = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, {0}, 0, 0, 0, -1, 0, 0, NULL, 0};
+    int w, h, next; /* next: CTU row to copy (atomic) */
+    ethcnn_ctx* ctx;
+} g_rd = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, {0}, 0, 0, 0, -1, 0, 0, NULL, 0, 0, 0, NULL};
 
 static int pread_exact(int fd, char* dst, size_t bytes, off_t off) {
     size_t got = 0;
@@ -121,26 +130,33 @@ static int pread_exact(int fd, char* dst, size_t bytes, off_t off) {
     }
     return 0;
 }
-static void part_of(int idx, size_t bytes, size_t* off, size_t* len) { /* quarter idx of [0, bytes), 4 KiB aligned cuts */
-    const size_t q = ((bytes / (NHELP + 1)) + 4095) & ~(size_t)4095;
-    *off = q * (size_t)idx < bytes ? q * (size_t)idx : bytes;
-    *len = (idx == NHELP || *off + q > bytes) ? bytes - *off : q;
+/* copy CTU rows until none is left; every row is reported even when its read failed (the kernels waiting for it must drain) */
+static int rd_rows(int fd, char* dst, int w, int h, ethcnn_ctx* ctx) {
+    const int nrows = (h + 63) / 64;
+    int bad = 0;
+    for (;;) {
+        const int cy = __atomic_fetch_add(&g_rd.next, 1, __ATOMIC_RELAXED);
+        if (cy >= nrows) break;
+        const size_t off = (size_t)cy * 64 * (size_t)w;
+        const int rows = (cy * 64 + 64 <= h) ? 64 : h - cy * 64;
+        if (pread_exact(fd, dst + off, (size_t)rows * (size_t)w, (off_t)off) != 0) bad = 1;
+        if (ctx) ethcnn_ldp_rows_ready(ctx, cy, cy + 1);
+    }
+    return bad;
 }
 static void* rd_helper(void* arg) {
-    const int idx = (int)(intptr_t)arg;
+    (void)arg;
     int seen = 0;
     pthread_mutex_lock(&g_rd.mu);
     for (;;) {
         while (g_rd.gen == seen && !g_rd.quit) pthread_cond_wait(&g_rd.go, &g_rd.mu);
         if (g_rd.quit) break;
         seen = g_rd.gen;
-        const int fd = g_rd.fd;
+        const int fd = g_rd.fd, w = g_rd.w, h = g_rd.h;
         char* dst = g_rd.dst;
-        const size_t bytes = g_rd.bytes;
+        ethcnn_ctx* ctx = g_rd.ctx;
         pthread_mutex_unlock(&g_rd.mu);
-        size_t off, len;
-        part_of(idx, bytes, &off, &len);
-        const int bad = len ? pread_exact(fd, dst + off, len, (off_t)off) : 0;
+        const int bad = rd_rows(fd, dst, w, h, ctx);
         pthread_mutex_lock(&g_rd.mu);
         if (bad) g_rd.failed = 1;
         if (--g_rd.pending == 0) pthread_cond_signal(&g_rd.done);
@@ -148,37 +164,37 @@ static void* rd_helper(void* arg) {
     pthread_mutex_unlock(&g_rd.mu);
     return NULL;
 }
-static int read_luma(const char* path, void* dst, size_t bytes) {
+/* start: open the file and (pictures of >= 512 KiB) wake the helpers; finish: the caller copies rows too, then waits for them.
+ * ctx != NULL: every CTU row is reported to the prediction begun on it. */
+static int read_luma_start(const char* path, void* dst, int w, int h, ethcnn_ctx* ctx) {
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return -1;
-    int rc;
-    if (bytes < (512u << 10)) {
-        rc = pread_exact(fd, (char*)dst, bytes, 0);
-    } else {
-        pthread_mutex_lock(&g_rd.mu);
-        if (!g_rd.started) {
-            g_rd.started = 1;
-            for (int i = 0; i < NHELP; ++i)
-                if (pthread_create(&g_rd.th[i], NULL, rd_helper, (void*)(intptr_t)i) != 0) g_rd.started = -1;
-        }
-        if (g_rd.started < 0) { /* no helpers: plain read */
-            pthread_mutex_unlock(&g_rd.mu);
-            rc = pread_exact(fd, (char*)dst, bytes, 0);
-        } else {
-            g_rd.fd = fd; g_rd.dst = (char*)dst; g_rd.bytes = bytes; g_rd.failed = 0; g_rd.pending = NHELP;
-            ++g_rd.gen;
-            pthread_cond_broadcast(&g_rd.go);
-            pthread_mutex_unlock(&g_rd.mu);
-            size_t off, len;
-            part_of(NHELP, bytes, &off, &len);
-            const int bad = len ? pread_exact(fd, (char*)dst + off, len, (off_t)off) : 0;
-            pthread_mutex_lock(&g_rd.mu);
-            while (g_rd.pending > 0) pthread_cond_wait(&g_rd.done, &g_rd.mu);
-            rc = (bad || g_rd.failed) ? -1 : 0;
-            pthread_mutex_unlock(&g_rd.mu);
-        }
+    pthread_mutex_lock(&g_rd.mu);
+    if (!g_rd.started && (size_t)w * (size_t)h >= (512u << 10)) {
+        g_rd.started = 1;
+        for (int i = 0; i < NHELP; ++i)
+            if (pthread_create(&g_rd.th[i], NULL, rd_helper, NULL) != 0) { g_rd.started = -1; break; }
+        /* (a partial set of helpers would deadlock the pending count: with -1 none is ever woken and the caller reads alone) */
     }
-    close(fd);
+    g_rd.fd = fd; g_rd.dst = (char*)dst; g_rd.w = w; g_rd.h = h; g_rd.ctx = ctx; g_rd.failed = 0;
+    __atomic_store_n(&g_rd.next, 0, __ATOMIC_RELAXED);
+    g_rd.pending = 0;
+    if (g_rd.started > 0 && (size_t)w * (size_t)h >= (512u << 10)) {
+        g_rd.pending = NHELP;
+        ++g_rd.gen;
+        pthread_cond_broadcast(&g_rd.go);
+    }
+    pthread_mutex_unlock(&g_rd.mu);
+    return 0;
+}
+static int read_luma_finish(void) {
+    const int bad = rd_rows(g_rd.fd, g_rd.dst, g_rd.w, g_rd.h, g_rd.ctx);
+    pthread_mutex_lock(&g_rd.mu);
+    while (g_rd.pending > 0) pthread_cond_wait(&g_rd.done, &g_rd.mu);
+    const int rc = (bad || g_rd.failed) ? -1 : 0;
+    pthread_mutex_unlock(&g_rd.mu);
+    close(g_rd.fd);
+    g_rd.fd = -1;
     return rc;
 }
 
@@ -232,7 +248,8 @@ static int sidecar(const char* text) {
  * one pwrite per frame (the file is re-created when the geometry changes, or when somebody removed it) */
 static int g_depth_fd = -1;
 static size_t g_depth_bytes = 0;
-static int write_cu_depth(const void* data, size_t bytes) {
+/* (the checks and the open: done while the GPU is still working on the frame) */
+static int prepare_cu_depth(size_t bytes) {
     struct stat st;
     if (g_depth_fd >= 0 && (g_depth_bytes != bytes || stat("cu_depth.dat", &st) != 0 || fstat(g_depth_fd, &st) != 0 || st.st_nlink == 0)) {
         close(g_depth_fd);
@@ -242,7 +259,10 @@ static int write_cu_depth(const void* data, size_t bytes) {
         g_depth_fd = open("cu_depth.dat", O_WRONLY | O_CREAT | O_TRUNC, 0644);
         g_depth_bytes = bytes;
     }
-    if (g_depth_fd < 0) return -1;
+    return g_depth_fd < 0 ? -1 : 0;
+}
+static int write_cu_depth(const void* data, size_t bytes) {
+    if (g_depth_fd < 0 || g_depth_bytes != bytes) return -1;
     const char* p = (const char*)data;
     size_t done = 0;
     while (done < bytes) {
@@ -253,18 +273,27 @@ static int write_cu_depth(const void* data, size_t bytes) {
     return 0;
 }
 
+/* --trace: per-stage times of up to TRACE_N frames; medians are printed (a mean is at the mercy of one 5 ms scheduling hiccup) */
+#define TRACE_N 8192
+static float g_tr[7][TRACE_N];
+static int cmp_f(const void* a, const void* b) { const float x = *(const float*)a, y = *(const float*)b; return x < y ? -1 : x > y; }
+static double median_us(float* v, int n) { if (n <= 0) return 0.0; qsort(v, (size_t)n, sizeof(float), cmp_f); return 1e6 * (double)v[n / 2]; }
+
 int main(int argc, char** argv) {
     long max_frames = -1;
     double idle_timeout = -1.0;
-    int quiet = 0, accept_stale = 0, trace = 0;
-    double t_cmd = 0, t_read = 0, t_state = 0, t_step = 0, t_out = 0, t_late = 0; /* --trace: seconds spent per stage */
+    int quiet = 0, accept_stale = 0, trace = 0, no_stream_opt = 0, streamed_frames = 0, spin = 0;
+    int sig_pending = 0; /* a frame has been accepted whose pred_start.sig is still there (it is removed off the critical path) */
+    int n_trace = 0;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--max-frames") && i + 1 < argc) max_frames = atol(argv[++i]);
         else if (!strcmp(argv[i], "--idle-timeout") && i + 1 < argc) idle_timeout = atof(argv[++i]);
         else if (!strcmp(argv[i], "--quiet")) quiet = 1;
         else if (!strcmp(argv[i], "--accept-stale")) accept_stale = 1;
         else if (!strcmp(argv[i], "--trace")) trace = 1;
-        else { fprintf(stderr, "usage: resi_to_cu_depth_ldp [--max-frames N] [--idle-timeout S] [--quiet] [--accept-stale] [--trace]\n"); return 2; }
+        else if (!strcmp(argv[i], "--spin")) spin = 1; /* busy-wait for pred_start.sig as the reference's daemon does (a core at 100 %) */
+        else if (!strcmp(argv[i], "--no-stream")) no_stream_opt = 1; /* read resi.yuv first, then predict (A/B runs) */
+        else { fprintf(stderr, "usage: resi_to_cu_depth_ldp [--max-frames N] [--idle-timeout S] [--quiet] [--accept-stale] [--trace] [--spin] [--no-stream]\n"); return 2; }
     }
     ethcnn_ctx* ctx = NULL;
     ethcnn_options opt;
@@ -299,7 +328,7 @@ int main(int argc, char** argv) {
         if (!file_exists("pred_start.sig")) {
             const double t = now_s();
             if (idle_timeout >= 0.0 && t - idle_since > idle_timeout) break;
-            if (t < spin_until) continue;                     /* right behind a frame: the next one may follow at once */
+            if (spin || t < spin_until) continue;             /* right behind a frame: the next one may follow at once */
             if (ifd >= 0) {
                 struct pollfd pf = {ifd, POLLIN, 0};
                 if (poll(&pf, 1, 100) > 0) {                  /* drain the events; the loop re-checks the file itself */
@@ -317,7 +346,7 @@ int main(int argc, char** argv) {
         if (get_command(&i_frame, &w, &h, &qp) != 0 || i_frame < 0) continue; /* command.dat still being written */
         const int qp_last = qp_seq;
         qp_seq = qp;
-        unlink("pred_start.sig");
+        sig_pending = 1;
         if (w <= 0 || h <= 0) { fprintf(stderr, "resi_to_cu_depth_ldp: bad geometry %dx%d in command.dat\n", w, h); goto out; }
         if (qp_seq != qp_last) {
             char name[96];
@@ -345,8 +374,6 @@ int main(int argc, char** argv) {
             if (!state) { fprintf(stderr, "resi_to_cu_depth_ldp: out of memory\n"); goto out; }
         }
         const double ts1 = now_s();
-        if (read_luma("resi.yuv", luma, npx) != 0) { fprintf(stderr, "resi_to_cu_depth_ldp: resi.yuv: short read (%zu luma bytes wanted)\n", npx); goto out; }
-        const double ts2 = now_s();
         /* the state of frame i_frame - 1: resident when this daemon produced it for this geometry and its state.dat is untouched */
         const float* state_in = NULL;
         const int resident = i_frame > 1 && last_w == w && last_h == h && last_i == i_frame - 1 && sig_eq(state_sig, sig_of("state.dat"));
@@ -373,15 +400,31 @@ int main(int argc, char** argv) {
             }
             state_in = state;
         }
+        const double ts2 = now_s();
+        /* helpers start copying resi.yuv; the frame's kernels are queued while they do and take the rows as they are reported */
+        const int stream = !no_stream_opt && npx >= (512u << 10);
+        const int no_stream = !stream;
+        if (read_luma_start("resi.yuv", luma, w, h, no_stream ? NULL : ctx) != 0) { fprintf(stderr, "resi_to_cu_depth_ldp: cannot open resi.yuv\n"); goto out; }
+        int step_rc = ETHCNN_OK;
+        if (!no_stream) step_rc = ethcnn_ldp_step_begin(ctx, luma, w, h, w, qp_seq, i_frame, state_in, probs);
+        const double ts2b = now_s();
+        unlink("pred_start.sig"); /* (HM only ever creates it; removed off the critical path, while the helpers copy) */
+        sig_pending = 0;
+        const int read_rc = read_luma_finish(); /* (also when begin failed: the rows it may be waiting for are reported) */
         const double ts3 = now_s();
-        if (ethcnn_ldp_step(ctx, luma, w, h, w, qp_seq, i_frame, state_in, probs) != ETHCNN_OK) {
+        /* while the GPU works: the sidecar says "pending" from here (it must, before the ending signal; a failure below ends the daemon
+         * with the marker in place, which is what a restart has to see), cu_depth.dat is checked / re-created */
+        char tagbuf[96];
+        snprintf(tagbuf, sizeof tagbuf, "pending %d %d %d", i_frame, w, h);
+        if (sidecar(tagbuf) != 0 || prepare_cu_depth(nctu * 21 * sizeof(float)) != 0) { fprintf(stderr, "resi_to_cu_depth_ldp: cannot write state.dat.idx / cu_depth.dat: %s\n", strerror(errno)); if (step_rc == ETHCNN_OK && !no_stream) (void)ethcnn_ldp_step_end(ctx); goto out; }
+        if (step_rc == ETHCNN_OK) step_rc = no_stream ? ethcnn_ldp_step(ctx, luma, w, h, w, qp_seq, i_frame, state_in, probs) : ethcnn_ldp_step_end(ctx);
+        if (read_rc != 0) { fprintf(stderr, "resi_to_cu_depth_ldp: resi.yuv: short read (%zu luma bytes wanted)\n", npx); goto out; }
+        if (step_rc != ETHCNN_OK) {
             fprintf(stderr, "resi_to_cu_depth_ldp: frame %d: %s\n", i_frame, ethcnn_last_error(ctx));
             goto out;
         }
         const double ts4 = now_s();
-        char tagbuf[96];
-        snprintf(tagbuf, sizeof tagbuf, "pending %d %d %d", i_frame, w, h);
-        if (sidecar(tagbuf) != 0 || write_cu_depth(probs, nctu * 21 * sizeof(float)) != 0) { fprintf(stderr, "resi_to_cu_depth_ldp: cannot write cu_depth.dat: %s\n", strerror(errno)); goto out; }
+        if (write_cu_depth(probs, nctu * 21 * sizeof(float)) != 0) { fprintf(stderr, "resi_to_cu_depth_ldp: cannot write cu_depth.dat: %s\n", strerror(errno)); goto out; }
         { const int fd = open("pred_end.sig", O_WRONLY | O_CREAT | O_TRUNC, 0644); if (fd < 0) { fprintf(stderr, "resi_to_cu_depth_ldp: cannot create pred_end.sig\n"); goto out; } close(fd); }
         const double ts5 = now_s();
         /* HM is encoding again from here; the state file is refreshed behind its back, as the protocol asks */
@@ -394,20 +437,29 @@ int main(int argc, char** argv) {
         last_w = w; last_h = h; last_i = i_frame;
         state_sig = sig_of("state.dat");
         ++n_total;
-        if (n_total > 5) { const double ts6 = now_s(); t_cmd += ts1 - ts0; t_read += ts2 - ts1; t_state += ts3 - ts2; t_step += ts4 - ts3; t_out += ts5 - ts4; t_late += ts6 - ts5; }
+        streamed_frames += stream;
+        if (n_total > 5 && n_trace < TRACE_N) {
+            const double ts6 = now_s();
+            const double v[7] = {ts1 - ts0, ts2 - ts1, ts3 - ts2, ts2b - ts2, ts4 - ts3, ts5 - ts4, ts6 - ts5};
+            for (int k = 0; k < 7; ++k) g_tr[k][n_trace] = (float)v[k];
+            ++n_trace;
+        }
         idle_since = now_s();
         spin_until = idle_since + 2e-3;
         if (!quiet) { printf("%ld frames predicted.\n", n_total); fflush(stdout); }
     }
     rc = 0;
     if (ifd >= 0) close(ifd);
-    if (trace && n_total > 5) {
-        const double k = 1e6 / (double)(n_total - 5);
-        fprintf(stderr, "trace (us per frame, frames 6..%ld): command.dat + unlink %.1f | resi.yuv read %.1f | state %.1f | ethcnn_ldp_step %.1f | "
-                        "sidecar + cu_depth.dat + pred_end.sig %.1f | behind the signal: state.dat refresh %.1f\n",
-                n_total, t_cmd * k, t_read * k, t_state * k, t_step * k, t_out * k, t_late * k);
+    if (trace && n_trace > 0) {
+        double m[7];
+        for (int k = 0; k < 7; ++k) m[k] = median_us(g_tr[k], n_trace);
+        fprintf(stderr, "trace (median us per frame, frames 6..%ld): command.dat %.1f | state %.1f | resi.yuv read%s %.1f (of which the caller spent %.1f queueing) | "
+                        "%s %.1f | cu_depth.dat + pred_end.sig %.1f | behind the signal: state.dat refresh %.1f\n",
+                n_total, m[0], m[1], !streamed_frames ? "" : " (kernels queued under it: ethcnn_ldp_step_begin)", m[2], m[3],
+                !streamed_frames ? "sidecar + ethcnn_ldp_step" : "sidecar + ethcnn_ldp_step_end", m[4], m[5], m[6]);
     }
 out:
+    if (sig_pending) unlink("pred_start.sig"); /* an error exit in between: the request counts as taken, as with the reference's daemon */
     free(state);
     ethcnn_destroy(ctx); /* frees the page-locked buffers with the context */
     return rc;
