@@ -204,13 +204,14 @@ struct ethcnn_ctx {
     // completion word (page-locked host memory): the last block of a latency-path launch stores the launch's sequence number
     // there and the host spins on it instead of calling hipStreamSynchronize (~5 us sooner, scripts/ubench/launch_rtt.hip)
     unsigned* h_done = nullptr;  // (word 1: "a tile block of streamed picture <seq> gave up waiting for its rows", ethcnn_tile.hip)
-    // streamed input (ethcnn_ldp_step_begin / ethcnn_ldp_rows_ready / ethcnn_ldp_step_end): one page-locked word per CTU row, holding the
+    // streamed input (ethcnn_ldp_step_begin / ethcnn_rows_ready / ethcnn_ldp_step_end): one page-locked word per CTU row, holding the
     // number of the streamed picture whose rows are in the caller's buffer; the number of the NEXT streamed picture is fixed when
     // the previous one ends, so filling threads may report rows before begin has been called
     unsigned* h_rows = nullptr;
     unsigned rows_seq = 1;
     const unsigned* tile_wait_rows = nullptr;  // set around the tile launch of a streamed step
     struct LdpPending { bool open = false, streamed = false; float* probs = nullptr; float* d_probs = nullptr; size_t pbytes = 0; int out = 0, nctu = 0; } ldp;
+    struct LumaPending { bool open = false; float* probs = nullptr; size_t out_bytes = 0; } ai;  // ethcnn_predict_luma_begin ... _end
     unsigned done_seq = 0;     // last number handed out
     unsigned done_armed = 0;   // != 0: the LAST operation enqueued on the main stream stores this number when all its outputs are final
     int done_sync = 1;         // env ETHCNN_DONE_WORD=0: always hipStreamSynchronize (A/B runs)
@@ -882,7 +883,8 @@ static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, lo
         // as ONE launch instead of five dependent ones
         Workspace wv = w;
         if (!c->debug_capture) wv.h2 = wv.logits = wv.raw = nullptr;
-        rc = run_small_pass(c, d_luma, g, ctu0, n, false, wv, w.h1, qn, d_probs_pass, (int)nchunks, c->luma_over_pcie);
+        rc = run_small_pass(c, d_luma, g, ctu0, n, false, wv, w.h1, qn, d_probs_pass, (int)nchunks, c->luma_over_pcie,
+                            c->luma_over_pcie ? c->tile_wait_rows : nullptr);
         if (rc) return rc;
         c->main_dirty = true;  // a later pipelined tile stage must wait for this pass
         c->times.ctus += n;
@@ -922,7 +924,8 @@ static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, lo
         HIPCHK(c, hipMemsetAsync(w.flags, 0, (size_t)sync_words(n, (int)nchunks) * sizeof(int), s_tile));
     } else {
         StageTimer t(c, ETHCNN_STAGE_TILE, n, s_tile);
-        launch_tile(d_luma, g, ctu0, n, w, sync_words(n, (int)nchunks), s_tile, side_tile ? c->tile_blocks : 0);
+        launch_tile(d_luma, g, ctu0, n, w, sync_words(n, (int)nchunks), s_tile, side_tile ? c->tile_blocks : 0,
+                    side_tile ? nullptr : c->tile_wait_rows, c->rows_seq, c->h_done + 1);  // (streamed input: a single main-stream pass)
     }
     LAUNCH_OK("tile");
     if (side_tile) {
@@ -1276,6 +1279,62 @@ static int predict_luma_latency(ethcnn_ctx* c, const uint8_t* luma, int w, int h
     return ETHCNN_OK;
 }
 
+// ---- ONE picture with streamed input (the in-process encoder hook converts HM's 16-bit picture to 8 bits row by row: the
+// conversion is as long as the prediction, and the prediction can run under it).  begin: the pass is queued on the page-locked
+// buffer and waits for its CTU rows (ethcnn_rows_ready); end: result copy + wait.  The pass is the one ethcnn_predict_luma runs.
+extern "C" int ethcnn_predict_luma_begin(ethcnn_ctx* c, const uint8_t* luma, int w, int h, int qp, float* probs) {
+    if (!c || !luma || !probs) return c ? set_err(c, ETHCNN_ERR_ARG, "null pointer") : ETHCNN_ERR_ARG;
+    if (c->ai.open || c->ldp.open) return set_err(c, ETHCNN_ERR_ARG, "ethcnn_predict_luma_begin: a streamed call is still open on this context");
+    FrameGeom g;
+    int rc = make_geom(c, w, h, w, (ptrdiff_t)w * h, &g);
+    if (rc) return rc;
+    if (!c->have_weights) return set_err(c, ETHCNN_ERR_NOWEIGHTS, "no weights loaded");
+    if (!c->h_rows) return set_err(c, ETHCNN_ERR_DEVICE, "ethcnn_predict_luma_begin: no page-locked memory for the row words");
+    if (g.ch > kStreamCtuRows) return set_err(c, ETHCNN_ERR_ARG, "ethcnn_predict_luma_begin: more than %d CTU rows", kStreamCtuRows);
+    if (g.nctu >= kPipelineMinCtus || g.nctu > c->max_ctus)
+        return set_err(c, ETHCNN_ERR_ARG, "ethcnn_predict_luma_begin: %d CTUs: streamed input is for one picture in one pass (< %d CTUs)", g.nctu, std::min(kPipelineMinCtus, c->max_ctus + 1));
+    const size_t plane = (size_t)w * h, out_bytes = (size_t)g.nctu * kNOut * 4;
+    if (!in_pinned(c, luma, plane))
+        return set_err(c, ETHCNN_ERR_ARG, "ethcnn_predict_luma_begin: the luma buffer must come from ethcnn_host_alloc (the kernels read it in place while it is filled)");
+    HIPCHK(c, hipSetDevice(c->device));
+    rc = ensure_staging(c, plane, out_bytes, 1);
+    // (everything that may wait for the stream happens before kernels are queued that wait for the caller)
+    if (rc == 0) rc = ensure_workspace(c, g.nctu, chunks_per_frame(g.nctu));
+    if (rc == 0 && c->fc1_plan != 0) rc = ensure_fast_weights(c, c->fc1_plan);  // (first use packs and uploads the 16-bit weight images)
+    if (rc) return rc;
+    c->luma_over_pcie = true;
+    c->tile_wait_rows = c->h_rows;
+    rc = run_pass(c, luma, g, 0, g.nctu, qp, c->d_out[0]);
+    c->luma_over_pcie = false;
+    c->tile_wait_rows = nullptr;
+    if (rc) {  // release whatever is already queued (the result is discarded) and let the stream drain
+        for (int cy = 0; cy < g.ch; ++cy) __atomic_store_n(c->h_rows + cy, c->rows_seq, __ATOMIC_RELEASE);
+        (void)hipStreamSynchronize(c->stream);
+        if (++c->rows_seq == 0) c->rows_seq = 1;
+        return rc;
+    }
+    c->ai.open = true;
+    c->ai.probs = probs;
+    c->ai.out_bytes = out_bytes;
+    return ETHCNN_OK;
+}
+
+extern "C" int ethcnn_predict_luma_end(ethcnn_ctx* c) {
+    if (!c) return ETHCNN_ERR_ARG;
+    if (!c->ai.open) return set_err(c, ETHCNN_ERR_ARG, "ethcnn_predict_luma_end: no picture has been begun");
+    c->ai.open = false;
+    const unsigned seq = c->rows_seq;
+    if (++c->rows_seq == 0) c->rows_seq = 1;  // the next streamed picture's number is fixed from here on
+    float* dst = in_pinned(c, c->ai.probs, c->ai.out_bytes) ? c->ai.probs : c->h_out[0];
+    c->done_armed = 0;
+    HIPCHK(c, hipMemcpyAsync(dst, c->d_out[0], c->ai.out_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (__atomic_load_n(c->h_done + 1, __ATOMIC_ACQUIRE) == seq)
+        return set_err(c, ETHCNN_ERR_DEVICE, "ethcnn_predict_luma_end: the kernels waited 1 s for luma rows that were never reported (ethcnn_rows_ready)");
+    if (dst != c->ai.probs) std::memcpy(c->ai.probs, dst, c->ai.out_bytes);
+    return ETHCNN_OK;
+}
+
 extern "C" int ethcnn_predict_luma(ethcnn_ctx* c, const uint8_t* luma, int w, int h, ptrdiff_t pitch, ptrdiff_t fstride,
                                    int nframes, int qp, float* probs) {
     if (!c || !luma || !probs || nframes < 0) return c ? set_err(c, ETHCNN_ERR_ARG, "null pointer / negative frame count") : ETHCNN_ERR_ARG;
@@ -1585,11 +1644,11 @@ static bool in_pinned(const ethcnn_ctx* c, const void* p, size_t bytes) {
 // predict_cu_depth() of resi_to_cu_depth_LDP.py:108-129 for one frame; the new state stays in HBM.
 // state source: host `state_in` when given, else zeros (resident == false) or the previous step's state in HBM.
 // Two halves: ldp_step_begin enqueues everything, ldp_step_end waits and finishes the bookkeeping.  streamed: the caller is still
-// FILLING the page-locked luma buffer (ethcnn_ldp_rows_ready reports its CTU rows); the tile stage waits for them row by row.
+// FILLING the page-locked luma buffer (ethcnn_rows_ready reports its CTU rows); the tile stage waits for them row by row.
 static int ldp_step_begin(ethcnn_ctx* c, const uint8_t* luma, int w, int h, ptrdiff_t pitch, int qp, int i_frame,
                           const float* state_in, bool resident, float* probs, bool streamed) {
     if (!c || !luma || !probs) return c ? set_err(c, ETHCNN_ERR_ARG, "null pointer") : ETHCNN_ERR_ARG;
-    if (c->ldp.open) return set_err(c, ETHCNN_ERR_ARG, "ethcnn_ldp_step_begin: the previous streamed step has not been ended (ethcnn_ldp_step_end)");
+    if (c->ldp.open || c->ai.open) return set_err(c, ETHCNN_ERR_ARG, "ethcnn_ldp_step_begin: the previous streamed call has not been ended (ethcnn_ldp_step_end / ethcnn_predict_luma_end)");
     if (w <= 0 || h <= 0 || pitch < w) return set_err(c, ETHCNN_ERR_ARG, "bad geometry");
     if (!c->have_weights) return set_err(c, ETHCNN_ERR_NOWEIGHTS, "no CNN weights loaded");
     if (!c->have_lstm) return set_err(c, ETHCNN_ERR_NOWEIGHTS, "no LSTM weights loaded");
@@ -1668,7 +1727,7 @@ static int ldp_step_end(ethcnn_ctx* c) {
     if (!c->ldp.open) return set_err(c, ETHCNN_ERR_ARG, "ethcnn_ldp_step_end: no step has been begun");
     c->ldp.open = false;
     const unsigned seq = c->rows_seq;
-    if (c->ldp.streamed) {  // the next streamed picture's number is fixed from here on (ethcnn_ldp_rows_ready may run before its begin)
+    if (c->ldp.streamed) {  // the next streamed picture's number is fixed from here on (ethcnn_rows_ready may run before its begin)
         ++c->rows_seq;
         if (c->rows_seq == 0) c->rows_seq = 1;
     }
@@ -1679,7 +1738,7 @@ static int ldp_step_end(ethcnn_ctx* c) {
     HIPCHK(c, stream_sync(c));
     if (c->ldp.streamed && __atomic_load_n(c->h_done + 1, __ATOMIC_ACQUIRE) == seq) {
         c->state_cur = -1;  // computed on rows that never arrived
-        return set_err(c, ETHCNN_ERR_DEVICE, "ethcnn_ldp_step_end: the kernels waited 1 s for luma rows that were never reported (ethcnn_ldp_rows_ready)");
+        return set_err(c, ETHCNN_ERR_DEVICE, "ethcnn_ldp_step_end: the kernels waited 1 s for luma rows that were never reported (ethcnn_rows_ready)");
     }
     if (c->ldp.d_probs == c->h_out[0]) std::memcpy(c->ldp.probs, c->ldp.d_probs, c->ldp.pbytes);
     c->state_cur = c->ldp.out;
@@ -1704,7 +1763,7 @@ extern "C" int ethcnn_ldp_step_begin(ethcnn_ctx* c, const uint8_t* luma, int w, 
     return ldp_step_begin(c, luma, w, h, pitch, qp, i_frame, state_in, /*resident=*/!state_in && i_frame > 1, probs, true);
 }
 
-extern "C" int ethcnn_ldp_rows_ready(ethcnn_ctx* c, int ctu_row_begin, int ctu_row_end) {
+extern "C" int ethcnn_rows_ready(ethcnn_ctx* c, int ctu_row_begin, int ctu_row_end) {
     // (thread-safe: touches nothing but the row words; no error text -- another thread may be inside a call on this context)
     if (!c || !c->h_rows || ctu_row_begin < 0 || ctu_row_end > kStreamCtuRows || ctu_row_begin > ctu_row_end) return ETHCNN_ERR_ARG;
     const unsigned seq = __atomic_load_n(&c->rows_seq, __ATOMIC_RELAXED);

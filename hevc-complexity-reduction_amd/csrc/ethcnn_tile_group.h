@@ -35,7 +35,7 @@ __device__ __forceinline__ uint4 nt_load(const uint4* p) {
 
 // WAIT (streamed input, ethcnn_ldp_step_begin): the picture lies in page-locked HOST memory that the caller is STILL FILLING when the
 // kernel starts -- an encoder-side reader copying resi.yuv out of the page cache, CTU row by CTU row.  rows[cy] == seq says "the 64
-// luma rows of CTU row cy of picture `seq` are in the buffer" (ethcnn_ldp_rows_ready: a release store by the filling thread; the
+// luma rows of CTU row cy of picture `seq` are in the buffer" (ethcnn_rows_ready: a release store by the filling thread; the
 // device's reads of host memory snoop the CPU caches and x86 makes the stores visible in order, so data read AFTER the flag is the
 // new picture's).  One thread per block polls the flags of its group's one or two CTU rows with system-scope loads.  A caller
 // that dies between begin and end must not hang the GPU: after ~1 s of wall clock the block gives up, stores `seq` to *gave_up (the

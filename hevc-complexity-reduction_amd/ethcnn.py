@@ -71,7 +71,9 @@ SIGNATURES = {
     "ethcnn_ldp_step": (_i, [_vp, _vp, _i, _i, _pd, _i, _i, _vp, _fp]),
     "ethcnn_ldp_get_state": (_i, [_vp, _fp, _sz]),
     "ethcnn_ldp_step_begin": (_i, [_vp, _vp, _i, _i, _pd, _i, _i, _vp, _fp]),
-    "ethcnn_ldp_rows_ready": (_i, [_vp, _i, _i]),
+    "ethcnn_rows_ready": (_i, [_vp, _i, _i]),
+    "ethcnn_predict_luma_begin": (_i, [_vp, _vp, _i, _i, _i, _fp]),
+    "ethcnn_predict_luma_end": (_i, [_vp]),
     "ethcnn_ldp_step_end": (_i, [_vp]),
     "ethcnn_host_alloc": (_i, [_vp, _sz, ctypes.POINTER(_vp)]),
     "ethcnn_host_free": (_i, [_vp, _vp]),
@@ -322,6 +324,18 @@ class EthCnn(object):
                                                nframes, int(qp), out.ctypes.data_as(_fp)))
         return out
 
+    def predict_luma_begin(self, luma_pinned, width, height, qp, probs_out):
+        """streamed input (ethcnn_predict_luma_begin): queue ONE picture's pass on a host_buffer() the caller is still filling; report
+        CTU rows with rows_ready (any thread), finish with predict_luma_end.  probs_out: float32 array of nctu * 21 (kept alive by
+        the caller until predict_luma_end returns)"""
+        n = ctus_per_frame(width, height)
+        assert luma_pinned.dtype == np.uint8 and luma_pinned.flags["C_CONTIGUOUS"] and luma_pinned.size >= width * height
+        assert probs_out.dtype == np.float32 and probs_out.size == n * NOUT and probs_out.flags["C_CONTIGUOUS"]
+        self._chk(self.lib.ethcnn_predict_luma_begin(self.h, luma_pinned.ctypes.data, width, height, int(qp), probs_out.ctypes.data_as(_fp)))
+
+    def predict_luma_end(self):
+        self._chk(self.lib.ethcnn_predict_luma_end(self.h))
+
     def predict_luma_device(self, d_luma, width, height, nframes, qp, d_probs, pitch=None, frame_stride=None):
         """Both pointers already in HBM (ints or DeviceBuffer); asynchronous."""
         pitch = width if pitch is None else pitch
@@ -446,7 +460,7 @@ class EthCnn(object):
 
     def ldp_step_begin(self, luma_pinned, width, height, qp, i_frame, probs_out, state_in=None, pitch=None):
         """streamed input (ethcnn_ldp_step_begin): queue the frame's kernels on a host_buffer() the caller is still filling; report
-        rows with ldp_rows_ready (any thread), finish with ldp_step_end.  probs_out: float32 array of nctu * 21 (kept alive by the
+        rows with rows_ready (any thread), finish with ldp_step_end.  probs_out: float32 array of nctu * 21 (kept alive by the
         caller until ldp_step_end returns)"""
         pitch = width if pitch is None else pitch
         n = ctus_per_frame(width, height)
@@ -458,9 +472,9 @@ class EthCnn(object):
         self._chk(self.lib.ethcnn_ldp_step_begin(self.h, luma_pinned.ctypes.data, width, height, pitch, int(qp), int(i_frame),
                                                  sin.ctypes.data if sin is not None else None, probs_out.ctypes.data_as(_fp)))
 
-    def ldp_rows_ready(self, ctu_row_begin, ctu_row_end):
-        if self.lib.ethcnn_ldp_rows_ready(self.h, int(ctu_row_begin), int(ctu_row_end)) != 0:
-            raise ValueError("ldp_rows_ready(%d, %d)" % (ctu_row_begin, ctu_row_end))
+    def rows_ready(self, ctu_row_begin, ctu_row_end):
+        if self.lib.ethcnn_rows_ready(self.h, int(ctu_row_begin), int(ctu_row_end)) != 0:
+            raise ValueError("rows_ready(%d, %d)" % (ctu_row_begin, ctu_row_end))
 
     def ldp_step_end(self):
         self._chk(self.lib.ethcnn_ldp_step_end(self.h))

@@ -95,6 +95,22 @@ int ethcnn_predict_luma_device(ethcnn_ctx* ctx, const uint8_t* d_luma, int width
 int ethcnn_predict_luma(ethcnn_ctx* ctx, const uint8_t* luma, int width, int height,
                         ptrdiff_t pitch, ptrdiff_t frame_stride, int nframes, int qp,
                         float* probs); /* host pointers; synchronous */
+/* ONE picture with STREAMED INPUT (the in-process encoder hook, INTEGRATION.md: TEncGOP hands over a 16-bit picture whose
+ * conversion to 8 bits takes as long as the prediction -- the prediction runs under it):
+ *   ethcnn_predict_luma_begin   queues the picture's pass on `luma` -- a tightly packed plane (pitch == width) in a buffer from
+ *                               ethcnn_host_alloc that the caller has NOT filled yet -- and returns.  One picture of fewer than
+ *                               8192 CTUs.  Until ethcnn_predict_luma_end no other call may be made on this context except
+ *                               ethcnn_rows_ready.
+ *   ethcnn_rows_ready           "luma rows [64 ctu_row_begin, 64 ctu_row_end) are in the buffer" (the last CTU row may be short).
+ *                               Any thread, any order, each CTU row once; also BEFORE the begin of the same picture, but not before
+ *                               the previous streamed call on this context has ended.  Every CTU row [0, ceil(height / 64)) must be
+ *                               reported: kernels that wait ~1 s for a row give up and the end call fails with ETHCNN_ERR_DEVICE
+ *                               (the GPU is not left hanging).  Shared with ethcnn_ldp_step_begin below.
+ *   ethcnn_predict_luma_end     waits; probs (the pointer given to begin) are final when it returns ETHCNN_OK.
+ * Results are bit-identical to ethcnn_predict_luma's. */
+int ethcnn_predict_luma_begin(ethcnn_ctx* ctx, const uint8_t* luma, int width, int height, int qp, float* probs);
+int ethcnn_rows_ready(ethcnn_ctx* ctx, int ctu_row_begin, int ctu_row_end);
+int ethcnn_predict_luma_end(ethcnn_ctx* ctx);
 /* Whole driver: all frames of the file from frame 0 (:135-140), writes `out_path`
  * (temp file + rename: never a partial cu_depth.dat).  *nframes_out may be NULL. */
 int ethcnn_predict_yuv_file(ethcnn_ctx* ctx, const char* yuv_path, int width, int height, int qp,
@@ -157,8 +173,8 @@ int ethcnn_ldp_get_state(ethcnn_ctx* ctx, float* state_out, size_t nfloats /* nc
  * and the launch overheads run under the read).
  *   ethcnn_ldp_step_begin   arguments as ethcnn_ldp_step; luma MUST lie in a buffer from ethcnn_host_alloc (read in place).  Returns
  *                           once everything is queued.  Until ethcnn_ldp_step_end no other call may be made on this context
- *                           except ethcnn_ldp_rows_ready.
- *   ethcnn_ldp_rows_ready   "luma rows [64 ctu_row_begin, 64 ctu_row_end) are in the buffer" (the last CTU row may be short).  Any
+ *                           except ethcnn_rows_ready.
+ *   ethcnn_rows_ready   "luma rows [64 ctu_row_begin, 64 ctu_row_end) are in the buffer" (the last CTU row may be short).  Any
  *                           thread, any order, each CTU row once; may be called BEFORE ethcnn_ldp_step_begin of the same frame, but
  *                           not before the previous streamed step has ended.  Every CTU row [0, ceil(height / 64)) must be
  *                           reported: kernels that wait ~1 s for a row give up, and ethcnn_ldp_step_end then fails with
@@ -167,7 +183,7 @@ int ethcnn_ldp_get_state(ethcnn_ctx* ctx, float* state_out, size_t nfloats /* nc
  * Results are bit-identical to ethcnn_ldp_step's. */
 int ethcnn_ldp_step_begin(ethcnn_ctx* ctx, const uint8_t* luma, int width, int height, ptrdiff_t pitch, int qp, int i_frame,
                           const float* state_in /* may be NULL */, float* probs);
-int ethcnn_ldp_rows_ready(ethcnn_ctx* ctx, int ctu_row_begin, int ctu_row_end);
+/* (ethcnn_rows_ready: declared with ethcnn_predict_luma_begin above) */
 int ethcnn_ldp_step_end(ethcnn_ctx* ctx);
 /* Pinned (page-locked) host memory: buffers a caller fills itself (file reads) and hands to the host entry points are
  * DMA-able directly, without the runtime's pageable staging copy.  ethcnn_ldp_step goes further: a luma / probs pointer that

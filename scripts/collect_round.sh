@@ -11,6 +11,7 @@ done
 [ -s gpurun_out/latency.txt ] && cp gpurun_out/latency.txt profiles/${R}_latency.txt
 [ -s gpurun_out/latency_ldp.txt ] && cp gpurun_out/latency_ldp.txt profiles/${R}_latency_ldp.txt
 [ -s gpurun_out/latency_ldp_stream.txt ] && cp gpurun_out/latency_ldp_stream.txt profiles/${R}_latency_ldp_stream.txt
+if [ -s gpurun_out/latency_hook.txt ]; then { grep "^# " profiles/${R}_latency_hook.txt 2>/dev/null | grep -v "^# ethcnn_hm_predict_picture"; cat gpurun_out/latency_hook.txt; } > /tmp/_hk.txt && cp /tmp/_hk.txt profiles/${R}_latency_hook.txt; fi
 if [ -s gpurun_out/latency_host.txt ]; then { grep "^# " profiles/${R}_latency_host.txt 2>/dev/null | grep -v "^# ---"; cat gpurun_out/latency_host.txt; } > /tmp/_lh.txt && cp /tmp/_lh.txt profiles/${R}_latency_host.txt; fi
 [ -s gpurun_out/pull_timeline.txt ] && cp gpurun_out/pull_timeline.txt profiles/${R}_pull_timeline.txt
 if [ -s gpurun_out/row_arrival_probe.txt ]; then { grep "^#" profiles/${R}_row_arrival_probe.txt 2>/dev/null; cat gpurun_out/row_arrival_probe.txt; } > /tmp/_ra.txt && cp /tmp/_ra.txt profiles/${R}_row_arrival_probe.txt; fi

@@ -32,6 +32,7 @@ python scripts/power_probe.py 2500 > gpurun_out/power_probe.txt 2>&1; tail -70 g
 python scripts/ldp_handshake.py 1000 > gpurun_out/ldp_handshake.txt 2>&1; cut -c1-200 gpurun_out/ldp_handshake.txt
 python scripts/latency_ldp.py --cpu > gpurun_out/latency_ldp.txt 2>&1; cat gpurun_out/latency_ldp.txt
 python scripts/latency_ldp_stream.py > gpurun_out/latency_ldp_stream.txt 2>&1; cat gpurun_out/latency_ldp_stream.txt
+python scripts/latency_hook.py 2>&1 | grep -v "^ethcnn (in-process)" > gpurun_out/latency_hook.txt; cat gpurun_out/latency_hook.txt
 { python scripts/latency_host.py; echo "# --- the same with ETHCNN_PULL=0 (experiments build): copy engine first, banded above 1024 CTUs (the round's first form)"; ETHCNN_LIB=$EXP ETHCNN_PULL=0 python scripts/latency_host.py; } > gpurun_out/latency_host.txt 2>&1; cat gpurun_out/latency_host.txt
 bash scripts/gpu_pull_probe.sh > /dev/null 2>&1; grep -E "^===|launch" gpurun_out/pull_timeline.txt | cut -c1-200
 cd /tmp

@@ -24,7 +24,7 @@ for name, w, h in (("832x480", 832, 480), ("1280x720", 1280, 720), ("1920x1080",
             a, b = cy * 64 * w, min(h, cy * 64 + 64) * w
             pin[a:b] = src[a:b]
             if report:
-                ctx.lib.ethcnn_ldp_rows_ready(ctx.h, cy, cy + 1)
+                ctx.lib.ethcnn_rows_ready(ctx.h, cy, cy + 1)
     res = {}
     for mode in ("plain", "streamed", "no-wait"):
         for i in range(1, 6 + reps):
@@ -39,7 +39,7 @@ for name, w, h in (("832x480", 832, 480), ("1280x720", 1280, 720), ("1920x1080",
                 ctx.ldp_step_end()
             else:
                 fill(0, nrows, False)
-                ctx.lib.ethcnn_ldp_rows_ready(ctx.h, 0, nrows)
+                ctx.lib.ethcnn_rows_ready(ctx.h, 0, nrows)
                 ctx.ldp_step_begin(pin, w, h, 32, i, pprobs)
                 ctx.ldp_step_end()
         res[mode] = (time.perf_counter() - t0) / reps * 1e6

@@ -209,3 +209,37 @@ def test_development_knobs_are_compiled_out_of_the_shipped_library():
     blob = open(exp, "rb").read()
     for k in dev:
         assert k + b"\0" in blob, k
+
+
+def test_hook_row_conversion_sse2_equals_scalar(tmp_path):
+    """tools/hm_inprocess_hook.c converts HM's 16-bit picture to 8 bits sixteen samples per step (shift, then the pack instruction's
+    saturation as the clamp): equal to the scalar `v >> shift` clamped to [0, 255] for EVERY 16-bit value, shifts 0..8, and row
+    widths that leave a scalar tail.  Compiled as the encoder build compiles it (gcc -std=c99 -O2) with the hook's source included."""
+    import subprocess
+    src = tmp_path / "conv.c"
+    src.write_text("""
+#include "%s"
+int main(void) {
+    static short row[65536 + 64];
+    static unsigned char got[65536 + 64];
+    int shift, w, i;
+    for (i = 0; i < 65536 + 64; ++i) row[i] = (short)(i - 32768);
+    for (shift = 0; shift <= 8; ++shift)
+        for (w = 65536; w <= 65536 + 33; w += 11) {
+            convert_row(row, got, w, shift);
+            for (i = 0; i < w; ++i) {
+                int v = row[i] >> shift;
+                unsigned char want = (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+                if (got[i] != want) { printf("mismatch: sample %%d shift %%d width %%d: %%d != %%d\\n", row[i], shift, w, got[i], want); return 1; }
+            }
+        }
+    puts("rows equal");
+    return 0;
+}
+""" % os.path.join(ROOT, "tools", "hm_inprocess_hook.c"))
+    lib = os.path.join(ROOT, "hevc-complexity-reduction_amd", "lib")
+    exe = str(tmp_path / "conv")
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-D_POSIX_C_SOURCE=200809L", "-I" + os.path.join(ROOT, "include"), str(src), "-o", exe,
+                           "-L" + lib, "-lethcnn", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "rows equal" in r.stdout, r.stdout[-400:] + r.stderr[-400:]

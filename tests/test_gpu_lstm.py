@@ -248,7 +248,7 @@ def test_ldp_step_keeps_the_state_resident(pkg, oracle, lstm):
 
 
 def test_ldp_step_streamed_input(pkg, oracle, lstm):
-    """ethcnn_ldp_step_begin / ethcnn_ldp_rows_ready / ethcnn_ldp_step_end: the frame's kernels are queued on a page-locked buffer that
+    """ethcnn_ldp_step_begin / ethcnn_rows_ready / ethcnn_ldp_step_end: the frame's kernels are queued on a page-locked buffer that
     a filling thread is still writing, CTU row by CTU row in a scrambled order, some rows reported before begin was even called --
     bit-identical to ethcnn_ldp_step (probabilities and resident state) over a recurrence, for frame widths with and without
     16-byte rows and a height that ends in a short CTU row.  Misuse: luma outside page-locked memory, a second begin, end without
@@ -277,7 +277,7 @@ def test_ldp_step_streamed_input(pkg, oracle, lstm):
                 pin[:] = 0xAA                                          # (the previous frame's pixels must not be what is read)
                 def put(cy):
                     pin[cy * 64 * w:min(h, cy * 64 + 64) * w] = luma[cy * 64:cy * 64 + 64].reshape(-1)
-                    a.ldp_rows_ready(cy, cy + 1)
+                    a.rows_ready(cy, cy + 1)
                 for cy in early:
                     put(int(cy))
                 def filler():
@@ -306,17 +306,17 @@ def test_ldp_step_streamed_input(pkg, oracle, lstm):
         with pytest.raises(e.EthCnnError):
             a.ldp_step_end()                                                   # nothing begun
         with pytest.raises(ValueError):
-            a.ldp_rows_ready(3, 2)
+            a.rows_ready(3, 2)
         a.ldp_step_begin(pin, w, h, 27, 1, pprobs)
         with pytest.raises(e.EthCnnError):
             a.ldp_step_begin(pin, w, h, 27, 1, pprobs)                         # still open
-        a.ldp_rows_ready(0, (h + 63) // 64)
+        a.rows_ready(0, (h + 63) // 64)
         a.ldp_step_end()
         # a row that never comes
         luma = rng.integers(0, 256, size=(h, w), dtype=np.uint8)
         pin[:] = luma.reshape(-1)
         a.ldp_step_begin(pin, w, h, 27, 1, pprobs)
-        a.ldp_rows_ready(0, (h + 63) // 64 - 1)
+        a.rows_ready(0, (h + 63) // 64 - 1)
         t0 = time.time()
         with pytest.raises(e.EthCnnError, match="never reported"):
             a.ldp_step_end()
@@ -324,7 +324,7 @@ def test_ldp_step_streamed_input(pkg, oracle, lstm):
         with pytest.raises(e.EthCnnError):
             a.ldp_step(luma, w, h, 27, 2)                                      # the state of that frame was dropped
         assert np.array_equal(_bits(a.ldp_step(luma, w, h, 27, 1)), _bits(b.ldp_step(luma, w, h, 27, 1)))
-        a.ldp_rows_ready(0, (h + 63) // 64)                                    # streamed again, right behind the failure
+        a.rows_ready(0, (h + 63) // 64)                                    # streamed again, right behind the failure
         a.ldp_step_begin(pin, w, h, 27, 2, pprobs)
         a.ldp_step_end()
         assert np.array_equal(_bits(pprobs.reshape(nctu, 21)), _bits(b.ldp_step(luma, w, h, 27, 2)))

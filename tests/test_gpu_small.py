@@ -176,6 +176,83 @@ def test_pull_form_page_locked_pictures(pkg, oracle):
         c.close()
 
 
+def test_predict_luma_streamed_input(pkg, oracle):
+    """ethcnn_predict_luma_begin / ethcnn_rows_ready / ethcnn_predict_luma_end: one picture's pass is queued on a page-locked buffer a
+    filling thread is still writing (the in-process hook's conversion loop) -- CTU rows in scrambled order, some before begin -- and
+    is bit-identical to the oracle: single-launch PULL form (<= 2304 CTUs, 16-byte rows), the five-launch path with a waiting tile
+    stage (odd width; 3927 CTUs), fast FC1 plan on the latter.  Misuse and the never-reported row as for the LDP entry."""
+    import threading
+    import time
+    e = pkg.ethcnn
+    rng = np.random.default_rng(78)
+    blob = oracle.synth_blob(10, 4.0)
+    c = pkg.EthCnn(0)
+    try:
+        c.load_blob(blob)
+        c.set_thresholds(0.6, 0.4)
+        for (w, h) in ((1920, 1080), (416, 240), (200, 136), (3840, 2160), (4928, 3264)):
+            nctu, nrows = e.ctus_per_frame(w, h), (h + 63) // 64
+            pin = c.host_buffer(w * h)
+            pprobs = c.host_buffer(nctu * 84).view(np.float32)
+            for rep in range(3):
+                luma = rng.integers(0, 256, size=(1, h, w), dtype=np.uint8)
+                want = oracle.predict_frames(blob, luma, w, h, 1, 30, 0.6, 0.4, mode=0)
+                order = rng.permutation(nrows)
+                early = order[:rep]
+                pin[:] = 0x55
+                def put(cy):
+                    pin[cy * 64 * w:min(h, cy * 64 + 64) * w] = luma[0, cy * 64:cy * 64 + 64].reshape(-1)
+                    c.rows_ready(cy, cy + 1)
+                for cy in early:
+                    put(int(cy))
+                def filler():
+                    time.sleep(0.001)
+                    for cy in order[len(early):]:
+                        put(int(cy))
+                t = threading.Thread(target=filler)
+                t.start()
+                c.predict_luma_begin(pin, w, h, 30, pprobs)
+                t.join()
+                c.predict_luma_end()
+                assert np.array_equal(_bits(pprobs.reshape(-1, 21)), _bits(want.reshape(-1, 21))), (w, h, rep)
+                # the plain call on the same context in between
+                assert np.array_equal(_bits(c.predict_luma(luma, w, h, 1, 30).reshape(-1, 21)), _bits(want.reshape(-1, 21))), (w, h, rep)
+            c.free_host_buffers()
+        # misuse
+        w, h = 416, 240
+        nctu, nrows = e.ctus_per_frame(w, h), 4
+        pin = c.host_buffer(w * h)
+        pprobs = c.host_buffer(nctu * 84).view(np.float32)
+        with pytest.raises(e.EthCnnError):
+            c.predict_luma_begin(np.zeros(w * h, np.uint8), w, h, 30, pprobs)   # pageable
+        with pytest.raises(e.EthCnnError):
+            c.predict_luma_end()                                                 # nothing begun
+        big = c.host_buffer(64 * 64 * 8192)
+        with pytest.raises(e.EthCnnError):
+            c.predict_luma_begin(big, 64 * 8192, 64, 30, np.zeros(8192 * 21, np.float32))  # 8192 CTUs: not one pass
+        c.predict_luma_begin(pin, w, h, 30, pprobs)
+        with pytest.raises(e.EthCnnError):
+            c.predict_luma_begin(pin, w, h, 30, pprobs)                          # still open
+        c.rows_ready(0, nrows)
+        c.predict_luma_end()
+        # a row that never comes: the kernels give up after ~1 s, the context keeps working
+        luma = rng.integers(0, 256, size=(1, h, w), dtype=np.uint8)
+        pin[:] = luma.reshape(-1)
+        c.predict_luma_begin(pin, w, h, 30, pprobs)
+        c.rows_ready(1, nrows)
+        t0 = time.time()
+        with pytest.raises(e.EthCnnError, match="never reported"):
+            c.predict_luma_end()
+        assert 0.5 < time.time() - t0 < 10.0
+        want = oracle.predict_frames(blob, luma, w, h, 1, 30, 0.6, 0.4, mode=0)
+        c.rows_ready(0, nrows)
+        c.predict_luma_begin(pin, w, h, 30, pprobs)
+        c.predict_luma_end()
+        assert np.array_equal(_bits(pprobs.reshape(-1, 21)), _bits(want.reshape(-1, 21)))
+    finally:
+        c.close()
+
+
 def test_claim_or_execute_when_producer_blocks_never_run(pkg, oracle):
     """FORWARD PROGRESS of the dataflow launch when the GPU is shared: a consumer that has waited too long executes
     the unclaimed work items it depends on itself.  ETHCNN_SMALL_STEAL_TEST=k makes every k-th producer block (trunk and FC1

@@ -27,6 +27,9 @@
 #include <string.h>
 
 #include "ethcnn.h"
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 /* context + thresholds + weights for sequence QP `qp`, as the launcher sets them up; NULL on failure */
 static ethcnn_ctx* open_predictor(int qp) {
@@ -61,6 +64,26 @@ fail:
     return NULL;
 }
 
+/* one row of HM's picture (Pel = 16-bit samples at the internal bit depth) -> 8 bits: v >> shift, clamped to [0, 255] */
+static void convert_row(const short* src, unsigned char* dst, int width, int shift) {
+    int x = 0;
+#if defined(__SSE2__)
+    /* sixteen samples per step: arithmetic shift, then the pack instruction's own saturation IS the clamp to [0, 255]
+     * (the scalar loop below, which gcc -O2 leaves scalar, cost 880 us per 1920x1080 picture: nine predictions;
+     * tests/test_abi_and_host.py checks the two forms equal for every sample value) */
+    const __m128i vshift = _mm_cvtsi32_si128(shift);
+    for (; x + 16 <= width; x += 16) {
+        const __m128i a = _mm_sra_epi16(_mm_loadu_si128((const __m128i*)(src + x)), vshift);
+        const __m128i b = _mm_sra_epi16(_mm_loadu_si128((const __m128i*)(src + x + 8)), vshift);
+        _mm_storeu_si128((__m128i*)(dst + x), _mm_packus_epi16(a, b));
+    }
+#endif
+    for (; x < width; ++x) {
+        int v = src[x] >> shift;
+        dst[x] = (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    }
+}
+
 /* ---- per-picture entry (the real in-process hook) ------------------------------------------- */
 static ethcnn_ctx* g_ctx = NULL;
 static int g_qp = -1;
@@ -85,7 +108,7 @@ static void close_predictor(void) {
 int ethcnn_hm_predict_picture(const short* luma, int stride, int width, int height, int bit_depth, int qp, float* probs) {
     const int shift = bit_depth > 8 ? bit_depth - 8 : 0;
     const size_t need = (size_t)width * (size_t)height;
-    int x, y;
+    int y;
     if (!luma || !probs || width <= 0 || height <= 0 || stride < width) return 1;
     if (!g_ctx || qp != g_qp) {
         if (g_ctx) {
@@ -108,17 +131,24 @@ int ethcnn_hm_predict_picture(const short* luma, int stride, int width, int heig
         g_luma8 = (unsigned char*)p;
         g_luma8_cap = need;
     }
-    for (y = 0; y < height; ++y) {
-        const short* src = luma + (size_t)y * stride;
-        unsigned char* dst = g_luma8 + (size_t)y * width;
-        for (x = 0; x < width; ++x) {
-            int v = src[x] >> shift;
-            dst[x] = (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    /* STREAMED: the picture's pass is queued first and takes the plane CTU row by CTU row while this loop is still converting it
+     * (a 1920x1080 conversion costs about what the prediction does; ETHCNN_HM_STREAM=0: convert, then ethcnn_predict_luma) */
+    {
+        static int stream = -1;
+        int streamed;
+        if (stream < 0) { const char* e = getenv("ETHCNN_HM_STREAM"); stream = !(e && atoi(e) == 0); }
+        streamed = stream && ethcnn_predict_luma_begin(g_ctx, g_luma8, width, height, qp, probs) == ETHCNN_OK;  /* (geometries the
+            streamed entry refuses -- more than 8191 CTUs -- take the plain call below) */
+        for (y = 0; y < height; ++y) {
+            const short* src = luma + (size_t)y * stride;
+            unsigned char* dst = g_luma8 + (size_t)y * width;
+            convert_row(src, dst, width, shift);
+            if (streamed && ((y & 63) == 63 || y == height - 1)) (void)ethcnn_rows_ready(g_ctx, y >> 6, (y >> 6) + 1);
         }
-    }
-    if (ethcnn_predict_luma(g_ctx, g_luma8, width, height, width, (ptrdiff_t)need, 1, qp, probs) != ETHCNN_OK) {
-        fprintf(stderr, "ethcnn (in-process): %s\n", ethcnn_last_error(g_ctx));
-        return 1;
+        if ((streamed ? ethcnn_predict_luma_end(g_ctx) : ethcnn_predict_luma(g_ctx, g_luma8, width, height, width, (ptrdiff_t)need, 1, qp, probs)) != ETHCNN_OK) {
+            fprintf(stderr, "ethcnn (in-process): %s\n", ethcnn_last_error(g_ctx));
+            return 1;
+        }
     }
     {   /* verification aid: ETHCNN_HM_DUMP=<file> appends every picture's probabilities (tests compare them
          * with the oracle); the encoder itself never reads it */

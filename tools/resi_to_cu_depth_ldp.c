@@ -17,7 +17,7 @@
  *     poll interval, no busy core while the encoder encodes; a short spin right after a frame catches back-to-back frames;
  *   * resi.yuv is read by eight threads straight into a page-locked buffer the kernels use in place (ethcnn_host_alloc) WHILE the
  *     frame's kernels are already queued and take the plane CTU row by CTU row as the threads report it (ethcnn_ldp_step_begin /
- *     ethcnn_ldp_rows_ready / ethcnn_ldp_step_end, see read_luma_start); the probabilities land in a second page-locked buffer and
+ *     ethcnn_rows_ready / ethcnn_ldp_step_end, see read_luma_start); the probabilities land in a second page-locked buffer and
  *     go to cu_depth.dat with one write().  (A library entry that read the file in 16 bands on its worker pool and DMA'd each band
  *     as it arrived -- kernels on device-resident pixels -- was built first and measured 276 us per 1080p call against 64 + 114
  *     for read-then-predict: sixteen small async copies from a pool cost more than the overlap wins.  Kernels that WAIT for the
@@ -106,7 +106,7 @@ static int read_exact(const char* path, void* dst, size_t bytes) {
  * single-threaded copy out of the page cache: ~180 us of the ~320 us the encoder waited in round 3's first daemon; four threads (three
  * persistent helpers + the caller) brought it to ~50 us -- followed by the 115 us of ethcnn_ldp_step.  Now the frame's kernels are queued
  * FIRST (ethcnn_ldp_step_begin) and the threads copy the plane one CTU row (64 luma rows) at a time, drawing row numbers from a shared
- * counter and reporting each (ethcnn_ldp_rows_ready): the tile stage pulls a row over PCIe as soon as it is there, so the transfer and
+ * counter and reporting each (ethcnn_rows_ready): the tile stage pulls a row over PCIe as soon as it is there, so the transfer and
  * the launch overheads run under the read: 1920x1080, handshake p50 249 -> 214 us with three helpers, and with seven the copy itself
  * drops under the 38 us the plane needs on the bus (profiles/r04_ldp_handshake.txt).  The helpers sleep on a condition variable between
  * frames.  Pictures under 512 KiB are read by the caller alone, then predicted (nothing to hide a launch under: 416x240 is 100 KB). */
@@ -140,7 +140,7 @@ static int rd_rows(int fd, char* dst, int w, int h, ethcnn_ctx* ctx) {
         const size_t off = (size_t)cy * 64 * (size_t)w;
         const int rows = (cy * 64 + 64 <= h) ? 64 : h - cy * 64;
         if (pread_exact(fd, dst + off, (size_t)rows * (size_t)w, (off_t)off) != 0) bad = 1;
-        if (ctx) ethcnn_ldp_rows_ready(ctx, cy, cy + 1);
+        if (ctx) ethcnn_rows_ready(ctx, cy, cy + 1);
     }
     return bad;
 }
