@@ -303,7 +303,8 @@ def test_four_processes_share_the_gpu(pkg, oracle, tmp_path):
     at the same time (their launches' waiting blocks can starve each other's producers; claim-or-execute keeps them moving).
     Four processes that start together (file barrier) and each issue single-picture passes of three geometries back to back for
     3 s (plus a 12,240-CTU pass now and then, whose long-running blocks skew the XCDs' dispatch progress), every 8th result
-    checked bit for bit; none may trap, hang, stall or fall silent."""
+    checked bit for bit; none may trap, hang, stall or fall silent.  Two of the four alternate with the PULL form of the launch
+    (page-locked pictures, host to host: pull blocks -> trunk items that wait for them), every result checked."""
     import os
     import subprocess
     import sys
@@ -326,7 +327,9 @@ def test_four_processes_share_the_gpu(pkg, oracle, tmp_path):
             nctu = pkg.ethcnn.ctus_per_frame(w, h)
             d_in, d_out = c.alloc(luma.nbytes), c.alloc(nctu * 84)
             d_in.upload(luma)
-            cases.append((w, h, nctu, d_in, d_out, oracle.predict_frames(blob, luma, w, h, 1, 30, 0.5, 0.5, mode=0)))
+            pin = c.host_buffer(w * h)   # ... and page-locked: the PULL form of the same launch (odd processes use it every other round)
+            pin[:] = luma.reshape(-1)
+            cases.append((w, h, nctu, d_in, d_out, oracle.predict_frames(blob, luma, w, h, 1, 30, 0.5, 0.5, mode=0), pin))
         open(os.path.join(gate, "ready%%d" %% seed), "w").close()
         while len(os.listdir(gate)) < 4:
             time.sleep(0.001)
@@ -336,7 +339,12 @@ def test_four_processes_share_the_gpu(pkg, oracle, tmp_path):
         while time.time() - t0 < float(os.environ.get('ETHCNN_SHARED_SECONDS', '3')) or k %% 8:
             if k %% 32 == 8 * seed:
                 c.predict_luma_device(big_in, 1920, 1080, 24, 30, big_out)
-            w, h, nctu, d_in, d_out, want = cases[(k // 8 + seed) %% 3]
+            w, h, nctu, d_in, d_out, want, pin = cases[(k // 8 + seed) %% 3]
+            if seed %% 2 == 1 and (k // 8) %% 2 == 1:  # host -> host through the pull blocks (synchronous call)
+                got = c.predict_luma(pin.reshape(1, h, w), w, h, 1, 30).reshape(-1, 21)
+                assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (seed, k, "pull")
+                k += 1
+                continue
             c.predict_luma_device(d_in, w, h, 1, 30, d_out)
             if k %% 8 == 7:
                 c.synchronize()
