@@ -1219,11 +1219,13 @@ static int predict_luma_latency(ethcnn_ctx* c, const uint8_t* luma, int w, int h
     // buffer) -- no copy-engine launch in front of the kernel, and the trunk / FC1 / heads of the first CTU rows run while the last
     // rows are still on the bus (ethcnn_small.hip, "PULL form"; profiles/r04_latency_host.txt)
     const bool stage_rows = !(packed && in_pinned(c, luma, in_bytes));
-    // (a big picture in PAGEABLE memory keeps the banded form below: its staging copy -- 8.3 MB, 150 us of memcpy -- overlaps the
-    // copy engine band by band there, while a pull could only start behind all of it: 347 against 367 us)
-    const bool pull = nframes == 1 && c->pull && c->small_launch && w % 16 == 0 && g.nctu <= kSmallPassMaxCtus && !(stage_rows && g.nctu > kSubBatch);
+    const bool pull = nframes == 1 && c->pull && c->small_launch && w % 16 == 0 && g.nctu <= kSmallPassMaxCtus;
+    // A picture in PAGEABLE (or pitched) memory has to be copied into the page-locked staging buffer first: that copy is STREAMED into
+    // the pass (the mechanism of ethcnn_predict_luma_begin, applied to the library's own staging) -- the launch is queued on the
+    // staging buffer, then the rows are copied CTU row by CTU row, each reported as it lands
+    const bool stream_stage = pull && stage_rows && c->h_rows != nullptr && g.ch <= kStreamCtuRows;
     const bool banded = !pull && nframes == 1 && g.nctu > kSubBatch && c->small_launch && w % 16 == 0;  // (below)
-    if (stage_rows && !banded) {  // tight planes into the pinned staging buffer
+    if (stage_rows && !banded && !stream_stage) {  // tight planes into the pinned staging buffer
         for (int f = 0; f < nframes; ++f) {
             const uint8_t* s = luma + (size_t)f * fstride;
             uint8_t* d = c->h_in[0] + (size_t)f * plane;
@@ -1232,7 +1234,22 @@ static int predict_luma_latency(ethcnn_ctx* c, const uint8_t* luma, int w, int h
         }
         src = c->h_in[0];
     }
-    if (pull) {
+    if (stream_stage) {
+        rc = ensure_workspace(c, g.nctu, chunks_per_frame(g.nctu));  // (whatever may wait for the stream: before the waiting kernels are queued)
+        if (rc) return rc;
+        c->luma_over_pcie = true;
+        c->tile_wait_rows = c->h_rows;
+        rc = run_pass(c, c->h_in[0], g, 0, g.nctu, qp, c->d_out[0]);
+        c->luma_over_pcie = false;
+        c->tile_wait_rows = nullptr;
+        const unsigned seq = c->rows_seq;
+        for (int cy = 0; cy < g.ch; ++cy) {  // (also when the launch failed: whatever is queued must drain)
+            if (rc == 0)
+                for (int y = cy * kCtu; y < std::min(h, cy * kCtu + kCtu); ++y) std::memcpy(c->h_in[0] + (size_t)y * w, luma + (size_t)y * pitch, (size_t)w);
+            __atomic_store_n(c->h_rows + cy, seq, __ATOMIC_RELEASE);
+        }
+        if (++c->rows_seq == 0) c->rows_seq = 1;
+    } else if (pull) {
         c->luma_over_pcie = true;
         rc = run_pass(c, src, g, 0, g.nctu, qp, c->d_out[0]);
         c->luma_over_pcie = false;
