@@ -256,7 +256,7 @@ def main():
                              "v_mfma_f32_32x32x16_bf16" if plan == 1 else
                              "every scaled fp32 feature / weight as two fp16 pieces (2^-24 relative), three products on "
                              "v_mfma_f32_32x32x16_f16") + "; opt-in, never the default",
-                    "roofline": {"kernel": "k_fc1_fast<%d,7> (FC1 [N,2688]x[2688,448] as %d 16-bit products per fp32 product)" % (fc1_plan, nprod),
+                    "roofline": {"kernel": "k_fc1_fast<%d, 7, nine> (ethcnn_fc1_fast.hip; FC1 [N,2688]x[2688,448] as %d 16-bit products per fp32 product)" % (fc1_plan, nprod),
                                  "bound": "mfma", "achieved": nprod * f_alg, "peak": PEAK_BF16_MFMA_TFLOPS,
                                  "unit": "TFLOP/s (16-bit products issued)", "frac": nprod * f_alg / PEAK_BF16_MFMA_TFLOPS,
                                  "algorithmic_f32_tflops": f_alg, "avg_launch_ms": f_ms, "launches_timed": f_st["timed"]["fc1"],

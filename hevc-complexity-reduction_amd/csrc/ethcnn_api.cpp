@@ -467,6 +467,8 @@ static void free_staging(ethcnn_ctx* c) {
 extern "C" void ethcnn_destroy(ethcnn_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if ((c->ldp.open || c->ai.open) && c->h_rows)  // destroyed between a streamed begin and its end: release the kernels that wait for
+        for (int cy = 0; cy < kStreamCtuRows; ++cy) __atomic_store_n(c->h_rows + cy, c->rows_seq, __ATOMIC_RELEASE);  // rows (else: 1 s each)
     (void)hipDeviceSynchronize();  // on THIS context's device: a launch still in flight may store the completion word
     if (c->h_done) { (void)hipHostFree(c->h_done); c->h_done = nullptr; }
     if (c->h_rows) { (void)hipHostFree(c->h_rows); c->h_rows = nullptr; }
@@ -1726,7 +1728,11 @@ static int ldp_step_begin(ethcnn_ctx* c, const uint8_t* luma, int w, int h, ptrd
     if (rc) {
         // (streamed: kernels already queued may be waiting for rows the caller will now never report: release them -- the result is
         // discarded -- so that the stream drains)
-        if (streamed) { for (int cy = 0; cy < (h + 63) / 64; ++cy) __atomic_store_n(c->h_rows + cy, c->rows_seq, __ATOMIC_RELEASE); ++c->rows_seq; if (c->rows_seq == 0) c->rows_seq = 1; }
+        if (streamed) {
+            for (int cy = 0; cy < (h + 63) / 64; ++cy) __atomic_store_n(c->h_rows + cy, c->rows_seq, __ATOMIC_RELEASE);
+            (void)hipStreamSynchronize(c->stream);  // (nothing may still be reading the caller's buffer when the error is returned)
+            if (++c->rows_seq == 0) c->rows_seq = 1;
+        }
         return rc;
     }
     c->ldp.open = true;

@@ -82,7 +82,7 @@ if fe is not None and wr is not None:
             out["%s_plan%d" % (wl, plan)] = {"kernel_source_blob": bench.fc1_fast_source_stamp(),
                 "bytes_per_launch": int(ffe*1024*2 + fwr*1024), "fetch_size_kb_reported": ffe, "write_size_kb_reported": fwr, "steps_averaged": k1,
                 "algorithmic_bytes_per_launch": n*2688*2*npieces + 2688*448*2*npieces + n*448*4,
-                "source": "the same passes, dispatches of k_fc1_fast<%d, 7> (FETCH_SIZE x2)" % plan}
+                "source": "the same passes, dispatches of k_fc1_fast<%d, 7, ...> (FETCH_SIZE x2)" % plan}
     json.dump(out, open("gpurun_out/fc1_traffic_%s.json" % wl,"w"), indent=1); print("fc1 traffic:", out)
 PY
 }
