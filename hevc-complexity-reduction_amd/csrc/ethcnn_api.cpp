@@ -171,6 +171,8 @@ struct ethcnn_ctx {
     int* flags1 = nullptr;
     hipStream_t s_tile = nullptr;
     hipEvent_t e_tile[2] = {}, e_trunk[2] = {}, e_main = nullptr;
+    hipEvent_t e_fc1[2] = {};     // fast plans: "FC1 of the pass on buffer set p has finished" (the next pass's tile stage starts behind it)
+    int tile_after_fc1 = 0;       // fast plans: the CTU-load stage of pass i+1 beside heads + gates of pass i instead of beside its FC1
     hipEvent_t e_band[4] = {};  // one big picture, host -> host: "the rows of piece k are in HBM" (predict_luma_latency)
     int* d_lgate = nullptr;  // LSTM heads launch: gate predicates + ticket tree (lstm_gate_words)
     int lgate_chunks = 0;    // its capacity in ints
@@ -365,7 +367,7 @@ extern "C" int ethcnn_create(ethcnn_ctx** out, const ethcnn_options* opt) {
         return set_err(nullptr, ETHCNN_ERR_DEVICE, "cannot create HIP streams on device %d", dev);
     }
     {
-        hipEvent_t* evs[] = {&c->e_tile[0], &c->e_tile[1], &c->e_trunk[0], &c->e_trunk[1], &c->e_main,
+        hipEvent_t* evs[] = {&c->e_tile[0], &c->e_tile[1], &c->e_trunk[0], &c->e_trunk[1], &c->e_main, &c->e_fc1[0], &c->e_fc1[1],
                              &c->e_band[0], &c->e_band[1], &c->e_band[2], &c->e_band[3]};
         for (hipEvent_t* e : evs)
             if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) {
@@ -383,6 +385,7 @@ extern "C" int ethcnn_create(ethcnn_ctx** out, const ethcnn_options* opt) {
     if (const char* e = dev_env("ETHCNN_GATE_FOLD")) c->gate_fold = std::atoi(e) != 0;  // development knob (A/B runs)
     if (const char* e = dev_env("ETHCNN_DONE_WORD")) c->done_sync = std::atoi(e) != 0;  // development knob (A/B runs)
     if (const char* e = dev_env("ETHCNN_PULL")) c->pull = std::atoi(e) != 0;            // development knob (A/B runs)
+    if (const char* e = dev_env("ETHCNN_TILE_AFTER_FC1")) c->tile_after_fc1 = std::atoi(e) != 0;  // development knob (A/B runs)
     if (const char* e = dev_env("ETHCNN_LSTM_ONE_LAUNCH")) c->lstm_one_launch = std::atoi(e) != 0;  // development knob (A/B runs)
     if (hipHostMalloc((void**)&c->h_done, 64, hipHostMallocDefault) != hipSuccess) {
         ethcnn_destroy(c);
@@ -488,7 +491,7 @@ extern "C" void ethcnn_destroy(ethcnn_ctx* c) {
             if (p) (void)hipFree(p);
     }
     {
-        hipEvent_t evs[] = {c->e_tile[0], c->e_tile[1], c->e_trunk[0], c->e_trunk[1], c->e_main, c->e_band[0], c->e_band[1], c->e_band[2], c->e_band[3]};
+        hipEvent_t evs[] = {c->e_tile[0], c->e_tile[1], c->e_trunk[0], c->e_trunk[1], c->e_main, c->e_fc1[0], c->e_fc1[1], c->e_band[0], c->e_band[1], c->e_band[2], c->e_band[3]};
         for (hipEvent_t e : evs)
             if (e) (void)hipEventDestroy(e);
     }
@@ -909,7 +912,8 @@ static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, lo
         HIPCHK(c, hipStreamWaitEvent(s_tile, c->e_main, 0));
         // ... and it should run beside FC1(i-1), not beside trunk(i-1): with the trunk it competes for VALU issue and HBM
         // (measured: trunk 556 -> 819 us, tile 180 -> 511 us, step period 2.60 -> 2.73 ms; profiles/r02_overlap_trace.txt)
-        HIPCHK(c, hipStreamWaitEvent(s_tile, c->e_trunk[p ^ 1], 0));
+        const bool behind_fc1 = c->tile_after_fc1 != 0 && c->fc1_plan != 0;
+        HIPCHK(c, hipStreamWaitEvent(s_tile, behind_fc1 ? c->e_fc1[p ^ 1] : c->e_trunk[p ^ 1], 0));
     }
     // A/B knob (experiments build): CTU-load stage folded into the trunk for big exact passes (profiles/r04_tile_fold.txt)
     static const bool fold_knob = [] { const char* e = dev_env("ETHCNN_TILE_FOLD"); return e && std::atoi(e) != 0; }();
@@ -947,6 +951,7 @@ static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, lo
     if (fast) {
         { StageTimer t(c, ETHCNN_STAGE_FC1, n); launch_fc1_fast(w, c->dw, n, w.h1, fast == 3 ? 2 : fast, c->stream, c->cus); }
         LAUNCH_OK("FC1 (plan 1 / 2)");
+        if (side_tile && c->tile_after_fc1) HIPCHK(c, hipEventRecord(c->e_fc1[p], c->stream));
         { StageTimer t(c, ETHCNN_STAGE_HEADS); launch_heads(wv, c->dw, n, qn, g.nctu, ctu0, c->thr1, c->thr2, d_probs_pass, c->stream, c->gate_fold ? (int)nchunks : 0); }
         if (!c->gate_fold) { StageTimer t(c, ETHCNN_STAGE_GATE); launch_gate(w, n, g.nctu, ctu0, c->thr2, d_probs_pass, c->stream); }
         LAUNCH_OK("heads / gate");
