@@ -296,6 +296,23 @@ def test_ldp_step_streamed_input(pkg, oracle, lstm):
             luma = rng.integers(0, 256, size=(h, w), dtype=np.uint8)
             assert np.array_equal(_bits(a.ldp_step(luma, w, h, 27, 5)), _bits(b.ldp_step(luma, w, h, 27, 5))), (w, h)
             a.free_host_buffers()
+        # a pitched plane (rows 48 bytes apart from the next one's start): single-launch PULL form with a pitch
+        w, h, pitch = 832, 480, 832 + 48
+        nctu, nrows = e.ctus_per_frame(w, h), (h + 63) // 64
+        pin = a.host_buffer(pitch * h)
+        pprobs = a.host_buffer(nctu * 21 * 4).view(np.float32)
+        for i_frame in (1, 2, 3):
+            luma = rng.integers(0, 256, size=(h, w), dtype=np.uint8)
+            want = b.ldp_step(luma, w, h, 27, i_frame)
+            pin[:] = 0x33
+            a.ldp_step_begin(pin, w, h, 27, i_frame, pprobs, pitch=pitch)
+            for cy in rng.permutation(nrows):
+                for y in range(cy * 64, min(h, cy * 64 + 64)):
+                    pin[y * pitch:y * pitch + w] = luma[y]
+                a.rows_ready(int(cy), int(cy) + 1)
+            a.ldp_step_end()
+            assert np.array_equal(_bits(pprobs.reshape(nctu, 21)), _bits(want)), ("pitched", i_frame)
+        a.free_host_buffers()
         # misuse
         w, h = 416, 240
         nctu = e.ctus_per_frame(w, h)
