@@ -212,8 +212,11 @@ struct ethcnn_ctx {
     unsigned* h_rows = nullptr;
     unsigned rows_seq = 1;
     const unsigned* tile_wait_rows = nullptr;  // set around the tile launch of a streamed step
+    float* host_probs = nullptr;               // set around a host -> host single-launch pass: page-locked destination its last block copies the
+                                               // probabilities to (then no copy launch behind the kernel: the caller waits on the completion word)
+    bool host_probs_used = false;              // ... and whether the pass took it (single-launch form, completion word armed)
     struct LdpPending { bool open = false, streamed = false; float* probs = nullptr; float* d_probs = nullptr; size_t pbytes = 0; int out = 0, nctu = 0; } ldp;
-    struct LumaPending { bool open = false; float* probs = nullptr; size_t out_bytes = 0; } ai;  // ethcnn_predict_luma_begin ... _end
+    struct LumaPending { bool open = false, direct = false; float* probs = nullptr; size_t out_bytes = 0; } ai;  // ethcnn_predict_luma_begin ... _end
     unsigned done_seq = 0;     // last number handed out
     unsigned done_armed = 0;   // != 0: the LAST operation enqueued on the main stream stores this number when all its outputs are final
     int done_sync = 1;         // env ETHCNN_DONE_WORD=0: always hipStreamSynchronize (A/B runs)
@@ -857,11 +860,12 @@ static int run_small_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom&
     c->ssync_clean = false;  // until this launch has been enqueued without an error
     (void)hipGetLastError();
     const unsigned seq = resi ? 0u : done_arm(c);
-    { StageTimer t(c, ETHCNN_STAGE_FC1, n); launch_small_pass(d_luma, g, ctu0, n, resi, w, c->dw, fc1_out, qn, c->thr1, c->thr2, d_probs, nchunks, c->d_ssync, c->small_epoch, seq ? c->h_done : nullptr, seq, c->stream, pull, wait_rows, c->rows_seq, c->h_done + 1); }
+    { StageTimer t(c, ETHCNN_STAGE_FC1, n); launch_small_pass(d_luma, g, ctu0, n, resi, w, c->dw, fc1_out, qn, c->thr1, c->thr2, d_probs, nchunks, c->d_ssync, c->small_epoch, seq ? c->h_done : nullptr, seq, c->stream, pull, wait_rows, c->rows_seq, c->h_done + 1, (seq && !resi) ? c->host_probs : nullptr); }
     const hipError_t le = hipGetLastError();
     if (le != hipSuccess) return set_err(c, ETHCNN_ERR_DEVICE, "launch of the single-launch small pass failed: %s", hipGetErrorString(le));
     c->ssync_clean = true;
     c->done_armed = seq;
+    c->host_probs_used = seq && !resi && c->host_probs != nullptr && reinterpret_cast<uintptr_t>(c->host_probs) % 16 == 0;
     return 0;
 }
 
@@ -1241,14 +1245,22 @@ static int predict_luma_latency(ethcnn_ctx* c, const uint8_t* luma, int w, int h
         }
         src = c->h_in[0];
     }
+    // (single-launch forms: the launch's last block hands the probabilities to the host itself and reports through the completion
+    // word -- no copy launch behind the kernel)
+    float* const dst = in_pinned(c, probs, out_bytes) ? probs : c->h_out[0];
+    bool direct = false;
     if (stream_stage) {
         rc = ensure_workspace(c, g.nctu, chunks_per_frame(g.nctu));  // (whatever may wait for the stream: before the waiting kernels are queued)
         if (rc) return rc;
+        c->host_probs = dst;
+        c->host_probs_used = false;
         c->luma_over_pcie = true;
         c->tile_wait_rows = c->h_rows;
         rc = run_pass(c, c->h_in[0], g, 0, g.nctu, qp, c->d_out[0]);
         c->luma_over_pcie = false;
         c->tile_wait_rows = nullptr;
+        c->host_probs = nullptr;
+        direct = rc == 0 && c->host_probs_used;
         const unsigned seq = c->rows_seq;
         for (int cy = 0; cy < g.ch; ++cy) {  // (also when the launch failed: whatever is queued must drain)
             if (rc == 0)
@@ -1257,9 +1269,13 @@ static int predict_luma_latency(ethcnn_ctx* c, const uint8_t* luma, int w, int h
         }
         if (++c->rows_seq == 0) c->rows_seq = 1;
     } else if (pull) {
+        c->host_probs = dst;
+        c->host_probs_used = false;
         c->luma_over_pcie = true;
         rc = run_pass(c, src, g, 0, g.nctu, qp, c->d_out[0]);
         c->luma_over_pcie = false;
+        c->host_probs = nullptr;
+        direct = rc == 0 && c->host_probs_used;
     } else if (banded) {
         // (the round's first form, kept for ETHCNN_PULL=0 A/B runs)  One big picture (3840x2160: 8.3 MB = 151 us of PCIe against ~100 us of kernels, serial until round 4): the picture is
         // cut on its gate sub-batch boundaries (1024 CTUs in raster order: video_to_cu_depth.py:61-73, so gate scope is intact) and
@@ -1295,10 +1311,13 @@ static int predict_luma_latency(ethcnn_ctx* c, const uint8_t* luma, int w, int h
     // (letting the single-launch pass write the probabilities straight into page-locked host memory and report through the
     // completion word was measured 3 us SLOWER than this copy + hipStreamSynchronize: 96 heads blocks storing 4-byte words
     // over PCIe; profiles/r03_completion_word.txt)
-    float* dst = in_pinned(c, probs, out_bytes) ? probs : c->h_out[0];
-    c->done_armed = 0;
-    HIPCHK(c, hipMemcpyAsync(dst, c->d_out[0], out_bytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (direct) {
+        HIPCHK(c, stream_sync(c));
+    } else {
+        c->done_armed = 0;
+        HIPCHK(c, hipMemcpyAsync(dst, c->d_out[0], out_bytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     if (dst != probs) std::memcpy(probs, dst, out_bytes);
     return ETHCNN_OK;
 }
@@ -1326,11 +1345,15 @@ extern "C" int ethcnn_predict_luma_begin(ethcnn_ctx* c, const uint8_t* luma, int
     if (rc == 0) rc = ensure_workspace(c, g.nctu, chunks_per_frame(g.nctu));
     if (rc == 0 && c->fc1_plan != 0) rc = ensure_fast_weights(c, c->fc1_plan);  // (first use packs and uploads the 16-bit weight images)
     if (rc) return rc;
+    c->host_probs = in_pinned(c, probs, out_bytes) ? probs : c->h_out[0];
+    c->host_probs_used = false;
     c->luma_over_pcie = true;
     c->tile_wait_rows = c->h_rows;
     rc = run_pass(c, luma, g, 0, g.nctu, qp, c->d_out[0]);
     c->luma_over_pcie = false;
     c->tile_wait_rows = nullptr;
+    c->host_probs = nullptr;
+    c->ai.direct = rc == 0 && c->host_probs_used;
     if (rc) {  // release whatever is already queued (the result is discarded) and let the stream drain
         for (int cy = 0; cy < g.ch; ++cy) __atomic_store_n(c->h_rows + cy, c->rows_seq, __ATOMIC_RELEASE);
         (void)hipStreamSynchronize(c->stream);
@@ -1350,9 +1373,13 @@ extern "C" int ethcnn_predict_luma_end(ethcnn_ctx* c) {
     const unsigned seq = c->rows_seq;
     if (++c->rows_seq == 0) c->rows_seq = 1;  // the next streamed picture's number is fixed from here on
     float* dst = in_pinned(c, c->ai.probs, c->ai.out_bytes) ? c->ai.probs : c->h_out[0];
-    c->done_armed = 0;
-    HIPCHK(c, hipMemcpyAsync(dst, c->d_out[0], c->ai.out_bytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->ai.direct) {  // (the launch's last block has written dst itself)
+        HIPCHK(c, stream_sync(c));
+    } else {
+        c->done_armed = 0;
+        HIPCHK(c, hipMemcpyAsync(dst, c->d_out[0], c->ai.out_bytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     if (__atomic_load_n(c->h_done + 1, __ATOMIC_ACQUIRE) == seq)
         return set_err(c, ETHCNN_ERR_DEVICE, "ethcnn_predict_luma_end: the kernels waited 1 s for luma rows that were never reported (ethcnn_rows_ready)");
     if (dst != c->ai.probs) std::memcpy(c->ai.probs, dst, c->ai.out_bytes);

@@ -70,7 +70,9 @@ int small_pass_sync_words(int n, int nchunks);
 void launch_small_pass(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, bool resi, const Workspace& ws,
                        const DeviceWeights& w, float* fc1_out, float qn, float thr1, float thr2, float* d_probs, int nchunks,
                        int* d_sync, int epoch, unsigned* done, unsigned done_seq, hipStream_t s, bool pull = false,
-                       const unsigned* wait_rows = nullptr, unsigned wait_seq = 0, unsigned* gave_up = nullptr);
+                       const unsigned* wait_rows = nullptr, unsigned wait_seq = 0, unsigned* gave_up = nullptr, float* host_probs = nullptr);
+// host_probs (with done; page-locked host memory, 16-byte aligned): the launch's last block copies the probabilities there before it
+// stores the completion word
 // wait_rows (with pull; streamed input, as launch_tile's): a group is pulled once the caller has reported its CTU rows
 // pull: d_luma is page-locked HOST memory; the launch's first blocks read it over PCIe into the workspace's pixel records (xs / xm /
 // xl) and the trunk starts group by group as they land (ethcnn_small.hip, "PULL form")

@@ -69,6 +69,8 @@ struct SmallParams {
     int epoch;      // this launch's claim tag (never 0; claim words hold the tag of the last launch that claimed them)
     unsigned* done;      // completion word in page-locked HOST memory (null: none) ...
     unsigned done_seq;   // ... the launch's last finishing block stores this value there, after every output of the launch
+    float* host_probs;   // page-locked HOST memory, 16-byte aligned (null: none): that block first copies the launch's probabilities
+                         // there, sixteen bytes per lane -- the host then needs no copy launch behind the kernel (host -> host calls)
     int steal_test; // 0 in production; k > 0: role blocks with id % k == 1 leave WITHOUT claiming and consumers have no patience,
                     // so the items must be executed by the consumers that depend on them (tests; results stay correct)
 };
@@ -402,9 +404,30 @@ __global__ __launch_bounds__(256, 2) void k_small_pass(SmallParams P) {  // <= 2
     if (P.done && sh.ga.n > 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (threadIdx.x == 0 && add_ret(Y.done_cnt, sh.ga.n) + sh.ga.n == P.nchunks) {
-            put(Y.done_cnt, 0);
-            __hip_atomic_store(P.done, P.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (threadIdx.x == 0) {
+            const bool last = add_ret(Y.done_cnt, sh.ga.n) + sh.ga.n == P.nchunks;
+            if (last) put(Y.done_cnt, 0);
+            sh.woken = last ? 1 : 0;
+        }
+        __syncthreads();
+        if (sh.woken) {  // (block-uniform) this block completes the launch
+            if (P.host_probs != nullptr) {
+                // every probability of the launch is in memory (agent-scope stores, completed before their blocks' arrivals): hand them
+                // to the host with full-width stores -- 96 heads blocks writing 4-byte words over PCIe were slower than a copy launch
+                // (profiles/r03_completion_word.txt); one block writing 16 bytes per lane is not
+                const int n16 = (N * kNOut) / 4, tail = (N * kNOut) % 4;
+                const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(P.probs, 0, -1, 0x00020000);
+                u32x4* dst = reinterpret_cast<u32x4*>(P.host_probs);
+#pragma unroll 4
+                for (int i = (int)threadIdx.x; i < n16; i += 256) dst[i] = __builtin_amdgcn_raw_buffer_load_b128(rP, i * 16, 0, kAuxSc1);
+                if ((int)threadIdx.x < tail) {
+                    const int i = n16 * 4 + (int)threadIdx.x;
+                    P.host_probs[i] = __hip_atomic_load(P.probs + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the block's stores to the host have left before the word does
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) __hip_atomic_store(P.done, P.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
     SMALL_STAMP(3);
@@ -434,7 +457,7 @@ static void launch_small_t(const SmallParams& P, int shape, unsigned blocks, hip
 void launch_small_pass(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, bool resi, const Workspace& ws,
                        const DeviceWeights& w, float* fc1_out, float qn, float thr1, float thr2, float* d_probs, int nchunks,
                        int* d_sync, int epoch, unsigned* done, unsigned done_seq, hipStream_t s, bool pull, const unsigned* wait_rows,
-                       unsigned wait_seq, unsigned* gave_up) {
+                       unsigned wait_seq, unsigned* gave_up, float* host_probs) {
     // (the LDP front-end keeps the tile-stage launch for a COMPLETE page-locked picture: measured equal to slower in PULL form -- 1080p
     // 116 against 105 us per resident-state call, 2160p 313 against 317 -- its launch ends with FC1 and has no long tail to hide the
     // bus under.  Streamed input is another matter: the rows arrive at the caller's pace, and trunk + FC1 of the first rows run
@@ -447,6 +470,7 @@ void launch_small_pass(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int
     P.xm = ws.xm;
     P.xl = ws.xl;
     P.done = resi ? nullptr : done;  // (the LDP front-end is not the end of its call)
+    P.host_probs = (P.done != nullptr && reinterpret_cast<uintptr_t>(host_probs) % 16 == 0) ? host_probs : nullptr;
     P.done_seq = done_seq;
     P.src.luma = d_luma;
     P.src.width = g.width;
