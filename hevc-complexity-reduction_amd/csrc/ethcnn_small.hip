@@ -226,23 +226,31 @@ __device__ __forceinline__ void do_trunk_item(const SmallParams& P, const SmallS
         __syncthreads();
         if (!mine) return;
         grp = item < P.bS ? item >> 2 : (item < P.bS + P.bM ? item - P.bS : item - P.bS - P.bM);
-        if (!block_wait(Y.trunk_flag + item * kPad, P, sh, P.steal_test ? 1 : kPatience)) {
-            do_pull_item(P, Y, grp, smem, sh);
-            (void)block_wait(Y.trunk_flag + item * kPad, P, sh, 0);  // the group is claimed by a resident block now
-        }
-        SMALL_STAMP(1);
-        if (threadIdx.x == 0) sh->owned = 1;
-        __syncthreads();
+        // the wait sits INSIDE the trunk task, behind its weight staging (20 KB of fragments; LDP: + the division table): when the
+        // records land the task only has to load them
+        auto ready = [&]() -> bool {
+            bool lent = false;
+            // (patience: the last rows of a 2160p picture are 150 us away by design; a trunk item that gave up after 100 us pulled its
+            // group itself, out of turn, beside the 16 pull blocks -- correct, but not the order the transfer was laid out for)
+            if (!block_wait(Y.trunk_flag + item * kPad, P, sh, P.steal_test ? 1 : 5 * kPatience)) {
+                do_pull_item(P, Y, grp, smem, sh);  // (its 16-row slabs go through the block's LDS)
+                (void)block_wait(Y.trunk_flag + item * kPad, P, sh, 0);  // the group is claimed by a resident block now
+                lent = true;
+            }
+            SMALL_STAMP(1);
+            return lent;
+        };
         if (item < P.bS) {
             ntask = 4;
-            Trunk<0, RESI, false, true>::run(P.xs, P.ngroups * 16, item * 4 + wv, P.bS * 4, P.trunk_w, P.trunk_b, P.feat, P.n, smem);
+            Trunk<0, RESI, false, true>::run(P.xs, P.ngroups * 16, item * 4 + wv, P.bS * 4, P.trunk_w, P.trunk_b, P.feat, P.n, smem, nullptr, nullptr, 0, nullptr, 1.0f, ready);
         } else if (item < P.bS + P.bM) {
             ntask = 4;
-            Trunk<1, RESI, false, true>::run(P.xm, P.ngroups * 4, (item - P.bS) * 4 + wv, P.bM * 4, P.trunk_w, P.trunk_b, P.feat, P.n, smem);
+            Trunk<1, RESI, false, true>::run(P.xm, P.ngroups * 4, (item - P.bS) * 4 + wv, P.bM * 4, P.trunk_w, P.trunk_b, P.feat, P.n, smem, nullptr, nullptr, 0, nullptr, 1.0f, ready);
         } else {
             ntask = 1;  // (one task: wave 0's; the others help with the weight staging and leave)
-            Trunk<2, RESI, false, true>::run(P.xl, wv == 0 ? P.ngroups : 0, grp, P.bL, P.trunk_w, P.trunk_b, P.feat, P.n, smem);
+            Trunk<2, RESI, false, true>::run(P.xl, wv == 0 ? P.ngroups : 0, grp, P.bL, P.trunk_w, P.trunk_b, P.feat, P.n, smem, nullptr, nullptr, 0, nullptr, 1.0f, ready);
         }
+        if (threadIdx.x == 0) sh->owned = 1;  // (claimed above; a pull item tried inside the wait has used the word for its own claim)
     } else if (item < P.bS) {
         grp = item >> 2; ntask = 4;
         Trunk<0, RESI, true, true>::run(nullptr, P.ngroups * 16, item * 4 + wv, P.bS * 4, P.trunk_w, P.trunk_b, P.feat, P.n, smem, &P.src, claim, P.epoch, &sh->owned);

@@ -255,10 +255,15 @@ struct Trunk {
         return true;
     }
 
+    // ready (PULL form of the single-launch pass): called by every thread once the weights are staged and before the task's pixel
+    // records are loaded -- it waits until they exist.  Returns true when the block's LDS was lent out meanwhile (stage again).
+    struct NoWait { __device__ __forceinline__ bool operator()() const { return false; } };
+    template <class Ready = NoWait>
     static __device__ __forceinline__ void run(const uint4* __restrict__ X, int ntasks, int wave, int nwaves,
                                                const float* __restrict__ wfrag, const float* __restrict__ bfrag,
                                                float* __restrict__ F, int N, float* wl, const DirectSrc* src = nullptr,
-                                               int* claim = nullptr, int tag = 0, int* s_owned = nullptr, float fscale = 1.0f) {
+                                               int* claim = nullptr, int tag = 0, int* s_owned = nullptr, float fscale = 1.0f,
+                                               Ready ready = Ready()) {
         int lane = threadIdx.x & 63;
         // (single-launch forms inline this function into several roles: an opaque copy of the lane index keeps the compiler from
         // computing the lane geometry once at kernel entry and carrying it through all of them -- VGPRs the register-fed heads need)
@@ -292,13 +297,15 @@ struct Trunk {
         // conv2 / conv3 A-operand fragments of this branch -> LDS, once per block (80 of the 84
         // fragments; every MFMA fetches its A operand with one conflict-free ds_read_b32, which costs
         // the matrix pipe nothing, and frees 80 VGPRs: three waves per SIMD instead of two)
-        {
+        auto stage = [&]() {
             const float* wf = wfrag + (size_t)BR * kTrunkWFrags * 64;
             for (int i = threadIdx.x; i < kTrunkWFrags * 64; i += 256) wl[i] = wf[i];
             if (RESI)  // (same expression as px_value's callers used per value: the table IS those values)
                 for (int i = threadIdx.x; i < TAB; i += 256) wl[kTrunkResiTabAt + i] = px_value<true>(i, POOL * POOL) * (BR == 0 ? 1.0f : SCALE);
-        }
-        __syncthreads();
+            __syncthreads();
+        };
+        stage();
+        if (ready()) stage();  // (block-uniform answer)
         if (claim != nullptr && !*s_owned) return;  // (block-uniform)
         if (!active) return;
         const float* tab = wl + kTrunkResiTabAt;  // (resi only)
