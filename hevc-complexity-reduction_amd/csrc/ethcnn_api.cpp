@@ -1325,8 +1325,18 @@ static int predict_luma_latency(ethcnn_ctx* c, const uint8_t* luma, int w, int h
 // ---- ONE picture with streamed input (the in-process encoder hook converts HM's 16-bit picture to 8 bits row by row: the
 // conversion is as long as the prediction, and the prediction can run under it).  begin: the pass is queued on the page-locked
 // buffer and waits for its CTU rows (ethcnn_rows_ready); end: result copy + wait.  The pass is the one ethcnn_predict_luma runs.
+static int predict_luma_begin_impl(ethcnn_ctx* c, const uint8_t* luma, int w, int h, int qp, float* probs);
 extern "C" int ethcnn_predict_luma_begin(ethcnn_ctx* c, const uint8_t* luma, int w, int h, int qp, float* probs) {
     if (!c || !luma || !probs) return c ? set_err(c, ETHCNN_ERR_ARG, "null pointer") : ETHCNN_ERR_ARG;
+    const bool was_open = c->ai.open || c->ldp.open;
+    const unsigned seq = c->rows_seq;
+    const int rc = predict_luma_begin_impl(c, luma, w, h, qp, probs);
+    // a begin that fails consumes the picture's number all the same: rows already reported for it (ethcnn_rows_ready may run ahead of
+    // begin) must not count for the next streamed picture.  (Not when the failure is "another streamed call is open": that one's rows.)
+    if (rc != ETHCNN_OK && !was_open && c->rows_seq == seq && ++c->rows_seq == 0) c->rows_seq = 1;
+    return rc;
+}
+static int predict_luma_begin_impl(ethcnn_ctx* c, const uint8_t* luma, int w, int h, int qp, float* probs) {
     if (c->ai.open || c->ldp.open) return set_err(c, ETHCNN_ERR_ARG, "ethcnn_predict_luma_begin: a streamed call is still open on this context");
     FrameGeom g;
     int rc = make_geom(c, w, h, w, (ptrdiff_t)w * h, &g);
@@ -1815,7 +1825,13 @@ extern "C" int ethcnn_ldp_step(ethcnn_ctx* c, const uint8_t* luma, int w, int h,
 // ---- streamed input: begin (kernels queued, waiting for rows) | rows_ready (any thread, as the buffer fills) | end
 extern "C" int ethcnn_ldp_step_begin(ethcnn_ctx* c, const uint8_t* luma, int w, int h, ptrdiff_t pitch, int qp, int i_frame,
                                      const float* state_in, float* probs) {
-    return ldp_step_begin(c, luma, w, h, pitch, qp, i_frame, state_in, /*resident=*/!state_in && i_frame > 1, probs, true);
+    if (!c) return ETHCNN_ERR_ARG;
+    const bool was_open = c->ai.open || c->ldp.open;
+    const unsigned seq = c->rows_seq;
+    const int rc = ldp_step_begin(c, luma, w, h, pitch, qp, i_frame, state_in, /*resident=*/!state_in && i_frame > 1, probs, true);
+    // (a failed begin consumes the picture's number: see ethcnn_predict_luma_begin)
+    if (rc != ETHCNN_OK && !was_open && c->rows_seq == seq && ++c->rows_seq == 0) c->rows_seq = 1;
+    return rc;
 }
 
 extern "C" int ethcnn_rows_ready(ethcnn_ctx* c, int ctu_row_begin, int ctu_row_end) {

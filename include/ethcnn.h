@@ -103,9 +103,10 @@ int ethcnn_predict_luma(ethcnn_ctx* ctx, const uint8_t* luma, int width, int hei
  *                               ethcnn_rows_ready.
  *   ethcnn_rows_ready           "luma rows [64 ctu_row_begin, 64 ctu_row_end) are in the buffer" (the last CTU row may be short).
  *                               Any thread, any order, each CTU row once; also BEFORE the begin of the same picture, but not before
- *                               the previous streamed call on this context has ended.  Every CTU row [0, ceil(height / 64)) must be
- *                               reported: kernels that wait ~1 s for a row give up and the end call fails with ETHCNN_ERR_DEVICE
- *                               (the GPU is not left hanging).  Shared with ethcnn_ldp_step_begin below.
+ *                               the previous streamed call on this context has ended (a begin that FAILS consumes the picture: rows
+ *                               reported for it are forgotten, and no further row of it may be reported).  Every CTU row
+ *                               [0, ceil(height / 64)) must be reported: kernels that wait ~1 s for a row give up and the end call
+ *                               fails with ETHCNN_ERR_DEVICE (the GPU is not left hanging).  Shared with ethcnn_ldp_step_begin below.
  *   ethcnn_predict_luma_end     waits; probs (the pointer given to begin) are final when it returns ETHCNN_OK.
  * Results are bit-identical to ethcnn_predict_luma's. */
 int ethcnn_predict_luma_begin(ethcnn_ctx* ctx, const uint8_t* luma, int width, int height, int qp, float* probs);

@@ -230,6 +230,23 @@ def test_predict_luma_streamed_input(pkg, oracle):
         big = c.host_buffer(64 * 64 * 8192)
         with pytest.raises(e.EthCnnError):
             c.predict_luma_begin(big, 64 * 8192, 64, 30, np.zeros(8192 * 21, np.float32))  # 8192 CTUs: not one pass
+        # rows reported AHEAD of a begin that then fails are forgotten: the next streamed picture waits for its own rows
+        luma = rng.integers(0, 256, size=(1, h, w), dtype=np.uint8)
+        want = oracle.predict_frames(blob, luma, w, h, 1, 30, 0.6, 0.4, mode=0)
+        c.rows_ready(0, nrows)
+        with pytest.raises(e.EthCnnError):
+            c.predict_luma_begin(np.zeros(w * h, np.uint8), w, h, 30, pprobs)
+        pin[:] = 0
+        def late():
+            time.sleep(0.003)
+            pin[:] = luma.reshape(-1)
+            c.rows_ready(0, nrows)
+        t = threading.Thread(target=late)
+        t.start()
+        c.predict_luma_begin(pin, w, h, 30, pprobs)
+        t.join()
+        c.predict_luma_end()
+        assert np.array_equal(_bits(pprobs.reshape(-1, 21)), _bits(want.reshape(-1, 21)))
         c.predict_luma_begin(pin, w, h, 30, pprobs)
         with pytest.raises(e.EthCnnError):
             c.predict_luma_begin(pin, w, h, 30, pprobs)                          # still open

@@ -26,6 +26,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <pthread.h>
+
 #include "ethcnn.h"
 #if defined(__SSE2__)
 #include <emmintrin.h>
@@ -84,6 +86,92 @@ static void convert_row(const short* src, unsigned char* dst, int width, int shi
     }
 }
 
+/* ---- conversion helpers.  HM is single-threaded, and at 3840x2160 one thread needs 270 us for the plane (16.6 MB in, 8.3 MB out) while
+ * the bus needs 155 us for it: pictures of two million samples and more are converted by the caller and three persistent helper
+ * threads (ETHCNN_HM_THREADS, 1 = the caller alone), CTU rows drawn from a shared counter, each reported to the queued prediction
+ * as it is finished.  The helpers sleep on a condition variable between pictures. */
+#define HM_MAX_HELP 7
+static struct {
+    pthread_mutex_t mu;
+    pthread_cond_t go, done;
+    pthread_t th[HM_MAX_HELP];
+    int nhelp, started, gen, pending, quit;
+    const short* src;
+    unsigned char* dst;
+    int stride, width, height, shift, next, report;
+    ethcnn_ctx* ctx;
+} g_cv = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, {0}, -1, 0, 0, 0, 0, NULL, NULL, 0, 0, 0, 0, 0, 0, NULL};
+
+static void convert_ctu_rows(void) { /* until no CTU row is left */
+    const int nrows = (g_cv.height + 63) / 64;
+    for (;;) {
+        const int cy = __atomic_fetch_add(&g_cv.next, 1, __ATOMIC_RELAXED);
+        int y;
+        if (cy >= nrows) break;
+        for (y = cy * 64; y < g_cv.height && y < cy * 64 + 64; ++y)
+            convert_row(g_cv.src + (size_t)y * g_cv.stride, g_cv.dst + (size_t)y * g_cv.width, g_cv.width, g_cv.shift);
+        if (g_cv.report) (void)ethcnn_rows_ready(g_cv.ctx, cy, cy + 1);
+    }
+}
+static void* convert_helper(void* arg) {
+    int seen = 0;
+    (void)arg;
+    pthread_mutex_lock(&g_cv.mu);
+    for (;;) {
+        while (g_cv.gen == seen && !g_cv.quit) pthread_cond_wait(&g_cv.go, &g_cv.mu);
+        if (g_cv.quit) break;
+        seen = g_cv.gen;
+        pthread_mutex_unlock(&g_cv.mu);
+        convert_ctu_rows();
+        pthread_mutex_lock(&g_cv.mu);
+        if (--g_cv.pending == 0) pthread_cond_signal(&g_cv.done);
+    }
+    pthread_mutex_unlock(&g_cv.mu);
+    return NULL;
+}
+/* start: the helpers begin on the picture (big pictures only); finish: the caller converts rows too, then waits for them */
+static void convert_start(const short* src, int stride, unsigned char* dst, int width, int height, int shift, ethcnn_ctx* ctx, int report) {
+    pthread_mutex_lock(&g_cv.mu);
+    if (g_cv.nhelp < 0) {
+        const char* e = getenv("ETHCNN_HM_THREADS");
+        const int n = e ? atoi(e) : 4;
+        g_cv.nhelp = n < 1 ? 0 : (n - 1 > HM_MAX_HELP ? HM_MAX_HELP : n - 1);
+    }
+    g_cv.src = src; g_cv.stride = stride; g_cv.dst = dst; g_cv.width = width; g_cv.height = height; g_cv.shift = shift;
+    g_cv.ctx = ctx; g_cv.report = report;
+    __atomic_store_n(&g_cv.next, 0, __ATOMIC_RELAXED);
+    g_cv.pending = 0;
+    if (g_cv.nhelp > 0 && (size_t)width * (size_t)height >= 2000000u) {
+        if (!g_cv.started) {
+            int i;
+            g_cv.started = 1;
+            for (i = 0; i < g_cv.nhelp; ++i)
+                if (pthread_create(&g_cv.th[i], NULL, convert_helper, NULL) != 0) { g_cv.nhelp = i; break; } /* (fewer helpers) */
+        }
+        if (g_cv.nhelp > 0) {
+            g_cv.pending = g_cv.nhelp;
+            ++g_cv.gen;
+            pthread_cond_broadcast(&g_cv.go);
+        }
+    }
+    pthread_mutex_unlock(&g_cv.mu);
+}
+static void convert_finish(void) {
+    convert_ctu_rows();
+    pthread_mutex_lock(&g_cv.mu);
+    while (g_cv.pending > 0) pthread_cond_wait(&g_cv.done, &g_cv.mu);
+    pthread_mutex_unlock(&g_cv.mu);
+}
+static void convert_shutdown(void) {
+    int i, n;
+    pthread_mutex_lock(&g_cv.mu);
+    g_cv.quit = 1;
+    n = g_cv.started ? g_cv.nhelp : 0;
+    pthread_cond_broadcast(&g_cv.go);
+    pthread_mutex_unlock(&g_cv.mu);
+    for (i = 0; i < n; ++i) pthread_join(g_cv.th[i], NULL);
+}
+
 /* ---- per-picture entry (the real in-process hook) ------------------------------------------- */
 static ethcnn_ctx* g_ctx = NULL;
 static int g_qp = -1;
@@ -92,6 +180,7 @@ static size_t g_luma8_cap = 0;
 static long g_pictures = 0;
 
 static void close_predictor(void) {
+    convert_shutdown();
     if (g_ctx) {
         printf("ethcnn (in-process): %ld picture(s) predicted from the encoder's own luma buffers\n", g_pictures);
         ethcnn_destroy(g_ctx); /* frees the page-locked luma buffer with it */
@@ -108,7 +197,6 @@ static void close_predictor(void) {
 int ethcnn_hm_predict_picture(const short* luma, int stride, int width, int height, int bit_depth, int qp, float* probs) {
     const int shift = bit_depth > 8 ? bit_depth - 8 : 0;
     const size_t need = (size_t)width * (size_t)height;
-    int y;
     if (!luma || !probs || width <= 0 || height <= 0 || stride < width) return 1;
     if (!g_ctx || qp != g_qp) {
         if (g_ctx) {
@@ -138,13 +226,10 @@ int ethcnn_hm_predict_picture(const short* luma, int stride, int width, int heig
         int streamed;
         if (stream < 0) { const char* e = getenv("ETHCNN_HM_STREAM"); stream = !(e && atoi(e) == 0); }
         streamed = stream && ethcnn_predict_luma_begin(g_ctx, g_luma8, width, height, qp, probs) == ETHCNN_OK;  /* (geometries the
-            streamed entry refuses -- more than 8191 CTUs -- take the plain call below) */
-        for (y = 0; y < height; ++y) {
-            const short* src = luma + (size_t)y * stride;
-            unsigned char* dst = g_luma8 + (size_t)y * width;
-            convert_row(src, dst, width, shift);
-            if (streamed && ((y & 63) == 63 || y == height - 1)) (void)ethcnn_rows_ready(g_ctx, y >> 6, (y >> 6) + 1);
-        }
+            streamed entry refuses -- more than 8191 CTUs -- take the plain call below.  Begin comes BEFORE the first row is reported:
+            rows reported for a picture whose begin then fails would count for the next one) */
+        convert_start(luma, stride, g_luma8, width, height, shift, g_ctx, streamed);
+        convert_finish();
         if ((streamed ? ethcnn_predict_luma_end(g_ctx) : ethcnn_predict_luma(g_ctx, g_luma8, width, height, width, (ptrdiff_t)need, 1, qp, probs)) != ETHCNN_OK) {
             fprintf(stderr, "ethcnn (in-process): %s\n", ethcnn_last_error(g_ctx));
             return 1;
