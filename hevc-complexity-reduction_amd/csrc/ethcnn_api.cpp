@@ -1262,11 +1262,16 @@ static int predict_luma_latency(ethcnn_ctx* c, const uint8_t* luma, int w, int h
         c->host_probs = nullptr;
         direct = rc == 0 && c->host_probs_used;
         const unsigned seq = c->rows_seq;
-        for (int cy = 0; cy < g.ch; ++cy) {  // (also when the launch failed: whatever is queued must drain)
-            if (rc == 0)
+        const bool copy = rc == 0;  // (rows are reported also when the launch failed: whatever is queued must drain)
+        const std::function<int(int)> ctu_row = [&](int cy) -> int {
+            if (copy)
                 for (int y = cy * kCtu; y < std::min(h, cy * kCtu + kCtu); ++y) std::memcpy(c->h_in[0] + (size_t)y * w, luma + (size_t)y * pitch, (size_t)w);
             __atomic_store_n(c->h_rows + cy, seq, __ATOMIC_RELEASE);
-        }
+            return 0;
+        };
+        // (4 MB and more -- a 2160p plane is 150 us of single-threaded memcpy, as long as its transfer -- on the worker pool)
+        if (copy && plane >= (4u << 20)) (void)host_pool(c)->run(g.ch, ctu_row);
+        else for (int cy = 0; cy < g.ch; ++cy) (void)ctu_row(cy);
         if (++c->rows_seq == 0) c->rows_seq = 1;
     } else if (pull) {
         c->host_probs = dst;

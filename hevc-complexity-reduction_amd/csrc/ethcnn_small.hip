@@ -548,8 +548,10 @@ void launch_small_pass(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int
     // one block per group: the whole picture is 2 MiB, and a block's second group would wait for its first (84 against 87-92 us).
     // (scripts/ubench/small_probe.hip W H 0 1, profiles/r04_pull_timeline.txt)
     static const int npull_env = [] { const char* e = dev_env("ETHCNN_PULL_BLOCKS"); return e ? atoi(e) : 0; }();  // development knob
-    // (streamed input: one pull block per group -- each sleeps until the caller has reported its rows, so the caller sets the order)
-    P.npull = !pull ? 0 : (wait_rows ? P.ngroups : std::min(P.ngroups, npull_env > 0 ? npull_env : (P.ngroups <= 32 ? 32 : 16)));
+    // (streamed input: the same -- a caller that fills the buffer faster than the bus empties it, four converting threads at 2160p,
+    // would otherwise have every group's block on the bus at once: 413 -> 328 us per picture was all the helpers bought with one block
+    // per group; a pull block sleeps until the caller has reported the rows of the group it has reached)
+    P.npull = !pull ? 0 : std::min(P.ngroups, npull_env > 0 ? npull_env : (P.ngroups <= 32 ? 32 : 16));
     blocks += (unsigned)P.npull;
     if (resi) pull ? launch_small_t<true, true>(P, shape, blocks, s) : launch_small_t<true, false>(P, shape, blocks, s);
     else pull ? launch_small_t<false, true>(P, shape, blocks, s) : launch_small_t<false, false>(P, shape, blocks, s);
