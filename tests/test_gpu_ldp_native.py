@@ -65,6 +65,20 @@ def test_native_daemon_matches_the_python_daemon(tmp_path, w, h, frames):
     assert out["python"][2] == out["native"][2] == [str(frames), str(w), str(h)]
 
 
+def test_launcher_native_switch(tmp_path):
+    """`python resi_to_cu_depth_LDP.py --native` (the drop-in launcher's switch) serves the handshake with the C daemon: same answers as
+    the Python one."""
+    out = {}
+    for kind in ("python", "launcher-native"):
+        work = _workdir(str(tmp_path / kind))
+        d = _serve("python", work, 6, extra=("--native", "--quiet") if kind == "launcher-native" else ())
+        c = _client(work, 416, 240, 6)
+        d.wait(timeout=60)
+        assert c.returncode == 0 and d.returncode == 0, (kind, c.stderr[-500:], d.stderr.read()[-800:])
+        out[kind] = open(os.path.join(work, "digest.txt")).read()
+    assert out["python"] == out["launcher-native"] and len(out["python"].splitlines()) == 6
+
+
 def test_native_daemon_restart_and_stale_state(tmp_path):
     """A second daemon continues a sequence from state.dat (frames 4.. after a restart = the same digests as one daemon serving
     all of them); a sidecar left at "pending" stops it (exit 1, message with the recovery step) unless --accept-stale."""
