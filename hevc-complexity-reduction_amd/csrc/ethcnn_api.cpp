@@ -1266,6 +1266,9 @@ static int predict_luma_latency(ethcnn_ctx* c, const uint8_t* luma, int w, int h
         const std::function<int(int)> ctu_row = [&](int cy) -> int {
             if (copy)
                 for (int y = cy * kCtu; y < std::min(h, cy * kCtu + kCtu); ++y) std::memcpy(c->h_in[0] + (size_t)y * w, luma + (size_t)y * pitch, (size_t)w);
+#if defined(__SSE2__)
+            _mm_sfence();  // (memcpy may use non-temporal stores)
+#endif
             __atomic_store_n(c->h_rows + cy, seq, __ATOMIC_RELEASE);
             return 0;
         };
@@ -1843,6 +1846,9 @@ extern "C" int ethcnn_rows_ready(ethcnn_ctx* c, int ctu_row_begin, int ctu_row_e
     // (thread-safe: touches nothing but the row words; no error text -- another thread may be inside a call on this context)
     if (!c || !c->h_rows || ctu_row_begin < 0 || ctu_row_end > kStreamCtuRows || ctu_row_begin > ctu_row_end) return ETHCNN_ERR_ARG;
     const unsigned seq = __atomic_load_n(&c->rows_seq, __ATOMIC_RELAXED);
+#if defined(__SSE2__)
+    _mm_sfence();  // rows written with non-temporal stores (big memcpy calls, streaming converters) are not ordered by a release store alone
+#endif
     for (int cy = ctu_row_begin; cy < ctu_row_end; ++cy) __atomic_store_n(c->h_rows + cy, seq, __ATOMIC_RELEASE);
     return ETHCNN_OK;
 }

@@ -102,6 +102,7 @@ int ethcnn_predict_luma(ethcnn_ctx* ctx, const uint8_t* luma, int width, int hei
  *                               8192 CTUs.  Until ethcnn_predict_luma_end no other call may be made on this context except
  *                               ethcnn_rows_ready.
  *   ethcnn_rows_ready           "luma rows [64 ctu_row_begin, 64 ctu_row_end) are in the buffer" (the last CTU row may be short).
+ *                               (The call orders the caller's earlier stores, non-temporal ones included, before the report.)
  *                               Any thread, any order, each CTU row once; also BEFORE the begin of the same picture, but not before
  *                               the previous streamed call on this context has ended (a begin that FAILS consumes the picture: rows
  *                               reported for it are forgotten, and no further row of it may be reported).  Every CTU row
