@@ -26,6 +26,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with two extra o
 """
 import argparse
 import importlib
+import ctypes
 import json
 import os
 import sys
@@ -565,6 +566,33 @@ def single_picture_latency(ctx, QP):
             d_in.free()
             d_out.free()
             out[name] = row
+        # host memory -> host memory through ethcnn_predict_luma: what a caller with the picture in its own memory pays (round 4: the
+        # single-launch pass PULLS a page-locked picture over PCIe itself, a pageable one is staged under the queued launch, the
+        # launch's last block hands the probabilities back; profiles/r04_latency_host.txt)
+        import numpy as np
+        h2h = {"unit": "us per call (host luma -> host probabilities)"}
+        for name, w, h in (("1920x1080", 1920, 1080), ("3840x2160", 3840, 2160)):
+            luma = synth_luma(w, h, 1, 5)
+            nctu = ((w + 63) // 64) * ((h + 63) // 64)
+            pin = ctx.host_buffer(w * h)
+            pin[:] = luma.reshape(-1)
+            pout = ctx.host_buffer(nctu * 84).view(np.float32)
+            row = {}
+            for label, src in (("page_locked", pin.reshape(1, h, w)), ("pageable", luma)):
+                def call():
+                    if label == "page_locked":
+                        ctx._chk(ctx.lib.ethcnn_predict_luma(ctx.h, pin.ctypes.data, w, h, w, w * h, 1, QP, pout.ctypes.data_as(ctypes.POINTER(ctypes.c_float))))
+                    else:
+                        ctx.predict_luma(src, w, h, 1, QP)
+                for _ in range(20):
+                    call()
+                t0 = time.perf_counter()
+                for _ in range(100):
+                    call()
+                row[label] = (time.perf_counter() - t0) / 100 * 1e6
+            ctx.free_host_buffers()
+            h2h[name] = row
+        out["host_to_host"] = h2h
     except Exception as exc:  # a side measurement is never fatal
         out["error"] = str(exc)
     return out

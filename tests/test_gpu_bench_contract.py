@@ -101,3 +101,7 @@ def test_one_gpu_line_states_the_north_star_ratio_and_the_fast_plans():
         assert dtype_word in fp["dtype"] and fp["value"] > 0 and fp["roofline"]["peak"] == 2500.0
         assert fp["gate_pattern_equal"] is False or fp["max_abs_vs_exact"] <= 1e-4  # north star's tolerance
         assert fp["flips_vs_exact"] <= 2
+    # side measurement: one picture host -> host (the path the in-process hook and every caller with the picture in its own memory takes)
+    h2h = d["single_picture_latency"]["host_to_host"]
+    for name in ("1920x1080", "3840x2160"):
+        assert 20.0 < h2h[name]["page_locked"] < 2000.0 and 20.0 < h2h[name]["pageable"] < 4000.0, h2h
