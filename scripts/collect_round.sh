@@ -22,7 +22,7 @@ if [ -s gpurun_out/latency_mid_now.txt ]; then { grep "^#" profiles/${R}_latency
 [ -s gpurun_out/launch_plans.txt ] && cp gpurun_out/launch_plans.txt profiles/${R}_launch_plans.txt
 [ -s gpurun_out/dist_smoke.json ] && cp gpurun_out/dist_smoke.json profiles/${R}_dist_smoke_2ranks_1gpu.json
 [ -s gpurun_out/power_probe.txt ] && cp gpurun_out/power_probe.txt profiles/${R}_power_probe.txt
-if [ -s gpurun_out/ldp_handshake.txt ]; then { grep "^#" gpurun_out/ldp_handshake.txt; grep "^# native\|^# first form\|^#   \|^# Boxes" profiles/${R}_ldp_handshake.txt 2>/dev/null; grep -v "^#" gpurun_out/ldp_handshake.txt; } > /tmp/_hs.txt && cp /tmp/_hs.txt profiles/${R}_ldp_handshake.txt; fi
+if [ -s gpurun_out/ldp_handshake.txt ]; then { grep "^#" gpurun_out/ldp_handshake.txt; grep "^# native\|^# first form\|^#   \|^#    \|^# Boxes" profiles/${R}_ldp_handshake.txt 2>/dev/null; grep -v "^#" gpurun_out/ldp_handshake.txt; } > /tmp/_hs.txt && cp /tmp/_hs.txt profiles/${R}_ldp_handshake.txt; fi
 python - "$R" <<'PY'
 import csv, glob, collections, json, sys
 R = sys.argv[1]
