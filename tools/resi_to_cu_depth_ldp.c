@@ -329,6 +329,7 @@ int main(int argc, char** argv) {
         ethcnn_device_name(ctx, name, sizeof name);
         if (!quiet) { printf("predictor initialized on %s.\n", name); fflush(stdout); }
     }
+    { const int fd = open(".pred_end.sig.ethcnn", O_WRONLY | O_CREAT | O_TRUNC, 0644); if (fd >= 0) close(fd); } /* (see the ending signal below) */
     /* wake-up source: inotify on the working directory (falls back to a 50 us poll when it cannot be had) */
     int ifd = inotify_init1(IN_NONBLOCK);
     if (ifd >= 0 && inotify_add_watch(ifd, ".", IN_CREATE | IN_MOVED_TO | IN_CLOSE_WRITE) < 0) { close(ifd); ifd = -1; }
@@ -439,7 +440,13 @@ int main(int argc, char** argv) {
         }
         const double ts4 = now_s();
         if (write_cu_depth(probs, nctu * 21 * sizeof(float)) != 0) { fprintf(stderr, "resi_to_cu_depth_ldp: cannot write cu_depth.dat: %s\n", strerror(errno)); goto out; }
-        { const int fd = open("pred_end.sig", O_WRONLY | O_CREAT | O_TRUNC, 0644); if (fd < 0) { fprintf(stderr, "resi_to_cu_depth_ldp: cannot create pred_end.sig\n"); goto out; } close(fd); }
+        /* the ending signal: a second name for an empty file this daemon keeps (one link() instead of open + close; HM only ever
+         * fopen()s and removes it), created the ordinary way where that fails */
+        if (link(".pred_end.sig.ethcnn", "pred_end.sig") != 0) {
+            const int fd = open("pred_end.sig", O_WRONLY | O_CREAT | O_TRUNC, 0644);
+            if (fd < 0) { fprintf(stderr, "resi_to_cu_depth_ldp: cannot create pred_end.sig\n"); goto out; }
+            close(fd);
+        }
         const double ts5 = now_s();
         /* HM is encoding again from here; the state file is refreshed behind its back, as the protocol asks */
         if (ethcnn_ldp_get_state(ctx, state, nctu * 896) != ETHCNN_OK || write_atomic("state.dat", state, nctu * 896 * sizeof(float)) != 0) {
@@ -473,6 +480,7 @@ int main(int argc, char** argv) {
                 !streamed_frames ? "sidecar + ethcnn_ldp_step" : "sidecar + ethcnn_ldp_step_end", m[4], m[5], m[6]);
     }
 out:
+    unlink(".pred_end.sig.ethcnn");
     if (sig_pending) unlink("pred_start.sig"); /* an error exit in between: the request counts as taken, as with the reference's daemon */
     free(state);
     ethcnn_destroy(ctx); /* frees the page-locked buffers with the context */
