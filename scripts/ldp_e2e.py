@@ -4,7 +4,8 @@ oracle/_ref/hm_ldp/TAppEncoderLDP (HM-16.5_Test_LDP built unchanged by oracle/bu
 synthetic moving sequence while a predictor daemon answers its command.dat / pred_start.sig requests.
 
     ldp_e2e.py gpu    <outdir>   daemon = hevc-complexity-reduction_amd/resi_to_cu_depth_LDP.serve (MI355X)
-    ldp_e2e.py gpu-cli <outdir>  same, started as a separate process through the root launcher resi_to_cu_depth_LDP.py
+    ldp_e2e.py gpu-cli <outdir>  started as a separate process through the root launcher resi_to_cu_depth_LDP.py (default = C daemon)
+    ldp_e2e.py gpu-cli-python <outdir>  the launcher with --python (the Python daemon)
     ldp_e2e.py gpu-native <outdir>  the native daemon (tools/resi_to_cu_depth_ldp.c over the C ABI), a separate process
     ldp_e2e.py oracle <outdir>   daemon = the same protocol answered by the CPU oracle (test infrastructure)
 
@@ -105,9 +106,12 @@ def main():
         shutil.copy(GOLD + ext, os.path.join(work, "model_LDP_200000_qp32.dat" + ext))
     log = []
     cli = None
-    if mode == "gpu-cli":  # the daemon exactly as a user starts it: `python resi_to_cu_depth_LDP.py` in the encoder's directory
+    if mode in ("gpu-cli", "gpu-cli-python"):
+        # the daemon exactly as a user starts it: `python resi_to_cu_depth_LDP.py` in the encoder's directory (default: the launcher
+        # execs the C daemon when it is built; gpu-cli-python: `--python`, the Python daemon)
         os.symlink(os.path.join(ROOT, "resi_to_cu_depth_LDP.py"), os.path.join(work, "resi_to_cu_depth_LDP.py"))
-        cli = subprocess.Popen([sys.executable, "resi_to_cu_depth_LDP.py", "--max-frames", str(FRAMES - 1), "--idle-timeout", "300"],
+        cli = subprocess.Popen([sys.executable, "resi_to_cu_depth_LDP.py", "--max-frames", str(FRAMES - 1), "--idle-timeout", "300"]
+                               + (["--python"] if mode == "gpu-cli-python" else []),
                                cwd=work, env=dict(os.environ, ETHCNN_SYNTHETIC_SEED=str(SEED)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         th = threading.Thread(target=cli.wait, daemon=True)
     elif mode == "gpu-native":  # the C daemon over the ABI, started in the encoder's directory like the Python one
@@ -118,7 +122,7 @@ def main():
     else:
         th = threading.Thread(target=(gpu_daemon if mode == "gpu" else oracle_daemon), args=(work, FRAMES - 1, log), daemon=True)
     th.start()
-    time.sleep(6.0 if mode == "gpu-cli" else (3.0 if mode in ("gpu", "gpu-native") else 0.5))  # the reference's daemon is started by hand before the encoder, too
+    time.sleep(6.0 if mode.startswith("gpu-cli") else (3.0 if mode in ("gpu", "gpu-native") else 0.5))  # the reference's daemon is started by hand before the encoder, too
     exe = os.path.join(ROOT, "oracle", "_ref", "hm_ldp", "TAppEncoderLDP")
     t0 = time.time()
     r = subprocess.run([exe, "-c", os.path.join(ROOT, "scripts", "hm_ldp_test.cfg"), "-i", "seq.yuv", "-wdt", str(W), "-hgt", str(H),

@@ -36,7 +36,7 @@ def run(kind, base, w, h, frames, gap_us, qp=32):
         env = dict(os.environ, ETHCNN_SYNTHETIC_SEED=SEED)
         if kind == "python":
             os.symlink(os.path.join(ROOT, "resi_to_cu_depth_LDP.py"), os.path.join(work, "resi_to_cu_depth_LDP.py"))
-            cmd = [sys.executable, "resi_to_cu_depth_LDP.py", "--max-frames", str(frames), "--idle-timeout", "120"]
+            cmd = [sys.executable, "resi_to_cu_depth_LDP.py", "--python", "--max-frames", str(frames), "--idle-timeout", "120"]
         else:
             cmd = [os.path.join(BIN, "resi_to_cu_depth_ldp"), "--max-frames", str(frames), "--idle-timeout", "120", "--quiet", "--trace"]
             if kind == "native-nostream":  # A/B: read resi.yuv first, then predict (the round's first form of the daemon)

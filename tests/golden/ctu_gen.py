@@ -63,3 +63,24 @@ def make_ctus(seed, n, residual=False):
 def crc(ctus):
     import zlib
     return zlib.crc32(np.ascontiguousarray(ctus).tobytes())
+
+
+def make_frame(seed, w, h, residual=False, flat_from_ctu=None):
+    """-> uint8 luma [h, w]: the CTUs of make_ctus(seed, nctu) laid out in raster order, cropped to the frame.
+    flat_from_ctu = k: every CTU with raster index >= k is flat (value 128): after the 16x16 mean removal such CTUs are
+    all-zero inputs, so every one of them yields the same probabilities (used to steer the <=1024-CTU batch gates)."""
+    wc, hc = (w + 63) // 64, (h + 63) // 64
+    ctus = make_ctus(seed, wc * hc, residual=residual)
+    if flat_from_ctu is not None:
+        ctus[flat_from_ctu:] = 128
+    full = ctus.reshape(hc, wc, 64, 64).transpose(0, 2, 1, 3).reshape(hc * 64, wc * 64)
+    return np.ascontiguousarray(full[:h, :w])
+
+
+def yuv420_bytes(luma_frames):
+    """planar 4:2:0 file content for a list of luma planes (chroma = 128), as video_to_cu_depth.py:47-48 reads it"""
+    out = bytearray()
+    for y in luma_frames:
+        h, w = y.shape
+        out += y.tobytes() + bytes([128]) * (w * h // 2)
+    return bytes(out)

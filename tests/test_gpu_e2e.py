@@ -121,7 +121,7 @@ def test_low_delay_p_with_the_reference_encoder(tmp_path):
     identical bitstreams (real motion-compensated residuals, trained LSTM weights, 5 recurrent steps)."""
     _need(HM_LDP)
     res = {}
-    for mode in ("gpu", "gpu-cli", "gpu-native", "oracle"):
+    for mode in ("gpu", "gpu-cli", "gpu-cli-python", "gpu-native", "oracle"):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "ldp_e2e.py"), mode, str(tmp_path)],
                            capture_output=True, text=True, timeout=240)
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
@@ -129,7 +129,8 @@ def test_low_delay_p_with_the_reference_encoder(tmp_path):
     assert len(res["gpu"]["per_frame_crc"]) == 5
     assert res["gpu"]["per_frame_crc"] == res["oracle"]["per_frame_crc"]
     assert res["gpu"]["bitstream_md5"] == res["oracle"]["bitstream_md5"]
-    assert res["gpu-cli"]["bitstream_md5"] == res["oracle"]["bitstream_md5"]  # the daemon as a separate process (root launcher)
+    assert res["gpu-cli"]["bitstream_md5"] == res["oracle"]["bitstream_md5"]  # the daemon as a user starts it: root launcher, no flag = C daemon
+    assert res["gpu-cli-python"]["bitstream_md5"] == res["oracle"]["bitstream_md5"]  # the launcher's --python opt-out
     # the native daemon (tools/resi_to_cu_depth_ldp.c over the C ABI): same bitstream, same last-frame files as every other mode
     assert res["gpu-native"]["bitstream_md5"] == res["oracle"]["bitstream_md5"]
     for key in ("final_cu_depth_crc", "final_state_crc"):

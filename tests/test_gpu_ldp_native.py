@@ -31,6 +31,9 @@ def _serve(kind, work, frames, extra=()):
     if kind == "python":
         os.symlink(os.path.join(ROOT, "resi_to_cu_depth_LDP.py"), os.path.join(work, "resi_to_cu_depth_LDP.py"))
         cmd = [sys.executable, "resi_to_cu_depth_LDP.py", "--max-frames", str(frames), "--idle-timeout", "60"]
+        if not set(extra) & {"--native", "--default"}:
+            cmd.append("--python")  # the launcher's default is the C daemon (when built); the Python one is the opt-out
+        extra = [a for a in extra if a != "--default"]
     else:
         cmd = [os.path.join(BIN, "resi_to_cu_depth_ldp"), "--max-frames", str(frames), "--idle-timeout", "60", "--quiet"]
     d = subprocess.Popen(cmd + list(extra), cwd=work, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
@@ -66,17 +69,17 @@ def test_native_daemon_matches_the_python_daemon(tmp_path, w, h, frames):
 
 
 def test_launcher_native_switch(tmp_path):
-    """`python resi_to_cu_depth_LDP.py --native` (the drop-in launcher's switch) serves the handshake with the C daemon: same answers as
-    the Python one."""
+    """`python resi_to_cu_depth_LDP.py` (the drop-in launcher, no flag) serves the handshake with the C daemon -- so does --native;
+    --python keeps the Python daemon: same answers from all three."""
     out = {}
-    for kind in ("python", "launcher-native"):
+    for kind in ("python", "launcher-native", "launcher-default"):
         work = _workdir(str(tmp_path / kind))
-        d = _serve("python", work, 6, extra=("--native", "--quiet") if kind == "launcher-native" else ())
+        d = _serve("python", work, 6, extra={"python": (), "launcher-native": ("--native", "--quiet"), "launcher-default": ("--default", "--quiet")}[kind])
         c = _client(work, 416, 240, 6)
         d.wait(timeout=60)
         assert c.returncode == 0 and d.returncode == 0, (kind, c.stderr[-500:], d.stderr.read()[-800:])
         out[kind] = open(os.path.join(work, "digest.txt")).read()
-    assert out["python"] == out["launcher-native"] and len(out["python"].splitlines()) == 6
+    assert out["python"] == out["launcher-native"] == out["launcher-default"] and len(out["python"].splitlines()) == 6
 
 
 def test_native_daemon_restart_and_stale_state(tmp_path):
