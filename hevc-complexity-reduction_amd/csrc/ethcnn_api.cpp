@@ -882,7 +882,11 @@ static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, lo
     const float qn = (float)qp * (1.0f / 51.0f);  // net_CNN.py:106
     // Small passes (a frame or a few: the in-process encoder hook, the LDP-sized calls) stay on one stream: there is no FC1 of
     // a previous pass long enough to hide anything under, and the cross-stream event costs ~10 us of a 75 us call
-    const bool side_tile = c->overlap != 0 && n >= kPipelineMinCtus;
+    // Plan 3 (round 5): the CTU-load stage is folded into the trunk's S branch (k1_trunk_f16_fold) -- no tile launch, nothing for a
+    // side stream to run.  (Experiments build: ETHCNN_PLAN3_FOLD=0 keeps round 4's tile stage beside FC1 for the A/B.)
+    static const bool fold3_knob = [] { const char* e = dev_env("ETHCNN_PLAN3_FOLD"); return !e || std::atoi(e) != 0; }();
+    const bool fold3 = c->fc1_plan == 3 && fold3_knob && c->tile_wait_rows == nullptr;
+    const bool side_tile = c->overlap != 0 && n >= kPipelineMinCtus && !fold3;
     const int p = side_tile ? (int)(c->pass_idx++ & 1) : 0;
     const Workspace w = ws_view(c, p);
     hipStream_t s_tile = side_tile ? c->s_tile : c->stream;
@@ -930,7 +934,9 @@ static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, lo
         if (le_ != hipSuccess) return set_err(c, ETHCNN_ERR_DEVICE, "launch of the %s stage failed: %s", name, hipGetErrorString(le_)); \
     } while (0)
     // the tile stage also zeroes the pass's sync area (gate predicates, sub-batch arrival counters, tile completion counters of the fused launch)
-    if (fold) {  // no tile launch: only the pass's sync area is cleared (what the tile stage does on the way)
+    if (fold3) {
+        // (no tile launch; the folded trunk below clears the sync area itself)
+    } else if (fold) {  // no tile launch: only the pass's sync area is cleared (what the tile stage does on the way)
         HIPCHK(c, hipMemsetAsync(w.flags, 0, (size_t)sync_words(n, (int)nchunks) * sizeof(int), s_tile));
     } else {
         StageTimer t(c, ETHCNN_STAGE_TILE, n, s_tile);
@@ -946,7 +952,10 @@ static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, lo
     if (fast && (rc = ensure_fast_weights(c, fast)) != 0) return rc;
     { StageTimer t(c, ETHCNN_STAGE_TRUNK);
       if (fold) launch_trunk_direct(d_luma, g, ctu0, w, c->dw, n, c->stream);
-      else if (fast == 3) launch_trunk_f16(w, c->dw, n, c->stream);
+      else if (fold3) {
+          launch_trunk_f16_fold(d_luma, g, ctu0, n, w, c->dw, sync_words(n, (int)nchunks), c->stream);
+          launch_trunk_f16(w, c->dw, n, c->stream, /*ml_only=*/true);
+      } else if (fast == 3) launch_trunk_f16(w, c->dw, n, c->stream);
       else launch_trunk(w, c->dw, n, false, c->stream, fast); }
     LAUNCH_OK("trunk");
     if (side_tile) HIPCHK(c, hipEventRecord(c->e_trunk[p], c->stream));

@@ -40,7 +40,11 @@ void launch_trunk(const Workspace& ws, const DeviceWeights& w, int n, bool resi,
 // k1 with the CTU-load stage folded in (A/B form, experiments build: ethcnn_trunk.hip); needs small_pass_ok-style 16-byte alignment
 void launch_trunk_direct(const uint8_t* d_luma, const FrameGeom& g, long ctu0, const Workspace& ws, const DeviceWeights& w, int n, hipStream_t s);
 // k1, plan 3 (ethcnn_trunk_fast.hip): the same trunk with its convolutions on the 16-bit matrix pipe (fp16 x 2 splits) -> featb in plan 2's form
-void launch_trunk_f16(const Workspace& ws, const DeviceWeights& w, int n, hipStream_t s);
+void launch_trunk_f16(const Workspace& ws, const DeviceWeights& w, int n, hipStream_t s, bool ml_only = false);
+// plan 3 with the CTU-load stage folded in: S tasks straight from the luma frames + the XM / XL records of the M / L tasks
+// (which follow as launch_trunk_f16(..., ml_only = true)); clears the pass's n_flags sync words like launch_tile
+void launch_trunk_f16_fold(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, const Workspace& ws, const DeviceWeights& w, int n_flags,
+                           hipStream_t s);
 // k2: feat -> h1 (bias + leaky-ReLU fused); out may be ws.h1 or a caller buffer (resi vectors)
 void launch_fc1(const Workspace& ws, const DeviceWeights& w, int n, float* out, hipStream_t s);
 // k2, plans 1 / 2 (ethcnn_fc1_fast.hip): featb -> h1 on the 16-bit matrix pipe: six bf16 products per fp32 product (exact three-way

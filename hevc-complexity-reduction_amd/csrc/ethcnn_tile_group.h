@@ -66,6 +66,124 @@ __device__ __forceinline__ void tile_wait_rows(const TileWait& tw, long ctu0, in
     __syncthreads();
 }
 
+// ---- the pieces of a group's work, shared by tile_group (below) and by the plan-3 trunk that consumes the S records straight out
+// of LDS (ethcnn_trunk_fast.hip, k1_trunk_f16_fold).  `tile`: 16 * kSlabCtuPitch dwords of LDS = one 16-row slab of the group.
+#define ETHCNN_PXS(tile, c, Y, Xd) (tile)[(c) * kSlabCtuPitch + (Y) * kRowPitch + (Xd)]
+
+// loader role of a 256-thread block: lane -> (CTU c, 16-B segment), wave -> 4 of the slab's 16 rows: one wave instruction covers a
+// whole 1 KiB run of a frame row when the 16 CTUs are horizontally adjacent
+struct SlabLoader {
+    const uint8_t* lbase;  // first pixel of this thread's segment in row 0 of its CTU; null = all zero (beyond the pass / the frame)
+    int ly0, lx, lc, lseg, lrow0;
+    __device__ __forceinline__ void init(int t, const uint8_t* __restrict__ luma, int width, long frame_stride, int cw, int nctu, long ctu0,
+                                         int n_total, int n0) {
+        lc = (t >> 2) & 15; lseg = t & 3; lrow0 = (t >> 6) * 4;
+        lbase = nullptr; ly0 = 0; lx = 0;
+        const int n = n0 + lc;
+        if (n < n_total) {
+            const long gn = ctu0 + n;
+            const long f = gn / nctu;
+            const int rr = (int)(gn - f * nctu);
+            const int cy = rr / cw, cx = rr - cy * cw;
+            ly0 = cy * 64;
+            lx = cx * 64 + lseg * 16;
+            if (lx < width) lbase = luma + f * frame_stride + lx;
+        }
+    }
+    // the same with the pass's first CTU given as (frame f0, CTU r0 inside it): 32-bit arithmetic only (the folded trunk re-derives
+    // the geometry for every slab item it walks)
+    __device__ __forceinline__ void init32(int t, const uint8_t* __restrict__ luma, int width, long frame_stride, int cw, int nctu, int f0, int r0,
+                                           int n_total, int n0) {
+        lc = (t >> 2) & 15; lseg = t & 3; lrow0 = (t >> 6) * 4;
+        lbase = nullptr; ly0 = 0; lx = 0;
+        const int n = n0 + lc;
+        if (n < n_total) {
+            const unsigned q = (unsigned)(r0 + n), df = q / (unsigned)nctu, rr = q - df * (unsigned)nctu;
+            const unsigned cy = rr / (unsigned)cw, cx = rr - cy * (unsigned)cw;
+            ly0 = (int)cy * 64;
+            lx = (int)cx * 64 + lseg * 16;
+            if (lx < width) lbase = luma + (long)(f0 + (int)df) * frame_stride + lx;
+        }
+    }
+    // rows lrow0 .. lrow0 + 3 of slab s (zero beyond the frame: video_to_cu_depth.py:54-57)
+    template <bool FAST>
+    __device__ __forceinline__ void load(int s, uint4 (&v)[4], int width, int height, long pitch) const {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int y = ly0 + 16 * s + lrow0 + k;
+            uint4 r = make_uint4(0u, 0u, 0u, 0u);
+            if (lbase != nullptr && y < height) {
+                const uint8_t* p = lbase + (long)y * pitch;
+                if (FAST) {
+                    r = nt_load(reinterpret_cast<const uint4*>(p));
+                } else {
+                    uint32_t w4[4] = {0u, 0u, 0u, 0u};
+                    const int lim = min(16, width - lx);
+                    for (int i = 0; i < lim; ++i) w4[i >> 2] |= (uint32_t)p[i] << (8 * (i & 3));
+                    r = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                }
+            }
+            v[k] = r;
+        }
+    }
+    __device__ __forceinline__ void to_lds(uint32_t* tile, const uint4 (&v)[4]) const {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t* dst = &ETHCNN_PXS(tile, lc, lrow0 + k, lseg * 4);
+            dst[0] = v[k].x; dst[1] = v[k].y; dst[2] = v[k].z; dst[3] = v[k].w;
+        }
+    }
+};
+
+// XS record j of S unit (uy = the slab, ux) for lane (c, g): the 4 pixels of row g of the patches (q2 = j, q1 = 0..3)
+__device__ __forceinline__ uint4 slab_xs_record(const uint32_t* tile, int c, int g, int j, int ux) {
+    uint32_t d[4];
+#pragma unroll
+    for (int q1 = 0; q1 < 4; ++q1) d[q1] = ETHCNN_PXS(tile, c, 8 * (j >> 1) + 4 * (q1 >> 1) + g, 4 * ux + 2 * (j & 1) + (q1 & 1));
+    return make_uint4(d[0], d[1], d[2], d[3]);
+}
+// XM record j (j = 4 (s & 1) + jj for slab s) of M unit column ux: two patch rows of exact 2x2 sums
+__device__ __forceinline__ uint4 slab_xm_record(const uint32_t* tile, int c, int g, int j, int ux) {
+    uint32_t out[4];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const int dd = 2 * j + hh, q2 = dd >> 2, q1 = dd & 3;
+        const int Yl = 8 * (q1 >> 1) + 2 * g;                    // raw row of the pooled row inside the slab
+        const int Xp = 16 * ux + 8 * (q2 & 1) + 4 * (q1 & 1);    // pooled col of px 0
+        const uint32_t a0 = ETHCNN_PXS(tile, c, Yl, Xp >> 1), a1 = ETHCNN_PXS(tile, c, Yl, (Xp >> 1) + 1);
+        const uint32_t b0 = ETHCNN_PXS(tile, c, Yl + 1, Xp >> 1), b1 = ETHCNN_PXS(tile, c, Yl + 1, (Xp >> 1) + 1);
+        // exact 2x2 byte sums as masked v_dot4_u32_u8 pairs: 5 VALU per output dword instead of ~15 shifts / masks /
+        // adds -- the stage runs beside FC1, where every VALU instruction costs matrix-pipe issue time
+        const uint32_t s0 = __builtin_amdgcn_udot4(a0, 0x00000101u, __builtin_amdgcn_udot4(b0, 0x00000101u, 0u, false), false);
+        const uint32_t s1 = __builtin_amdgcn_udot4(a0, 0x01010000u, __builtin_amdgcn_udot4(b0, 0x01010000u, 0u, false), false);
+        const uint32_t s2 = __builtin_amdgcn_udot4(a1, 0x00000101u, __builtin_amdgcn_udot4(b1, 0x00000101u, 0u, false), false);
+        const uint32_t s3 = __builtin_amdgcn_udot4(a1, 0x01010000u, __builtin_amdgcn_udot4(b1, 0x01010000u, 0u, false), false);
+        out[2 * hh] = s0 | (s1 << 16);
+        out[2 * hh + 1] = s2 | (s3 << 16);
+    }
+    return make_uint4(out[0], out[1], out[2], out[3]);
+}
+// XL record j (j = 4 (s >> 1) + 2 m + (s & 1), m = 0, 1, for slab s): two patch rows of exact 4x4 sums
+__device__ __forceinline__ uint4 slab_xl_record(const uint32_t* tile, int c, int g, int j) {
+    uint32_t out[4];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const int dd = 2 * j + hh, q2 = dd >> 2, q1 = dd & 3;
+        const int Xp = 8 * (q2 & 1) + 4 * (q1 & 1);  // pooled col == dword col
+        uint32_t sacc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint32_t acc = 0;
+#pragma unroll
+            for (int ry = 0; ry < 4; ++ry) acc = __builtin_amdgcn_udot4(ETHCNN_PXS(tile, c, 4 * g + ry, Xp + i), 0x01010101u, acc, false);
+            sacc[i] = acc;
+        }
+        out[2 * hh] = sacc[0] | (sacc[1] << 16);
+        out[2 * hh + 1] = sacc[2] | (sacc[3] << 16);
+    }
+    return make_uint4(out[0], out[1], out[2], out[3]);
+}
+
 // One group.  `tile`: 16 * kSlabCtuPitch dwords of LDS.  FAST: rows are 16-byte aligned (width, pitch, frame stride, base).
 // SC1: the records are consumed INSIDE this launch (agent-scope stores; the caller completes them -- s_waitcnt vmcnt(0) --
 // before it signals); otherwise streaming stores for the next launch.  ALL: the four slabs' loads are requested at once
@@ -86,124 +204,44 @@ __device__ __forceinline__ void tile_group(uint32_t* tile, const uint8_t* __rest
         if (SC1) __builtin_amdgcn_raw_buffer_store_b128((u32x4_t){v.x, v.y, v.z, v.w}, r, (int)(idx * 16), 0, kAuxSc1);
         else nt_store(base + idx, v);
     };
-    const int n0 = grp * 16;
-
-    // loader role: lane -> (CTU c, 16-B segment), wave -> 4 of the slab's 16 rows: one wave instruction covers a whole
-    // 1 KiB run of a frame row when the 16 CTUs are horizontally adjacent
-    const int lc = (t >> 2) & 15, lseg = t & 3, lrow0 = (t >> 6) * 4;
-    const uint8_t* lbase = nullptr;  // first pixel of this thread's segment in row 0 of its CTU; null = all zero
-    int ly0 = 0, lx = 0;
-    {
-        const int n = n0 + lc;
-        if (n < n_total) {
-            const long gn = ctu0 + n;
-            const long f = gn / nctu;
-            const int rr = (int)(gn - f * nctu);
-            const int cy = rr / cw, cx = rr - cy * cw;
-            ly0 = cy * 64;
-            lx = cx * 64 + lseg * 16;
-            if (lx < width) lbase = luma + f * frame_stride + lx;
-        }
-    }
-    auto load_slab = [&](int s, uint4 (&v)[4]) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int y = ly0 + 16 * s + lrow0 + k;
-            uint4 r = make_uint4(0u, 0u, 0u, 0u);
-            if (lbase != nullptr && y < height) {
-                const uint8_t* p = lbase + (long)y * pitch;
-                if (FAST) {
-                    r = nt_load(reinterpret_cast<const uint4*>(p));
-                } else {
-                    uint32_t w4[4] = {0u, 0u, 0u, 0u};
-                    const int lim = min(16, width - lx);
-                    for (int i = 0; i < lim; ++i) w4[i >> 2] |= (uint32_t)p[i] << (8 * (i & 3));
-                    r = make_uint4(w4[0], w4[1], w4[2], w4[3]);
-                }
-            }
-            v[k] = r;
-        }
-    };
-#define PXS(c, Y, Xd) tile[(c) * kSlabCtuPitch + (Y) * kRowPitch + (Xd)]
+    SlabLoader L;
+    L.init(t, luma, width, frame_stride, cw, nctu, ctu0, n_total, grp * 16);
     uint4 pre[ALL ? 4 : 1][4];
-    load_slab(0, pre[0]);
+    L.template load<FAST>(0, pre[0], width, height, pitch);
     if (ALL) {
 #pragma unroll
-        for (int s = 1; s < 4; ++s) load_slab(s, pre[ALL ? s : 0]);
+        for (int s = 1; s < 4; ++s) L.template load<FAST>(s, pre[ALL ? s : 0], width, height, pitch);
     }
     constexpr int kSlabUnroll = ALL ? 4 : 1;  // (ALL: pre[s] must be a compile-time register choice)
 #pragma unroll kSlabUnroll
     for (int s = 0; s < 4; ++s) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            uint32_t* dst = &PXS(lc, lrow0 + k, lseg * 4);
-            const uint4 pv = pre[ALL ? s : 0][k];
-            dst[0] = pv.x; dst[1] = pv.y; dst[2] = pv.z; dst[3] = pv.w;
-        }
+        L.to_lds(tile, pre[ALL ? s : 0]);
         __syncthreads();
-        if (!ALL && s < 3) load_slab(s + 1, pre[0]);  // in flight while this slab is turned into records
+        if (!ALL && s < 3) L.template load<FAST>(s + 1, pre[0], width, height, pitch);  // in flight while this slab is turned into records
 
         // ---- XS: unit row uy = s: 4 units x 4 j x 64 lanes, 4 per thread; output index e + 1024 s (u = 4 s + ux)
 #pragma unroll
         for (int rep = 0; rep < 4; ++rep) {
             const int e = t + 256 * rep;
             const int lane = e & 63, j = (e >> 6) & 3, ux = e >> 8;
-            const int c = lane & 15, g = lane >> 4;
-            uint32_t d[4];
-#pragma unroll
-            for (int q1 = 0; q1 < 4; ++q1) d[q1] = PXS(c, 8 * (j >> 1) + 4 * (q1 >> 1) + g, 4 * ux + 2 * (j & 1) + (q1 & 1));
-            put_rec(XS, rS, (size_t)grp * 4096 + 1024 * s + e, make_uint4(d[0], d[1], d[2], d[3]));
+            put_rec(XS, rS, (size_t)grp * 4096 + 1024 * s + e, slab_xs_record(tile, lane & 15, lane >> 4, j, ux));
         }
         // ---- XM: units (uy = s >> 1, ux = 0, 1), j = 4 (s & 1) + jj: 2 x 4 x 64, 2 per thread
 #pragma unroll
         for (int rep = 0; rep < 2; ++rep) {
             const int e = t + 256 * rep;
             const int lane = e & 63, jj = (e >> 6) & 3, ux = e >> 8;
-            const int c = lane & 15, g = lane >> 4, j = 4 * (s & 1) + jj, unit = 2 * (s >> 1) + ux;
-            uint32_t out[4];
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const int dd = 2 * j + hh, q2 = dd >> 2, q1 = dd & 3;
-                const int Yl = 8 * (q1 >> 1) + 2 * g;                    // raw row of the pooled row inside the slab
-                const int Xp = 16 * ux + 8 * (q2 & 1) + 4 * (q1 & 1);    // pooled col of px 0
-                const uint32_t a0 = PXS(c, Yl, Xp >> 1), a1 = PXS(c, Yl, (Xp >> 1) + 1);
-                const uint32_t b0 = PXS(c, Yl + 1, Xp >> 1), b1 = PXS(c, Yl + 1, (Xp >> 1) + 1);
-                // exact 2x2 byte sums as masked v_dot4_u32_u8 pairs: 5 VALU per output dword instead of ~15 shifts / masks /
-                // adds -- the stage runs beside FC1, where every VALU instruction costs matrix-pipe issue time
-                const uint32_t s0 = __builtin_amdgcn_udot4(a0, 0x00000101u, __builtin_amdgcn_udot4(b0, 0x00000101u, 0u, false), false);
-                const uint32_t s1 = __builtin_amdgcn_udot4(a0, 0x01010000u, __builtin_amdgcn_udot4(b0, 0x01010000u, 0u, false), false);
-                const uint32_t s2 = __builtin_amdgcn_udot4(a1, 0x00000101u, __builtin_amdgcn_udot4(b1, 0x00000101u, 0u, false), false);
-                const uint32_t s3 = __builtin_amdgcn_udot4(a1, 0x01010000u, __builtin_amdgcn_udot4(b1, 0x01010000u, 0u, false), false);
-                out[2 * hh] = s0 | (s1 << 16);
-                out[2 * hh + 1] = s2 | (s3 << 16);
-            }
-            put_rec(XM, rM, (size_t)grp * 2048 + 512 * unit + 64 * j + lane, make_uint4(out[0], out[1], out[2], out[3]));
+            const int j = 4 * (s & 1) + jj, unit = 2 * (s >> 1) + ux;
+            put_rec(XM, rM, (size_t)grp * 2048 + 512 * unit + 64 * j + lane, slab_xm_record(tile, lane & 15, lane >> 4, j, ux));
         }
         // ---- XL: j = 4 (s >> 1) + 2 m + (s & 1): 2 x 64, threads 0..127
         if (t < 128) {
             const int lane = t & 63, m = t >> 6;
-            const int c = lane & 15, g = lane >> 4, j = 4 * (s >> 1) + 2 * m + (s & 1);
-            uint32_t out[4];
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const int dd = 2 * j + hh, q2 = dd >> 2, q1 = dd & 3;
-                const int Xp = 8 * (q2 & 1) + 4 * (q1 & 1);  // pooled col == dword col
-                uint32_t sacc[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    uint32_t acc = 0;
-#pragma unroll
-                    for (int ry = 0; ry < 4; ++ry) acc = __builtin_amdgcn_udot4(PXS(c, 4 * g + ry, Xp + i), 0x01010101u, acc, false);
-                    sacc[i] = acc;
-                }
-                out[2 * hh] = sacc[0] | (sacc[1] << 16);
-                out[2 * hh + 1] = sacc[2] | (sacc[3] << 16);
-            }
-            put_rec(XL, rL, (size_t)grp * 512 + 64 * j + lane, make_uint4(out[0], out[1], out[2], out[3]));
+            const int j = 4 * (s >> 1) + 2 * m + (s & 1);
+            put_rec(XL, rL, (size_t)grp * 512 + 64 * j + lane, slab_xl_record(tile, lane & 15, lane >> 4, j));
         }
         __syncthreads();  // the slab is consumed: the next one may overwrite it
     }
-#undef PXS
 }
 
 }  // namespace ethcnn

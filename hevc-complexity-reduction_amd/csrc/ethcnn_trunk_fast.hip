@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 
 #include "ethcnn_kernels.h"
+#include "ethcnn_tile_group.h"
 #include "ethcnn_trunk_task.h"
 
 namespace ethcnn {
@@ -59,52 +60,58 @@ __device__ __forceinline__ unsigned minus_1024(unsigned two_halves) {
 }
 __device__ __forceinline__ unsigned ints_to_halves(unsigned packed_u16) { return minus_1024(packed_u16 | 0x64006400u); }
 
+// One wave's view of branch BR: weights / constants in registers + LDS (setup, once per block), then task() per unit position.
 template <int BR>
-__device__ __forceinline__ void trunk16_run(const uint4* __restrict__ X, int ntasks, int wave, int nwaves, const uint16_t* __restrict__ wimg,
-                                            const float* __restrict__ cfrag, float C1, float U2, float U3, char* __restrict__ F, int N,
-                                            char* lds) {
+struct Trunk16 {
     using T0 = Trunk<BR, false>;
-    constexpr int POOL = T0::POOL, NB = T0::NB, NJ = T0::NJ;
-    constexpr float SCALE = T0::SCALE;
-    constexpr int FCH = 2 * 1024;  // plan 2's pair image: two pieces per chunk
-    const int lane = threadIdx.x & 63;
-    const int col = lane & 15, g = lane >> 4;
+    static constexpr int POOL = T0::POOL, NJ = T0::NJ;
+    static constexpr float SCALE = T0::SCALE;
+    static constexpr int FCH = 2 * 1024;  // plan 2's pair image: two pieces per chunk
 
-    // conv2 / conv3 A fragments -> LDS (20 KB), once per block
-    {
-        const uint4* src = reinterpret_cast<const uint4*>(wimg + kTrunk16Conv2At);
-        uint4* dst = reinterpret_cast<uint4*>(lds);
-        for (int i = threadIdx.x; i < 20 * 64; i += 256) dst[i] = src[i];
-    }
-    // conv1 A pieces (piece 0, piece 1, and both x 16 for the L branch's high digit) and the per-channel constants: registers
     h4 A1[4];
-#pragma unroll
-    for (int f = 0; f < 4; ++f) A1[f] = *reinterpret_cast<const h4*>(wimg + (f * 64 + lane) * 4);
     float m1[4], b1s[4], b2s[2][4], b3s[2][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        m1[r] = cfrag[(0 + r) * 64 + lane];
-        b1s[r] = cfrag[(4 + r) * 64 + lane];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            b2s[t][r] = cfrag[(8 + t * 4 + r) * 64 + lane];
-            b3s[t][r] = cfrag[(16 + t * 4 + r) * 64 + lane];
+    const char *a2_lds, *a3_lds;
+    int lane, col, g, lane_off, N;
+    float C1, U2, U3;
+    __amdgpu_buffer_rsrc_t rF;
+
+    // every thread of the 256-thread block; ends with a barrier (the fragments are in `lds`, 20 KB)
+    __device__ __forceinline__ void setup(const uint16_t* __restrict__ wimg, const float* __restrict__ cfrag, float c1, float u2, float u3,
+                                          char* __restrict__ F, int n, char* lds) {
+        lane = threadIdx.x & 63;
+        col = lane & 15;
+        g = lane >> 4;
+        N = n; C1 = c1; U2 = u2; U3 = u3;
+        // conv2 / conv3 A fragments -> LDS (20 KB), once per block
+        {
+            const uint4* src = reinterpret_cast<const uint4*>(wimg + kTrunk16Conv2At);
+            uint4* dst = reinterpret_cast<uint4*>(lds);
+            for (int i = threadIdx.x; i < 20 * 64; i += 256) dst[i] = src[i];
         }
-    }
-    __syncthreads();
-    if (wave >= ntasks) return;
-    const char* a2_lds = lds + lane * 16;           // conv2 fragment (t, s, p) at ((t * 2 + s) * 2 + p) KiB
-    const char* a3_lds = lds + 8 * 1024 + lane * 16;  // conv3 fragment (t, s, p) at ((t * 3 + s) * 2 + p) KiB
-
-    const int lane16 = lane * 16;
-    const int lane_off = (g >> 1) * FCH + (g & 1) * 512 + col * 16;  // [chunk][piece][k half][row][8 x 16 bit] (ethcnn_spec.h)
-    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(X), 0, -1, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rF = __builtin_amdgcn_make_buffer_rsrc(F, 0, -1, 0x00020000);
-    uint4 raw[NJ];
+        // conv1 A pieces (piece 0, piece 1, and both x 16 for the L branch's high digit) and the per-channel constants: registers
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) raw[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rX, lane16, (wave * NJ + j) * 1024, 0));
+        for (int f = 0; f < 4; ++f) A1[f] = *reinterpret_cast<const h4*>(wimg + (f * 64 + lane) * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            m1[r] = cfrag[(0 + r) * 64 + lane];
+            b1s[r] = cfrag[(4 + r) * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                b2s[t][r] = cfrag[(8 + t * 4 + r) * 64 + lane];
+                b3s[t][r] = cfrag[(16 + t * 4 + r) * 64 + lane];
+            }
+        }
+        __syncthreads();
+        a2_lds = lds + lane * 16;             // conv2 fragment (t, s, p) at ((t * 2 + s) * 2 + p) KiB
+        a3_lds = lds + 8 * 1024 + lane * 16;  // conv3 fragment (t, s, p) at ((t * 3 + s) * 2 + p) KiB
+        lane_off = (g >> 1) * FCH + (g & 1) * 512 + col * 16;  // [chunk][piece][k half][row][8 x 16 bit] (ethcnn_spec.h)
+        rF = __builtin_amdgcn_make_buffer_rsrc(F, 0, -1, 0x00020000);
+    }
 
-    for (int task = wave; task < ntasks; task += nwaves) {
+    // one task (unit position `task` of its group; `raw` = the lane's pixel record).  mid(): called once the record registers are
+    // dead -- the caller's prefetch of the next record lands in them, under the rest of the task.
+    template <class Mid>
+    __device__ __forceinline__ void task(uint4 (&raw)[NJ], int task, Mid mid) const {
         int T = T0::raw_sum(raw);
         T += __shfl_xor(T, 16);
         T += __shfl_xor(T, 32);
@@ -113,11 +120,7 @@ __device__ __forceinline__ void trunk16_run(const uint4* __restrict__ X, int nta
 #pragma unroll
         for (int r = 0; r < 4; ++r) hb[r] = fmaf(mean, m1[r], b1s[r]);  // S1 (b1 - mean sum(w))
 
-        int grp, by, bx;  // wave-uniform
-        if (BR == 0) { grp = task >> 4; by = (task >> 2) & 3; bx = task & 3; }
-        else if (BR == 1) { grp = task >> 2; by = (task >> 1) & 1; bx = task & 1; }
-        else { grp = task; by = 0; bx = 0; }
-        (void)by; (void)bx; (void)NB;
+        const int grp = (BR == 0) ? (task >> 4) : (BR == 1 ? (task >> 2) : task);  // wave-uniform
         const bool valid = grp * 16 + col < N;
         const int Tpos = (BR == 0) ? (task & 15) : (BR == 1 ? 16 + (task & 3) : 20);
         const int Fb = (grp >> 1) * (kFastChunks * FCH) + Tpos * 8 * FCH + (grp & 1) * 256;
@@ -180,12 +183,7 @@ __device__ __forceinline__ void trunk16_run(const uint4* __restrict__ X, int nta
 #pragma unroll
                 for (int r = 0; r < 4; ++r) a2f[q2][t][r] = lrelu1(fmaf(acc2[t][r], U2, b2s[t][r]));  // features, in plan 2's feature scale
         }
-        // the raw registers are dead now: the next task's record is fetched under the rest
-        if (task + nwaves < ntasks) {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-                raw[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rX, lane16, ((task + nwaves) * NJ + j) * 1024, 0));
-        }
+        mid();  // the raw registers are dead now: the next record is fetched under the rest
         // ---- the task's four register pairs (ethcnn_weights.cpp::fast_feature_k): split once -- stored for FC1 AND fed to conv3
         u32x4 phi[3], plo[3];
 #pragma unroll
@@ -238,6 +236,30 @@ __device__ __forceinline__ void trunk16_run(const uint4* __restrict__ X, int nta
             }
         }
     }
+};
+
+// records from the tile stage's buffers (XS / XM / XL): tasks wave, wave + nwaves, ...
+template <int BR>
+__device__ __forceinline__ void trunk16_run(const uint4* __restrict__ X, int ntasks, int wave, int nwaves, const uint16_t* __restrict__ wimg,
+                                            const float* __restrict__ cfrag, float C1, float U2, float U3, char* __restrict__ F, int N,
+                                            char* lds) {
+    Trunk16<BR> tk;
+    constexpr int NJ = Trunk16<BR>::NJ;
+    tk.setup(wimg, cfrag, C1, U2, U3, F, N, lds);
+    if (wave >= ntasks) return;
+    const int lane16 = tk.lane * 16;
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(X), 0, -1, 0x00020000);
+    uint4 raw[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) raw[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rX, lane16, (wave * NJ + j) * 1024, 0));
+    for (int task = wave; task < ntasks; task += nwaves)
+        tk.task(raw, task, [&]() {
+            if (task + nwaves < ntasks) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    raw[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rX, lane16, ((task + nwaves) * NJ + j) * 1024, 0));
+            }
+        });
 }
 
 __global__ __launch_bounds__(256) void k1_trunk_f16(const uint4* __restrict__ XS, const uint4* __restrict__ XM, const uint4* __restrict__ XL,
@@ -256,14 +278,96 @@ __global__ __launch_bounds__(256) void k1_trunk_f16(const uint4* __restrict__ XS
                        sc.C1[2], sc.U2[2], sc.U3[2], F, N, lds);
 }
 
-void launch_trunk_f16(const Workspace& ws, const DeviceWeights& w, int n, hipStream_t s) {
+// ---- plan 3 with the CTU-load stage FOLDED IN (round 5).  Under plan 3 a step moves ~4.6 GB through HBM (profiles/r04_pmc_c3.txt),
+// 1.36 GB of it the pixel records' round trip (k0_tile_slab writes 6,656 B per CTU, the trunk reads them back), and the tile stage
+// beside FC1 costs the 16-bit FC1 0.15 ms.  Here the S branch (16 of a group's 21 tasks, 4,096 of the 6,656 record bytes) takes its
+// records straight out of the LDS slab the loader role fills -- the same coalesced 1 KiB-per-wave-instruction frame reads and the
+// same exact integer record words as k0_tile_slab (ethcnn_tile_group.h) -- and the block writes only the slab's XM / XL records
+// (2,560 B per CTU) for the M / L tasks, which run as a second, small launch (k1_trunk_f16 with bS = 0).  No XS buffer, no tile
+// launch, no side stream.
+//   work item = one 16-row slab of one group (4 per group): load -> LDS -> barrier -> wave w reads the record of unit (uy = slab,
+//   ux = w), the block emits the slab's 2.5 KiB of XM / XL records -> barrier -> S task; the next item's pixels are requested at the
+//   task's mid point into the dead record registers.
+template <bool FAST>
+__global__ __launch_bounds__(256) void k1_trunk_f16_fold(const uint8_t* __restrict__ luma, int width, int height, long pitch, long frame_stride,
+                                                         int cw, int nctu, int f0, int r0, int N, uint4* __restrict__ XM, uint4* __restrict__ XL,
+                                                         int* __restrict__ gate_flags, int n_flags, const uint16_t* __restrict__ wimg,
+                                                         const float* __restrict__ cfrag, Trunk16Scalars sc, char* __restrict__ F) {
+    __shared__ __attribute__((aligned(16))) char lds[20 * 1024];
+    __shared__ uint32_t tile[16 * kSlabCtuPitch];
+    if (blockIdx.x == 0)  // (what the tile stage does on the way: the pass's sync area, read by the heads / gate launches behind us)
+        for (int i = threadIdx.x; i < n_flags; i += 256) gate_flags[i] = 0;
+    const int t = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    Trunk16<0> tk;
+    tk.setup(wimg, cfrag, sc.C1[0], sc.U2[0], sc.U3[0], F, N, lds);
+    const int nitems = ((N + 15) >> 4) * 4;
+    int it = blockIdx.x;
+    if (it >= nitems) return;
+    const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc(XM, 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rL = __builtin_amdgcn_make_buffer_rsrc(XL, 0, -1, 0x00020000);
+    SlabLoader L;
+    uint4 pre[4];
+    L.init32(t, luma, width, frame_stride, cw, nctu, f0, r0, N, (it >> 2) * 16);
+    L.template load<FAST>(it & 3, pre, width, height, pitch);
+#pragma unroll 1
+    for (; it < nitems; it += gridDim.x) {
+        const int grp = it >> 2, s = it & 3;
+        L.to_lds(tile, pre);
+        __syncthreads();
+        uint4 raw[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) raw[j] = slab_xs_record(tile, tk.col, tk.g, j, w);
+        // the slab's XM / XL records (same index arithmetic as tile_group): 512 + 128 uint4, 2.5 per thread
+#pragma unroll
+        for (int rep = 0; rep < 2; ++rep) {
+            const int e = t + 256 * rep;
+            const int lane = e & 63, jj = (e >> 6) & 3, ux = e >> 8;
+            const int j = 4 * (s & 1) + jj, unit = 2 * (s >> 1) + ux;
+            const uint4 v = slab_xm_record(tile, lane & 15, lane >> 4, j, ux);
+            // (whole offset in the VGPR, soffset = 0: see the store-hazard remark in ethcnn_trunk_task.h)
+            __builtin_amdgcn_raw_buffer_store_b128((u32x4_t){v.x, v.y, v.z, v.w}, rM, (grp * 2048 + 512 * unit + 64 * j + lane) * 16, 0, 0);
+        }
+        if (t < 128) {
+            const int lane = t & 63, m = t >> 6;
+            const int j = 4 * (s >> 1) + 2 * m + (s & 1);
+            const uint4 v = slab_xl_record(tile, lane & 15, lane >> 4, j);
+            __builtin_amdgcn_raw_buffer_store_b128((u32x4_t){v.x, v.y, v.z, v.w}, rL, (grp * 512 + 64 * j + lane) * 16, 0, 0);
+        }
+        __syncthreads();  // the slab is consumed: the next item may overwrite it
+        tk.task(raw, grp * 16 + 4 * s + w, [&]() {
+            const int nx = it + (int)gridDim.x;
+            if (nx < nitems) {
+                L.init32(t, luma, width, frame_stride, cw, nctu, f0, r0, N, (nx >> 2) * 16);
+                L.template load<FAST>(nx & 3, pre, width, height, pitch);
+            }
+        });
+    }
+}
+
+void launch_trunk_f16(const Workspace& ws, const DeviceWeights& w, int n, hipStream_t s, bool ml_only) {
     // tasks per group: 16 S, 4 M, 1 L; blocks per CU by registers (see the resource remark of the build); same branch shares as k1_trunk
     const int groups = (n + 15) / 16, tS = groups * 16, tM = groups * 4, tL = groups;
     auto blocks = [](int tasks, int budget) { int b = (tasks + 3) / 4; return b < budget ? b : budget; };
     constexpr int per_cu = 4;
-    const int bS = blocks(tS, 193 * per_cu), bM = blocks(tM, 50 * per_cu), bL = blocks(tL, 13 * per_cu);
+    // ml_only (the S branch ran in k1_trunk_f16_fold): the whole grid to the M / L tasks, 4 : 1
+    const int bS = ml_only ? 0 : blocks(tS, 193 * per_cu), bM = blocks(tM, (ml_only ? 205 : 50) * per_cu), bL = blocks(tL, (ml_only ? 51 : 13) * per_cu);
     hipLaunchKernelGGL(k1_trunk_f16, dim3(bS + bM + bL), dim3(256), 0, s, ws.xs, ws.xm, ws.xl, n, bS, bM, w.trunk16_w, w.trunk16_c, w.trunk16_s,
                        reinterpret_cast<char*>(ws.featb));
+}
+
+void launch_trunk_f16_fold(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, const Workspace& ws, const DeviceWeights& w, int n_flags,
+                           hipStream_t s) {
+    const int items = ((n + 15) / 16) * 4;
+    const int blocks = items < 768 ? items : 768;  // 3 per CU (registers), persistent over the slab items
+    const bool fast = (g.width % 16 == 0) && (g.pitch % 16 == 0) && (g.frame_stride % 16 == 0) && (reinterpret_cast<uintptr_t>(d_luma) % 16 == 0);
+    const int f0 = (int)(ctu0 / g.nctu), r0 = (int)(ctu0 % g.nctu);  // first frame of the pass / first CTU inside it: 32-bit geometry in the kernel
+    if (fast)
+        hipLaunchKernelGGL(k1_trunk_f16_fold<true>, dim3(blocks), dim3(256), 0, s, d_luma, g.width, g.height, g.pitch, g.frame_stride, g.cw, g.nctu,
+                           f0, r0, n, ws.xm, ws.xl, ws.flags, n_flags, w.trunk16_w, w.trunk16_c, w.trunk16_s, reinterpret_cast<char*>(ws.featb));
+    else
+        hipLaunchKernelGGL(k1_trunk_f16_fold<false>, dim3(blocks), dim3(256), 0, s, d_luma, g.width, g.height, g.pitch, g.frame_stride, g.cw, g.nctu,
+                           f0, r0, n, ws.xm, ws.xl, ws.flags, n_flags, w.trunk16_w, w.trunk16_c, w.trunk16_s, reinterpret_cast<char*>(ws.featb));
 }
 
 }  // namespace ethcnn
