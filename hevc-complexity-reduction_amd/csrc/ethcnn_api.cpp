@@ -200,6 +200,7 @@ struct ethcnn_ctx {
                              // 16-bit matrix pipe with split operands, bf16 x 3 / fp16 x 2 (ethcnn_fc1_fast.hip; ethcnn_set_fc1_plan, env ETHCNN_FC1_PLAN)
     uint16_t* dw_fast[2] = {nullptr, nullptr};  // W1 in the form of plan 1 / 2 (packed on first use), 7.2 / 4.8 MB
     uint16_t* dw_trunk16 = nullptr;             // plan 3: the trunk's A operands as fp16 x 2 pieces + its per-lane constants (one allocation)
+    uint16_t* dw_heads16 = nullptr;             // plan 3: FC2 / FC3 A operands as fp16 x 2 pieces (kHeads16Halves)
     int last_fast = 0;       // the FC1 plan of the last pass (debug_fetch reads the features of plans 1 / 2 from ws.featb)
     int fused = 0;           // 1 = big passes run FC1 + heads + gates as ONE launch (ethcnn_set_fused_launch, env ETHCNN_FUSED=1).
                              // Off by default: measured equal-to-1 % slower than the separate launches
@@ -212,6 +213,7 @@ struct ethcnn_ctx {
     unsigned* h_rows = nullptr;
     unsigned rows_seq = 1;
     const unsigned* tile_wait_rows = nullptr;  // set around the tile launch of a streamed step
+    int stream_stage_reruns = 0;               // passes of predict_luma_latency repeated because their streamed staging copy came > 1 s late
     float* host_probs = nullptr;               // set around a host -> host single-launch pass: page-locked destination its last block copies the
                                                // probabilities to (then no copy launch behind the kernel: the caller waits on the completion word)
     bool host_probs_used = false;              // ... and whether the pass took it (single-launch form, completion word armed)
@@ -488,6 +490,7 @@ extern "C" void ethcnn_destroy(ethcnn_ctx* c) {
     for (uint16_t* q : c->dw_fast)
         if (q) (void)hipFree(q);
     if (c->dw_trunk16) (void)hipFree(c->dw_trunk16);
+    if (c->dw_heads16) (void)hipFree(c->dw_heads16);
     {
         void* lp[] = {c->d_lstm, c->d_vec, c->d_state[0], c->d_state[1], c->d_lprobs, c->d_lgate, c->d_ssync};
         for (void* p : lp)
@@ -567,6 +570,7 @@ static int upload_weights(ethcnn_ctx* c) {
     }
     d.fc1_fast[0] = d.fc1_fast[1] = nullptr;  // the fast plans' images of W1 belong to the previous weights: repacked on the next such pass
     d.trunk16_w = nullptr;
+    d.heads16_w = nullptr;
     d.trunk16_c = nullptr;
     c->have_weights = true;
     return ETHCNN_OK;
@@ -587,6 +591,14 @@ static int ensure_fast_weights(ethcnn_ctx* c, int plan) {
         HIPCHK(c, hipMemcpy(reinterpret_cast<char*>(c->dw_trunk16) + wbytes, cimg.data(), cbytes, hipMemcpyHostToDevice));
         c->dw.trunk16_w = c->dw_trunk16;
         c->dw.trunk16_c = reinterpret_cast<float*>(reinterpret_cast<char*>(c->dw_trunk16) + wbytes);
+        // ... and the heads' FC2 / FC3 (ethcnn_heads_fast.hip): scales from guaranteed bounds; degenerate weights (a zero / non-finite
+        // bound) keep the exact heads
+        std::vector<uint16_t> himg((size_t)kHeads16Halves);
+        if (pack_heads_f16(c->blob.data(), fast_feature_bound(c->blob.data()), himg.data(), &c->dw.heads16_s)) {
+            if (!c->dw_heads16) HIPCHK(c, hipMalloc((void**)&c->dw_heads16, (size_t)kHeads16Halves * 2));
+            HIPCHK(c, hipMemcpy(c->dw_heads16, himg.data(), (size_t)kHeads16Halves * 2, hipMemcpyHostToDevice));
+            c->dw.heads16_w = c->dw_heads16;
+        }
         return 0;
     }
     if (c->dw.fc1_fast[plan - 1]) return 0;
@@ -884,8 +896,9 @@ static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, lo
     // a previous pass long enough to hide anything under, and the cross-stream event costs ~10 us of a 75 us call
     // Plan 3 (round 5): the CTU-load stage is folded into the trunk's S branch (k1_trunk_f16_fold) -- no tile launch, nothing for a
     // side stream to run.  (Experiments build: ETHCNN_PLAN3_FOLD=0 keeps round 4's tile stage beside FC1 for the A/B.)
-    static const bool fold3_knob = [] { const char* e = dev_env("ETHCNN_PLAN3_FOLD"); return !e || std::atoi(e) != 0; }();
-    const bool fold3 = c->fc1_plan == 3 && fold3_knob && c->tile_wait_rows == nullptr;
+    // 2 (default): the whole trunk behind one pass over the frames (k1_trunk_f16_foldall); 1: S branch folded, M / L as a second launch
+    static const int fold3_knob = [] { const char* e = dev_env("ETHCNN_PLAN3_FOLD"); return e ? std::atoi(e) : 2; }();
+    const bool fold3 = c->fc1_plan == 3 && fold3_knob != 0 && c->tile_wait_rows == nullptr;
     const bool side_tile = c->overlap != 0 && n >= kPipelineMinCtus && !fold3;
     const int p = side_tile ? (int)(c->pass_idx++ & 1) : 0;
     const Workspace w = ws_view(c, p);
@@ -952,9 +965,12 @@ static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, lo
     if (fast && (rc = ensure_fast_weights(c, fast)) != 0) return rc;
     { StageTimer t(c, ETHCNN_STAGE_TRUNK);
       if (fold) launch_trunk_direct(d_luma, g, ctu0, w, c->dw, n, c->stream);
-      else if (fold3) {
+      else if (fold3 && fold3_knob == 1) {
           launch_trunk_f16_fold(d_luma, g, ctu0, n, w, c->dw, sync_words(n, (int)nchunks), c->stream);
           launch_trunk_f16(w, c->dw, n, c->stream, /*ml_only=*/true);
+      } else if (fold3) {
+          static const int bpc = [] { const char* e = dev_env("ETHCNN_PLAN3_FOLD_BLOCKS"); return e ? std::atoi(e) : 2; }();
+          launch_trunk_f16_foldall(d_luma, g, ctu0, n, w, c->dw, sync_words(n, (int)nchunks), c->stream, bpc);
       } else if (fast == 3) launch_trunk_f16(w, c->dw, n, c->stream);
       else launch_trunk(w, c->dw, n, false, c->stream, fast); }
     LAUNCH_OK("trunk");
@@ -965,7 +981,12 @@ static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, lo
         { StageTimer t(c, ETHCNN_STAGE_FC1, n); launch_fc1_fast(w, c->dw, n, w.h1, fast == 3 ? 2 : fast, c->stream, c->cus); }
         LAUNCH_OK("FC1 (plan 1 / 2)");
         if (side_tile && c->tile_after_fc1) HIPCHK(c, hipEventRecord(c->e_fc1[p], c->stream));
-        { StageTimer t(c, ETHCNN_STAGE_HEADS); launch_heads(wv, c->dw, n, qn, g.nctu, ctu0, c->thr1, c->thr2, d_probs_pass, c->stream, c->gate_fold ? (int)nchunks : 0); }
+        // plan 3: the heads on the 16-bit pipe as well (experiments build: ETHCNN_PLAN3_HEADS=0 keeps the exact heads for the A/B)
+        static const bool heads16_knob = [] { const char* e = dev_env("ETHCNN_PLAN3_HEADS"); return !e || std::atoi(e) != 0; }();
+        { StageTimer t(c, ETHCNN_STAGE_HEADS);
+          if (fast == 3 && heads16_knob && c->dw.heads16_w)
+              launch_heads_f16(wv, c->dw, n, qn, g.nctu, ctu0, c->thr1, c->thr2, d_probs_pass, c->stream, c->gate_fold ? (int)nchunks : 0);
+          else launch_heads(wv, c->dw, n, qn, g.nctu, ctu0, c->thr1, c->thr2, d_probs_pass, c->stream, c->gate_fold ? (int)nchunks : 0); }
         if (!c->gate_fold) { StageTimer t(c, ETHCNN_STAGE_GATE); launch_gate(w, n, g.nctu, ctu0, c->thr2, d_probs_pass, c->stream); }
         LAUNCH_OK("heads / gate");
     } else if (c->fused && fc1_heads_fusable(n)) {
@@ -1258,6 +1279,7 @@ static int predict_luma_latency(ethcnn_ctx* c, const uint8_t* luma, int w, int h
     // word -- no copy launch behind the kernel)
     float* const dst = in_pinned(c, probs, out_bytes) ? probs : c->h_out[0];
     bool direct = false;
+    unsigned streamed_seq = 0;  // != 0: the pass was queued on a staging buffer that was still being filled (checked after the wait below)
     if (stream_stage) {
         rc = ensure_workspace(c, g.nctu, chunks_per_frame(g.nctu));  // (whatever may wait for the stream: before the waiting kernels are queued)
         if (rc) return rc;
@@ -1271,6 +1293,10 @@ static int predict_luma_latency(ethcnn_ctx* c, const uint8_t* luma, int w, int h
         c->host_probs = nullptr;
         direct = rc == 0 && c->host_probs_used;
         const unsigned seq = c->rows_seq;
+        {   // experiments build only: hold this thread between the launch and the copy (tests/test_gpu_small.py: the give-up path)
+            static const int stall_ms = [] { const char* e = dev_env("ETHCNN_TEST_STAGE_STALL_MS"); return e ? std::atoi(e) : 0; }();
+            if (stall_ms > 0) std::this_thread::sleep_for(std::chrono::milliseconds(stall_ms));
+        }
         const bool copy = rc == 0;  // (rows are reported also when the launch failed: whatever is queued must drain)
         const std::function<int(int)> ctu_row = [&](int cy) -> int {
             if (copy)
@@ -1284,6 +1310,7 @@ static int predict_luma_latency(ethcnn_ctx* c, const uint8_t* luma, int w, int h
         // (4 MB and more -- a 2160p plane is 150 us of single-threaded memcpy, as long as its transfer -- on the worker pool)
         if (copy && plane >= (4u << 20)) (void)host_pool(c)->run(g.ch, ctu_row);
         else for (int cy = 0; cy < g.ch; ++cy) (void)ctu_row(cy);
+        streamed_seq = seq;
         if (++c->rows_seq == 0) c->rows_seq = 1;
     } else if (pull) {
         c->host_probs = dst;
@@ -1334,6 +1361,28 @@ static int predict_luma_latency(ethcnn_ctx* c, const uint8_t* luma, int w, int h
         c->done_armed = 0;
         HIPCHK(c, hipMemcpyAsync(dst, c->d_out[0], out_bytes, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    if (streamed_seq && __atomic_load_n(c->h_done + 1, __ATOMIC_ACQUIRE) == streamed_seq) {
+        // The pass was queued before the staging copy and its tile blocks gave up waiting for rows (this thread was stopped for more
+        // than ~1 s between the launch and the copy: SIGSTOP / ptrace, a VM pause, a swap storm on the pageable source) -- they then
+        // computed on whatever the staging buffer held.  ethcnn_predict_luma_end / ethcnn_ldp_step_end report this as an error because
+        // the CALLER owns the fill there; here the fill is ours and the staging buffer is complete by now: run the pass again on it,
+        // not streamed (a silently wrong ETHCNN_OK otherwise).
+        c->host_probs = dst;
+        c->host_probs_used = false;
+        c->luma_over_pcie = true;
+        rc = run_pass(c, c->h_in[0], g, 0, g.nctu, qp, c->d_out[0]);
+        c->luma_over_pcie = false;
+        c->host_probs = nullptr;
+        if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
+        if (c->host_probs_used) {
+            HIPCHK(c, stream_sync(c));
+        } else {
+            c->done_armed = 0;
+            HIPCHK(c, hipMemcpyAsync(dst, c->d_out[0], out_bytes, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+        ++c->stream_stage_reruns;
     }
     if (dst != probs) std::memcpy(probs, dst, out_bytes);
     return ETHCNN_OK;

@@ -45,6 +45,9 @@ void launch_trunk_f16(const Workspace& ws, const DeviceWeights& w, int n, hipStr
 // (which follow as launch_trunk_f16(..., ml_only = true)); clears the pass's n_flags sync words like launch_tile
 void launch_trunk_f16_fold(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, const Workspace& ws, const DeviceWeights& w, int n_flags,
                            hipStream_t s);
+// the whole plan-3 trunk behind one pass over the frames (S, M and L tasks of a group in one block; no pixel records in HBM at all)
+void launch_trunk_f16_foldall(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, const Workspace& ws, const DeviceWeights& w, int n_flags,
+                              hipStream_t s, int blocks_per_cu = 2);
 // k2: feat -> h1 (bias + leaky-ReLU fused); out may be ws.h1 or a caller buffer (resi vectors)
 void launch_fc1(const Workspace& ws, const DeviceWeights& w, int n, float* out, hipStream_t s);
 // k2, plans 1 / 2 (ethcnn_fc1_fast.hip): featb -> h1 on the 16-bit matrix pipe: six bf16 products per fp32 product (exact three-way
@@ -56,6 +59,9 @@ void launch_fc1_fast(const Workspace& ws, const DeviceWeights& w, int n, float* 
 // entry); 0: probs are left ungated for launch_gate
 void launch_heads(const Workspace& ws, const DeviceWeights& w, int n, float qn, int nctu_per_frame,
                   long ctu0, float thr1, float thr2, float* d_probs, hipStream_t s, int gate_nchunks = 0);
+// the same heads on the 16-bit matrix pipe (plan 3; ethcnn_heads_fast.hip): fp16 x 2 splits of h1 / h2 and of W2 / W3 (w.heads16_w)
+void launch_heads_f16(const Workspace& ws, const DeviceWeights& w, int n, float qn, int nctu_per_frame, long ctu0, float thr1, float thr2,
+                      float* d_probs, hipStream_t s, int gate_nchunks = 0);
 // FC1 + heads + gates of a big pass as ONE launch (ethcnn_fused.hip): the heads blocks are appended to FC1's grid and wait on
 // per-M-tile completion counters; the last heads block applies the gates.  ws.flags = the pass's sync area
 // [2 * nchunks gate predicates][nchunks sub-batch arrival counters][tile counters], sync_words(n, nchunks) ints, ZERO on entry (the tile stage clears it).

@@ -66,6 +66,7 @@ constexpr int kTrunk16Conv2At = 4 * 64 * 4, kTrunk16Conv3At = kTrunk16Conv2At + 
 constexpr int kTrunk16Consts = 24 * 64;
 struct Trunk16Scalars { float C1[3], U2[3], U3[3]; };
 void pack_trunk_f16(const float* blob, float scale_a, uint16_t* w_out /*[3][kTrunk16Halves]*/, float* c_out /*[3][kTrunk16Consts]*/, Trunk16Scalars* sc);
+
 // fp32 <-> IEEE binary16 on the host (round to nearest even, subnormals kept: what v_cvt_pk_f16_f32 / v_cvt_f32_f16 do on the device)
 inline uint16_t f16_rne(float x) {
     uint32_t u;
@@ -156,6 +157,26 @@ constexpr size_t kOffFc2B[3] = {5125984 / 4, 5076064 / 4, 4877920 / 4};
 constexpr size_t kOffFc3W[3] = {5152644 / 4, 5151088 / 4, 5138720 / 4};
 constexpr size_t kOffFc3B[3] = {5152640 / 4, 5151072 / 4, 5138656 / 4};
 
+// ---- plan 3, round 5: the heads (FC2 + FC3) on the 16-bit matrix pipe as well (ethcnn_heads_fast.hip), operands as fp16 x 2 splits of
+// power-of-two scaled values like FC1's and the trunk's.  Per head h (n1 = 64 / 128 / 256, n2 = 48 / 96 / 192, n3 = 1 / 4 / 16), A operands
+// of v_mfma_f32_16x16x32_f16 ("transposed": rows = output features, columns = CTUs), lane = row + 16 kg holds eight k values:
+//   FC2 image [n1 / 32 chunks][n2 / 16 tiles][2 pieces][64 lanes][8]:  W2[32 c + 8 kg + i][16 j + row] * sw2
+//   FC3 image [ceil(n2 / 32) steps][2 pieces][64 lanes][8]:            W3[16 (2 p + (i >> 2)) + 4 kg + (i & 3)][row] * sw3  (0 for row >= n3
+//                                                                       or a tile beyond n2): the k order in which the FC2 accumulators
+//                                                                       of tiles 2 p, 2 p + 1 sit in a lane's registers
+// The scales are powers of two from GUARANTEED bounds (fast_feature_bound pushed through |W1| and |W2|), so no piece can overflow.
+constexpr int heads16_n1(int h) { return 64 << h; }
+constexpr int heads16_n2(int h) { return 48 << h; }
+constexpr int heads16_fc2_halves(int h) { return heads16_n1(h) * heads16_n2(h) * 2; }
+constexpr int heads16_fc3_steps(int h) { return (heads16_n2(h) / 16 + 1) / 2; }
+constexpr int heads16_fc3_halves(int h) { return heads16_fc3_steps(h) * 2 * 512; }
+constexpr int heads16_fc2_at(int h) { return h == 0 ? 0 : heads16_fc2_at(h - 1) + heads16_fc2_halves(h - 1); }  // (usable in device code)
+constexpr int heads16_fc3_at(int h) { return h == 0 ? heads16_fc2_at(3) : heads16_fc3_at(h - 1) + heads16_fc3_halves(h - 1); }
+constexpr int kHeads16Halves = heads16_fc3_at(3);
+struct Heads16Scalars { float S1[3], U2[3], S2[3], U3[3]; };  // h1 scale, 1 / (S1 sw2), h2 scale, 1 / (S2 sw3)
+// false: a bound is not finite / zero (degenerate weights) -- the caller keeps the exact heads
+bool pack_heads_f16(const float* blob, float feature_bound, uint16_t* img_out /*[kHeads16Halves]*/, Heads16Scalars* sc);
+
 // feature-vector map
 constexpr int kOff3[3] = {0, 512, 640};       // conv3 S, M, L
 constexpr int kOff2[3] = {672, 2208, 2592};   // conv2 S, M, L
@@ -193,6 +214,8 @@ struct DeviceWeights {
     uint16_t* trunk16_w = nullptr;  // plan 3: [3][kTrunk16Halves]
     float* trunk16_c = nullptr;     //         [3][kTrunk16Consts]
     Trunk16Scalars trunk16_s{};
+    uint16_t* heads16_w = nullptr;  // plan 3: FC2 / FC3 A operands as fp16 x 2 pieces, [kHeads16Halves] (null: exact heads)
+    Heads16Scalars heads16_s{};
     float fast_scale_a = 1.0f, fast_scale_w = 1.0f;  // plan 2: powers of two applied to features / W1 before the fp16 split
     float* fc1_b = nullptr;    // [448]
     float* fc2_w[3] = {nullptr, nullptr, nullptr};  // [n1+1][n2] (last row = qp row)

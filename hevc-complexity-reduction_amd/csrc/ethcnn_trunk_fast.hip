@@ -75,20 +75,19 @@ struct Trunk16 {
     float C1, U2, U3;
     __amdgpu_buffer_rsrc_t rF;
 
-    // every thread of the 256-thread block; ends with a barrier (the fragments are in `lds`, 20 KB)
-    __device__ __forceinline__ void setup(const uint16_t* __restrict__ wimg, const float* __restrict__ cfrag, float c1, float u2, float u3,
-                                          char* __restrict__ F, int n, char* lds) {
+    // conv2 / conv3 A fragments of the branch -> LDS (20 KB); every thread of the 256-thread block; the caller puts a barrier behind it
+    static __device__ __forceinline__ void stage(const uint16_t* __restrict__ wimg, char* lds) {
+        const uint4* src = reinterpret_cast<const uint4*>(wimg + kTrunk16Conv2At);
+        uint4* dst = reinterpret_cast<uint4*>(lds);
+        for (int i = threadIdx.x; i < 20 * 64; i += 256) dst[i] = src[i];
+    }
+    // conv1 A pieces (piece 0, piece 1, and both x 16 for the L branch's high digit) and the per-channel constants: registers
+    __device__ __forceinline__ void load_consts(const uint16_t* __restrict__ wimg, const float* __restrict__ cfrag, float c1, float u2, float u3,
+                                                char* __restrict__ F, int n, char* lds) {
         lane = threadIdx.x & 63;
         col = lane & 15;
         g = lane >> 4;
         N = n; C1 = c1; U2 = u2; U3 = u3;
-        // conv2 / conv3 A fragments -> LDS (20 KB), once per block
-        {
-            const uint4* src = reinterpret_cast<const uint4*>(wimg + kTrunk16Conv2At);
-            uint4* dst = reinterpret_cast<uint4*>(lds);
-            for (int i = threadIdx.x; i < 20 * 64; i += 256) dst[i] = src[i];
-        }
-        // conv1 A pieces (piece 0, piece 1, and both x 16 for the L branch's high digit) and the per-channel constants: registers
 #pragma unroll
         for (int f = 0; f < 4; ++f) A1[f] = *reinterpret_cast<const h4*>(wimg + (f * 64 + lane) * 4);
 #pragma unroll
@@ -101,11 +100,17 @@ struct Trunk16 {
                 b3s[t][r] = cfrag[(16 + t * 4 + r) * 64 + lane];
             }
         }
-        __syncthreads();
         a2_lds = lds + lane * 16;             // conv2 fragment (t, s, p) at ((t * 2 + s) * 2 + p) KiB
         a3_lds = lds + 8 * 1024 + lane * 16;  // conv3 fragment (t, s, p) at ((t * 3 + s) * 2 + p) KiB
         lane_off = (g >> 1) * FCH + (g & 1) * 512 + col * 16;  // [chunk][piece][k half][row][8 x 16 bit] (ethcnn_spec.h)
         rF = __builtin_amdgcn_make_buffer_rsrc(F, 0, -1, 0x00020000);
+    }
+    // every thread of the 256-thread block; ends with a barrier (the fragments are in `lds`, 20 KB)
+    __device__ __forceinline__ void setup(const uint16_t* __restrict__ wimg, const float* __restrict__ cfrag, float c1, float u2, float u3,
+                                          char* __restrict__ F, int n, char* lds) {
+        stage(wimg, lds);
+        load_consts(wimg, cfrag, c1, u2, u3, F, n, lds);
+        __syncthreads();
     }
 
     // one task (unit position `task` of its group; `raw` = the lane's pixel record).  mid(): called once the record registers are
@@ -345,15 +350,113 @@ __global__ __launch_bounds__(256) void k1_trunk_f16_fold(const uint8_t* __restri
     }
 }
 
+// ---- the whole trunk of plan 3 behind ONE pass over the luma frames (round 5).  k1_trunk_f16_fold above still writes and re-reads
+// 2,560 B of XM / XL records per CTU and pays a second launch for the M / L tasks; the trunk is HBM-bound (profiles/r05_plan3_prof.txt:
+// 1.5 GB in 0.295 ms + 0.52 GB in 0.119 ms, ~5 TB/s of mixed read / write), so bytes are what count.  Here a block takes a whole GROUP:
+// it walks the four slabs, every wave runs the slab's S task of its unit column, and the pooled records of the M / L units are built
+// from the same LDS slab straight into the registers of the wave that will run that task -- waves 0 / 1 the M units (uy, ux = w) after
+// slabs 1 and 3, wave 2 the L unit after slab 3.  HBM traffic of the trunk: 4,096 B in, 10,752 B of feature pieces out per CTU.
+// 21 tasks in 24 wave slots per group; 77.5 KB of LDS (three branches' fragments + the slab): two blocks per CU.
+template <bool FAST>
+__global__ __launch_bounds__(256) void k1_trunk_f16_foldall(const uint8_t* __restrict__ luma, int width, int height, long pitch, long frame_stride,
+                                                            int cw, int nctu, int f0, int r0, int N, int* __restrict__ gate_flags, int n_flags,
+                                                            const uint16_t* __restrict__ wimg, const float* __restrict__ cfrag, Trunk16Scalars sc,
+                                                            char* __restrict__ F) {
+    __shared__ __attribute__((aligned(16))) char lds[3][20 * 1024];
+    __shared__ uint32_t tile[16 * kSlabCtuPitch];
+    if (blockIdx.x == 0)  // (what the tile stage does on the way: the pass's sync area, read by the heads / gate launches behind us)
+        for (int i = threadIdx.x; i < n_flags; i += 256) gate_flags[i] = 0;
+    const int t = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    Trunk16<0>::stage(wimg, lds[0]);
+    Trunk16<1>::stage(wimg + kTrunk16Halves, lds[1]);
+    Trunk16<2>::stage(wimg + 2 * kTrunk16Halves, lds[2]);
+    Trunk16<0> tk;
+    tk.load_consts(wimg, cfrag, sc.C1[0], sc.U2[0], sc.U3[0], F, N, lds[0]);
+    __syncthreads();
+    const int ngroups = (N + 15) >> 4;
+    int grp = blockIdx.x;
+    if (grp >= ngroups) return;
+    SlabLoader L;
+    uint4 pre[4];
+    L.init32(t, luma, width, frame_stride, cw, nctu, f0, r0, N, grp * 16);
+    L.template load<FAST>(0, pre, width, height, pitch);
+#pragma unroll 1
+    for (; grp < ngroups; grp += gridDim.x) {
+        uint4 rawx[8];  // waves 0 / 1: the record of M unit (uy, w), rebuilt per slab pair; wave 2: the L unit's, over the four slabs
+#pragma unroll 1
+        for (int uy = 0; uy < 2; ++uy) {
+#pragma unroll
+            for (int sh = 0; sh < 2; ++sh) {
+                const int s = 2 * uy + sh;
+                L.to_lds(tile, pre);
+                __syncthreads();
+                uint4 raw[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) raw[j] = slab_xs_record(tile, tk.col, tk.g, j, w);
+                if (w < 2) {
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) rawx[4 * sh + jj] = slab_xm_record(tile, tk.col, tk.g, 4 * sh + jj, w);
+                } else if (w == 2) {
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {  // record j = 4 uy + 2 m + sh (the columns depend on m only)
+                        const uint4 rec = slab_xl_record(tile, tk.col, tk.g, 2 * m + sh);
+                        if (uy == 0) rawx[2 * m + sh] = rec;
+                        else rawx[4 + 2 * m + sh] = rec;
+                    }
+                }
+                __syncthreads();  // the slab is consumed: the next one may overwrite it
+                tk.task(raw, grp * 16 + 4 * s + w, [&]() {
+                    if (s < 3) {
+                        L.template load<FAST>(s + 1, pre, width, height, pitch);
+                    } else {
+                        const int nx = grp + (int)gridDim.x;
+                        if (nx < ngroups) {
+                            L.init32(t, luma, width, frame_stride, cw, nctu, f0, r0, N, nx * 16);
+                            L.template load<FAST>(0, pre, width, height, pitch);
+                        }
+                    }
+                });
+            }
+            if (w < 2) {
+                Trunk16<1> tm;
+                tm.load_consts(wimg + kTrunk16Halves, cfrag + kTrunk16Consts, sc.C1[1], sc.U2[1], sc.U3[1], F, N, lds[1]);
+                tm.task(rawx, grp * 4 + 2 * uy + w, []() {});
+            }
+        }
+        if (w == 2) {
+            Trunk16<2> tl;
+            tl.load_consts(wimg + 2 * kTrunk16Halves, cfrag + 2 * kTrunk16Consts, sc.C1[2], sc.U2[2], sc.U3[2], F, N, lds[2]);
+            tl.task(rawx, grp, []() {});
+        }
+    }
+}
+
 void launch_trunk_f16(const Workspace& ws, const DeviceWeights& w, int n, hipStream_t s, bool ml_only) {
     // tasks per group: 16 S, 4 M, 1 L; blocks per CU by registers (see the resource remark of the build); same branch shares as k1_trunk
     const int groups = (n + 15) / 16, tS = groups * 16, tM = groups * 4, tL = groups;
     auto blocks = [](int tasks, int budget) { int b = (tasks + 3) / 4; return b < budget ? b : budget; };
     constexpr int per_cu = 4;
-    // ml_only (the S branch ran in k1_trunk_f16_fold): the whole grid to the M / L tasks, 4 : 1
-    const int bS = ml_only ? 0 : blocks(tS, 193 * per_cu), bM = blocks(tM, (ml_only ? 205 : 50) * per_cu), bL = blocks(tL, (ml_only ? 51 : 13) * per_cu);
+    // ml_only (the S branch ran in k1_trunk_f16_fold): the whole grid to the M / L tasks, 4 : 1, three resident blocks per CU (~8 tasks
+    // per wave: a fourth, non-resident block per CU would be a second round for a quarter of the work)
+    const int bS = ml_only ? 0 : blocks(tS, 193 * per_cu), bM = blocks(tM, ml_only ? 205 * 3 : 50 * per_cu), bL = blocks(tL, ml_only ? 51 * 3 : 13 * per_cu);
     hipLaunchKernelGGL(k1_trunk_f16, dim3(bS + bM + bL), dim3(256), 0, s, ws.xs, ws.xm, ws.xl, n, bS, bM, w.trunk16_w, w.trunk16_c, w.trunk16_s,
                        reinterpret_cast<char*>(ws.featb));
+}
+
+void launch_trunk_f16_foldall(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, const Workspace& ws, const DeviceWeights& w, int n_flags,
+                              hipStream_t s, int blocks_per_cu) {
+    const int groups = (n + 15) / 16;
+    const int cap = 256 * (blocks_per_cu > 0 ? blocks_per_cu : 2);
+    const int blocks = groups < cap ? groups : cap;
+    const bool fast = (g.width % 16 == 0) && (g.pitch % 16 == 0) && (g.frame_stride % 16 == 0) && (reinterpret_cast<uintptr_t>(d_luma) % 16 == 0);
+    const int f0 = (int)(ctu0 / g.nctu), r0 = (int)(ctu0 % g.nctu);
+    if (fast)
+        hipLaunchKernelGGL(k1_trunk_f16_foldall<true>, dim3(blocks), dim3(256), 0, s, d_luma, g.width, g.height, g.pitch, g.frame_stride, g.cw, g.nctu,
+                           f0, r0, n, ws.flags, n_flags, w.trunk16_w, w.trunk16_c, w.trunk16_s, reinterpret_cast<char*>(ws.featb));
+    else
+        hipLaunchKernelGGL(k1_trunk_f16_foldall<false>, dim3(blocks), dim3(256), 0, s, d_luma, g.width, g.height, g.pitch, g.frame_stride, g.cw, g.nctu,
+                           f0, r0, n, ws.flags, n_flags, w.trunk16_w, w.trunk16_c, w.trunk16_s, reinterpret_cast<char*>(ws.featb));
 }
 
 void launch_trunk_f16_fold(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, const Workspace& ws, const DeviceWeights& w, int n_flags,

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <vector>
 
 #include "ethcnn_spec.h"
 
@@ -402,6 +403,67 @@ void pack_trunk_f16(const float* blob, float scale_a, uint16_t* w_out, float* c_
             }
         }
     }
+}
+
+// ---- plan 3: FC2 / FC3 A operands as fp16 x 2 pieces (ethcnn_heads_fast.hip; layout: ethcnn_spec.h)
+static void f16x2r(float x, uint16_t* hi, uint16_t* lo) {  // scaled residual: x = hi + lo * 2^-11 (ethcnn_heads_fast.hip::split8r)
+    *hi = f16_rne(x);
+    *lo = f16_rne((x - f16_f32(*hi)) * 2048.0f);
+}
+bool pack_heads_f16(const float* blob, float feature_bound, uint16_t* img, Heads16Scalars* sc) {
+    for (int h = 0; h < 3; ++h) {
+        const int n1 = kN1[h], n2 = kN2[h], n3 = kN3[h], nt = n2 / 16;
+        const float* W1 = blob + kOffFc1W[h];  // [2688][n1]
+        const float* B1 = blob + kOffFc1B[h];
+        const float* W2 = blob + kOffFc2W[h];  // [n1 + 1][n2], last row = qp
+        const float* B2 = blob + kOffFc2B[h];
+        const float* W3 = blob + kOffFc3W[h];  // [n2 + 1][n3]
+        // |h1[n]| <= |b1[n]| + feature_bound * sum_k |W1[k][n]|  (leaky-ReLU never grows a magnitude);
+        // |h2[m]| <= |b2[m]| + |W2[n1][m]| (qp / 51 <= 1) + sum_n |W2[n][m]| * bound1[n]
+        std::vector<double> b1(n1);
+        double worst1 = 0, worst2 = 0, m2 = 0, m3 = 0;
+        for (int n = 0; n < n1; ++n) {
+            double acc = 0;
+            for (int k = 0; k < kNFeat; ++k) acc += std::fabs((double)W1[(size_t)k * n1 + n]);
+            b1[n] = std::fabs((double)B1[n]) + (double)feature_bound * acc;
+            worst1 = std::max(worst1, b1[n]);
+        }
+        for (int m = 0; m < n2; ++m) {
+            double acc = std::fabs((double)B2[m]) + std::fabs((double)W2[(size_t)n1 * n2 + m]);
+            for (int n = 0; n < n1; ++n) acc += std::fabs((double)W2[(size_t)n * n2 + m]) * b1[n];
+            worst2 = std::max(worst2, acc);
+        }
+        for (int i = 0; i < n1 * n2; ++i) m2 = std::max(m2, (double)std::fabs(W2[i]));
+        for (int i = 0; i < n2 * n3; ++i) m3 = std::max(m3, (double)std::fabs(W3[i]));
+        if (!(worst1 > 0) || !(worst2 > 0) || !(m2 > 0) || !(m3 > 0) || !std::isfinite(worst1) || !std::isfinite(worst2)) return false;
+        const float S1 = pow2_scale(worst1 * 1.0001), S2 = pow2_scale(worst2 * 1.0001), sw2 = pow2_scale(m2), sw3 = pow2_scale(m3);
+        sc->S1[h] = S1;
+        sc->U2[h] = 1.0f / (S1 * sw2);
+        sc->S2[h] = S2;
+        sc->U3[h] = 1.0f / (S2 * sw3);
+        uint16_t* f2 = img + heads16_fc2_at(h);
+        for (int c = 0; c < n1 / 32; ++c)
+            for (int j = 0; j < nt; ++j)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int i = 0; i < 8; ++i) {
+                        const int row = lane & 15, kg = lane >> 4;
+                        uint16_t hi, lo;
+                        f16x2r(W2[(size_t)(32 * c + 8 * kg + i) * n2 + 16 * j + row] * sw2, &hi, &lo);
+                        f2[(((size_t)(c * nt + j) * 2 + 0) * 64 + lane) * 8 + i] = hi;
+                        f2[(((size_t)(c * nt + j) * 2 + 1) * 64 + lane) * 8 + i] = lo;
+                    }
+        uint16_t* f3 = img + heads16_fc3_at(h);
+        for (int p = 0; p < heads16_fc3_steps(h); ++p)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int i = 0; i < 8; ++i) {
+                    const int row = lane & 15, kg = lane >> 4, tile = 2 * p + (i >> 2), k = 16 * tile + 4 * kg + (i & 3);
+                    uint16_t hi, lo;
+                    f16x2r((row < n3 && tile < nt) ? W3[(size_t)k * n3 + row] * sw3 : 0.0f, &hi, &lo);
+                    f3[((size_t)(p * 2 + 0) * 64 + lane) * 8 + i] = hi;
+                    f3[((size_t)(p * 2 + 1) * 64 + lane) * 8 + i] = lo;
+                }
+    }
+    return true;
 }
 
 void pack_fc2_lane_image(const float* w2, int n1, int n2, float* img) {

@@ -1,23 +1,26 @@
 #!/bin/bash
-# round 5: plan 3 with the CTU-load stage folded into the trunk's S branch (k1_trunk_f16_fold) against round 4's form (k0_tile_slab
-# beside FC1; experiments build, ETHCNN_PLAN3_FOLD=0): parity of the fast plans first, then C3 step / stage times of both forms.
+# round 5: plan 3 with the CTU-load stage folded into the trunk (experiments build, ETHCNN_PLAN3_FOLD = 2: the whole trunk in one pass
+# over the frames, k1_trunk_f16_foldall; 1: S branch folded + an M / L launch, k1_trunk_f16_fold; 0: round 4's form, k0_tile_slab beside
+# FC1): parity of the fast plans first, then C3 step / stage times of the forms.
 set -u
 mkdir -p gpurun_out
 REPO=$PWD
 {
-python -m pytest tests/test_gpu_fast_plan.py tests/test_gpu_parity.py -m gpu -x -q --timeout 600 2>&1 | tail -5
+python -m pytest tests/test_gpu_fast_plan.py -m gpu -x -q --timeout 600 2>&1 | tail -5
 export ETHCNN_LIB=$REPO/hevc-complexity-reduction_amd/lib_exp/libethcnn.so
-for rep in 1 2; do for f in 1 0; do
-  ETHCNN_PLAN3_FOLD=$f python bench.py --no-cpu-baseline --no-host-scopes --steps 30 > gpurun_out/fold3_${f}_$rep.json 2> gpurun_out/fold3.err || tail -3 gpurun_out/fold3.err
+for rep in 1 2; do for f in ${FORMS:-2 1 0}; do
+  ETHCNN_PLAN3_FOLD=$f python bench.py --no-cpu-baseline --no-host-scopes --fast-plans 3 --steps 30 > gpurun_out/fold3_${f}_$rep.json 2> gpurun_out/fold3.err || tail -3 gpurun_out/fold3.err
 done; done
 python - <<'PY'
-import json
-for f in (1, 0):
+import json, os
+for f in (2, 1, 0):
     for rep in (1, 2):
-        d = json.load(open("gpurun_out/fold3_%d_%d.json" % (f, rep)))
+        fn = "gpurun_out/fold3_%d_%d.json" % (f, rep)
+        if not os.path.exists(fn): continue
+        d = json.load(open(fn))
         p = d["fast_plan_fp16x2_trunk"]
         print("ETHCNN_PLAN3_FOLD=%d run %d: plan 3 %.2f M CTU/s  %.3f ms/step  stages %s  max|d| %.3g flips %s | exact %.2f M" %
-              (f, rep, p["value"] / 1e6, p["ms_per_step"], p.get("stages_ms_per_step"), p.get("max_abs_vs_exact") or float("nan"), p.get("flips_vs_exact"), d["value"] / 1e6))
+              (f, rep, p["value"] / 1e6, p["ms_per_step"], {k: round(v, 3) for k, v in p["stages_ms_per_step"].items()}, p.get("max_abs_vs_exact") or float("nan"), p.get("flips_vs_exact"), d["value"] / 1e6))
 PY
 } > gpurun_out/fold3.txt 2>&1
 cat gpurun_out/fold3.txt

@@ -435,3 +435,41 @@ def test_completion_word_only_covers_the_last_launch(pkg, oracle):
             b.free()
     finally:
         c.close()
+
+
+def test_streamed_staging_copy_that_comes_too_late_is_rerun_not_returned(pkg, oracle):
+    """a pageable picture takes the streamed-staging form of ethcnn_predict_luma -- the single-launch pass is
+    queued on the page-locked staging buffer FIRST, then the rows are copied in and reported.  If the calling thread is held for
+    more than ~1 s between the two (SIGSTOP, a VM pause), the kernels give up waiting and compute on stale staging contents; the
+    call must notice (the gave-up word) and run the pass again on the now complete buffer instead of returning ETHCNN_OK with wrong
+    numbers.  ETHCNN_TEST_STAGE_STALL_MS (experiments build) holds the thread there."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import importlib, os, sys, time
+        import numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "oracle"))
+        import ethcnn_np as oracle
+        pkg = importlib.import_module("hevc-complexity-reduction_amd")
+        rng = np.random.default_rng(15)
+        blob = oracle.synth_blob(6, 8.0)
+        c = pkg.EthCnn(0)
+        c.load_blob(blob)
+        c.set_thresholds(0.5, 0.5)
+        w, h = 832, 480
+        for k in range(2):  # the second picture meets a staging buffer that holds the FIRST one: stale data would be a plausible-looking wrong answer
+            luma = rng.integers(0, 256, size=(1, h, w), dtype=np.uint8)
+            want = oracle.predict_frames(blob, luma, w, h, 1, 32, 0.5, 0.5, mode=0)
+            t0 = time.time()
+            got = c.predict_luma(luma, w, h, 1, 32)
+            dt = time.time() - t0
+            assert dt > 1.2, dt  # the stall really happened on this path
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), k
+        print("rerun ok")
+    """ % (root, root))
+    from conftest import exp_env
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=exp_env(ETHCNN_TEST_STAGE_STALL_MS=1300))
+    assert r.returncode == 0 and "rerun ok" in r.stdout, (r.stdout[-800:], r.stderr[-1500:])
