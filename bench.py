@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--no-host-scopes", action="store_true", help="skip the PCIe / file-inclusive side measurements")
     ap.add_argument("--no-fast-plan", action="store_true", help="skip the further timed regions (opt-in FC1 / trunk plans on the 16-bit matrix pipe), reported as `fast_plan*`")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short driver-timed regions of the other BASELINE configs (`other_configs`)")
-    ap.add_argument("--fast-plans", default="1,2,3", help="which opt-in plans get a timed region (profiling runs: --fast-plans 3)")
+    ap.add_argument("--fast-plans", default="2,3", help="which opt-in plans get a timed region (profiling runs: --fast-plans 3)")
     args = ap.parse_args()
 
     import numpy as np
@@ -247,18 +247,16 @@ def main():
                 f_ms = f_st["ms"]["fc1"] / max(1, f_st["timed"]["fc1"])
                 f_alg = FC1_FLOP_PER_CTU * f_st["timed_ctus"]["fc1"] / (f_st["ms"]["fc1"] * 1e-3) / 1e12 if f_st["ms"]["fc1"] > 0 else 0.0
                 same_zero = bool(np.array_equal(fast_out == 0.0, exact_out == 0.0))
-                nprod = 6 if plan == 1 else 3
-                fc1_plan = 2 if plan == 3 else plan
+                nprod = 3
+                fc1_plan = 2
                 fast[plan] = {
                     "value": ctus_per_step * args.steps * world / f_elapsed, "unit": "CTU/s", "ms_per_step": f_elapsed / args.steps * 1e3,
-                    "dtype": ("bf16x3 split, f32 accumulate" if plan == 1 else "fp16x2 split (power-of-two scaled), f32 accumulate") +
+                    "dtype": "fp16x2 split (power-of-two scaled), f32 accumulate" +
                              (" (FC1 only; trunk, heads and gates exact f32 as in `value`)" if plan < 3 else
-                              " (FC1 AND the trunk's three conv layers; heads and gates exact f32 as in `value`)"),
+                              " (trunk convolutions, FC1 and the heads' FC2 / FC3; CTU-load stage folded into the trunk; gates exact as in `value`)"),
                     "plan": "ethcnn_set_fc1_plan(ctx, %d): " % plan +
-                            ("every fp32 feature / weight as three bf16 pieces (exact split), the six products with i + j <= 2 on "
-                             "v_mfma_f32_32x32x16_bf16" if plan == 1 else
-                             "every scaled fp32 feature / weight as two fp16 pieces (2^-24 relative), three products on "
-                             "v_mfma_f32_32x32x16_f16") + "; opt-in, never the default",
+                            "every scaled fp32 feature / weight as two fp16 pieces (2^-24 relative), three products on "
+                            "v_mfma_f32_32x32x16_f16; opt-in, never the default",
                     "roofline": {"kernel": "k_fc1_fast<%d, 7, nine> (ethcnn_fc1_fast.hip; FC1 [N,2688]x[2688,448] as %d 16-bit products per fp32 product)" % (fc1_plan, nprod),
                                  "bound": "mfma", "achieved": nprod * f_alg, "peak": PEAK_BF16_MFMA_TFLOPS,
                                  "unit": "TFLOP/s (16-bit products issued)", "frac": nprod * f_alg / PEAK_BF16_MFMA_TFLOPS,
@@ -267,6 +265,7 @@ def main():
                                  "note": "the chip lowers its shader clock under dense 16-bit MFMA streams (profiles/r04_power_probe.txt): "
                                          "the data-sheet peak assumes 2.4 GHz"},
                     "stages_ms_per_step": {k: v / 3.0 for k, v in f_all["ms"].items()},
+                    "hbm": step_hbm("%s_plan%d" % (args.workload, plan), f_elapsed / args.steps * 1e3),
                     "max_abs_vs_exact": float(np.abs(fast_out - exact_out).max()) if same_zero else None,
                     "flips_vs_exact": int(((fast_out > 0.5) != (exact_out > 0.5)).sum()),
                     "gate_pattern_equal": same_zero,
@@ -309,6 +308,7 @@ def main():
                             "tile stage of step i+1 runs beside FC1 of step i, so ms_per_step < the sum of these"),
             "stages_frac_of_f32_mfma_peak": stage_fracs({k: v / 3.0 for k, v in st_all["ms"].items()}, ctus_per_step),
             "kernel_ms_per_step": kernel_ms,
+            "hbm": step_hbm(args.workload, elapsed / args.steps * 1e3),
             "whole_path_tflops": 2.0 * MAC_PER_CTU * total_ctus / elapsed / 1e12,
             "whole_path_frac_of_f32_mfma_peak": 2.0 * MAC_PER_CTU * total_ctus / elapsed / 1e12 / PEAK_F32_MFMA_TFLOPS / world,
             "ctu_load_stage": {"kernel": "k0_tile", "bound": "hbm", "achieved": tile_gbps, "peak": PEAK_HBM_GBPS,
@@ -344,8 +344,6 @@ def main():
             if not args.no_cpu_baseline:
                 result["cpu_baseline"] = cpu_baseline_ldp(luma, W, H, QP, cpu_seconds)
             result["parity_first_frames_bit_exact"] = ldp_parity(ctx, luma, W, H, QP)
-        if 1 in fast:
-            result["fast_plan"] = fast[1]
         if 2 in fast:
             result["fast_plan_fp16x2"] = fast[2]
         if 3 in fast:
@@ -550,7 +548,7 @@ def other_configs(ctx, skip):
     are repeats (generating 54 distinct 4928x3264 frames costs more than the measurement); throughput does not depend on content."""
     import numpy as np
     out = {}
-    for key in ("c2", "c4", "c5"):
+    for key in ("c2", "c3", "c4", "c5"):
         if key == skip:
             continue
         wl = WORKLOADS[key]
@@ -781,6 +779,32 @@ def pmc_traffic_fast(workload, plan):
                 "traffic_source": d["source"]}
     except Exception:
         return {"traffic": None}
+
+
+def kernel_source_stamp():
+    """identifies the device code of the whole step: one hash over the git blob hashes of every .hip / .h file of csrc/"""
+    import hashlib
+    src = os.path.join(ROOT, "hevc-complexity-reduction_amd", "csrc")
+    names = sorted(f for f in os.listdir(src) if f.endswith((".hip", ".h")))
+    return hashlib.sha1("".join(git_blob_sha1(os.path.join(src, f)) for f in names).encode()).hexdigest()[:16]
+
+
+def step_hbm(key, ms_per_step):
+    """HBM-side bytes of ONE step of a plan from the committed PMC passes (profiles/step_traffic.json, scripts/gpu_step_traffic.sh;
+    key: c3 / c3_plan2 / c3_plan3) against this run's step time: how close the STEP is to the memory system, beside the FC1
+    `roofline` object.  Valid only for the kernel sources the passes were taken at."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "step_traffic.json")))
+        if d.get("kernel_source_stamp") != kernel_source_stamp():
+            return {"bytes_per_step": None, "note": "profiles/step_traffic.json was taken at other kernel sources: re-run scripts/gpu_step_traffic.sh"}
+        e = d[key]
+        gbps = e["bytes_per_step"] / (ms_per_step * 1e-3) / 1e9
+        return {"bytes_per_step": e["bytes_per_step"], "gbps": gbps, "frac_of_6.3TBps": gbps / 6300.0,
+                "algorithmic_bytes_per_step": e["algorithmic_bytes_per_step"], "per_kernel_bytes": e["per_kernel"],
+                "source": d["source"], "note": "counter bytes (FETCH_SIZE x 2 + WRITE_SIZE) of a separate PMC run / this run's ms_per_step; "
+                                               "6.3 TB/s = what the guide calls achievable of the 8 TB/s peak"}
+    except Exception as exc:  # noqa: BLE001
+        return {"bytes_per_step": None, "note": "unavailable: %s" % exc}
 
 
 def git_blob_sha1(path):

@@ -196,9 +196,9 @@ struct ethcnn_ctx {
     int ssync_cap = 0;       // in ints
     bool ssync_clean = false;
     int small_epoch = 0;     // claim tag of the last single-launch pass (1 .. 2^30, wraps: the area is re-zeroed then)
-    int fc1_plan = 0;        // 0 = exact fp32 FC1 (default; bit-identical to the oracle); 1 / 2 = "fast": FC1 of the multi-launch path on the
-                             // 16-bit matrix pipe with split operands, bf16 x 3 / fp16 x 2 (ethcnn_fc1_fast.hip; ethcnn_set_fc1_plan, env ETHCNN_FC1_PLAN)
-    uint16_t* dw_fast[2] = {nullptr, nullptr};  // W1 in the form of plan 1 / 2 (packed on first use), 7.2 / 4.8 MB
+    int fc1_plan = 0;        // 0 = exact fp32 FC1 (default; bit-identical to the oracle); 2 / 3 = "fast": FC1 of the multi-launch path on the
+                             // 16-bit matrix pipe with split operands, fp16 x 2 (ethcnn_fc1_fast.hip; 3: trunk and heads as well; ethcnn_set_fc1_plan, env ETHCNN_FC1_PLAN)
+    uint16_t* dw_fast = nullptr;                // W1 in the form of plan 2 (packed on first use), 4.8 MB
     uint16_t* dw_trunk16 = nullptr;             // plan 3: the trunk's A operands as fp16 x 2 pieces + its per-lane constants (one allocation)
     uint16_t* dw_heads16 = nullptr;             // plan 3: FC2 / FC3 A operands as fp16 x 2 pieces (kHeads16Halves)
     int last_fast = 0;       // the FC1 plan of the last pass (debug_fetch reads the features of plans 1 / 2 from ws.featb)
@@ -217,7 +217,7 @@ struct ethcnn_ctx {
     float* host_probs = nullptr;               // set around a host -> host single-launch pass: page-locked destination its last block copies the
                                                // probabilities to (then no copy launch behind the kernel: the caller waits on the completion word)
     bool host_probs_used = false;              // ... and whether the pass took it (single-launch form, completion word armed)
-    struct LdpPending { bool open = false, streamed = false; float* probs = nullptr; float* d_probs = nullptr; size_t pbytes = 0; int out = 0, nctu = 0; } ldp;
+    struct LdpPending { bool open = false, streamed = false; float* probs = nullptr; float* d_probs = nullptr; size_t pbytes = 0; int out = 0, in = -1, nctu = 0; } ldp;
     struct LumaPending { bool open = false, direct = false; float* probs = nullptr; size_t out_bytes = 0; } ai;  // ethcnn_predict_luma_begin ... _end
     unsigned done_seq = 0;     // last number handed out
     unsigned done_armed = 0;   // != 0: the LAST operation enqueued on the main stream stores this number when all its outputs are final
@@ -325,7 +325,7 @@ static int ensure_workspace(ethcnn_ctx* c, int n, int chunks) {
         HIPCHK(c, hipMalloc((void**)&c->h1_1, (size_t)cap * kNVec * 4));
         w.cap = cap;
     }
-    if (c->fc1_plan != 0 && !w.featb)  // plans 1 / 2: the features as 16-bit pieces, up to 16,128 B per CTU (ethcnn_spec.h)
+    if (c->fc1_plan != 0 && !w.featb)  // plans 2 / 3: the features as fp16 x 2 pieces, 10,752 B per CTU (ethcnn_spec.h)
         HIPCHK(c, hipMalloc((void**)&w.featb, (size_t)((w.cap + 31) / 32) * kFastPairBytes));
     const int words = sync_words(std::max(n, w.cap), chunks);
     if (words > w.flags_cap) {
@@ -382,9 +382,9 @@ extern "C" int ethcnn_create(ethcnn_ctx** out, const ethcnn_options* opt) {
     }
     if (const char* e = dev_env("ETHCNN_OVERLAP")) c->overlap = std::atoi(e) != 0;  // development knob (A/B runs)
     if (const char* e = dev_env("ETHCNN_SMALL")) c->small_launch = std::atoi(e) != 0;  // development knob (A/B runs)
-    if (const char* e = std::getenv("ETHCNN_FC1_PLAN")) {  // user-facing: start contexts in FC1 plan 1 / 2
+    if (const char* e = std::getenv("ETHCNN_FC1_PLAN")) {  // user-facing: start contexts in plan 2 / 3
         const int pl = std::atoi(e);
-        c->fc1_plan = (pl >= 1 && pl <= 3) ? pl : 0;
+        c->fc1_plan = (pl == 2 || pl == 3) ? pl : 0;
     }
     if (const char* e = dev_env("ETHCNN_FUSED")) c->fused = std::atoi(e) != 0;      // development knob (A/B runs)
     if (const char* e = dev_env("ETHCNN_GATE_FOLD")) c->gate_fold = std::atoi(e) != 0;  // development knob (A/B runs)
@@ -487,8 +487,7 @@ extern "C" void ethcnn_destroy(ethcnn_ctx* c) {
     for (const auto& r : c->pinned) (void)hipHostFree(const_cast<char*>(r.first));  // ethcnn_host_alloc buffers die with the context
     delete c->pool;
     if (c->dw_arena) (void)hipFree(c->dw_arena);
-    for (uint16_t* q : c->dw_fast)
-        if (q) (void)hipFree(q);
+    if (c->dw_fast) (void)hipFree(c->dw_fast);
     if (c->dw_trunk16) (void)hipFree(c->dw_trunk16);
     if (c->dw_heads16) (void)hipFree(c->dw_heads16);
     {
@@ -568,7 +567,7 @@ static int upload_weights(ethcnn_ctx* c) {
         d.fc3_w[h] = c->dw_arena + offs[10 + 2 * h];
         d.fc3_b[h] = c->dw_arena + offs[11 + 2 * h];
     }
-    d.fc1_fast[0] = d.fc1_fast[1] = nullptr;  // the fast plans' images of W1 belong to the previous weights: repacked on the next such pass
+    d.fc1_fast = nullptr;  // the fast plans' images of W1 belong to the previous weights: repacked on the next such pass
     d.trunk16_w = nullptr;
     d.heads16_w = nullptr;
     d.trunk16_c = nullptr;
@@ -576,7 +575,7 @@ static int upload_weights(ethcnn_ctx* c) {
     return ETHCNN_OK;
 }
 
-// plans 1 / 2: W1 as 16-bit pieces in the MFMA's B-operand order (ethcnn_weights.cpp::pack_fc1_fast_image), once per weight load
+// plan 2: W1 as fp16 x 2 pieces in the MFMA's B-operand order (ethcnn_weights.cpp::pack_fc1_fast_image), once per weight load
 static int ensure_fast_weights(ethcnn_ctx* c, int plan) {
     if (plan == 3) {  // plan 3 = plan 2's FC1 + the trunk's convolutions as fp16 x 2 (ethcnn_trunk_fast.hip)
         int rc = ensure_fast_weights(c, 2);
@@ -601,7 +600,7 @@ static int ensure_fast_weights(ethcnn_ctx* c, int plan) {
         }
         return 0;
     }
-    if (c->dw.fc1_fast[plan - 1]) return 0;
+    if (c->dw.fc1_fast) return 0;
     const size_t n16 = (size_t)kNFeat * kNVec * fast_pieces(plan);
     std::vector<float> wcat((size_t)kNFeat * kNVec), b1(kNVec);
     pack_fc1(c->blob.data(), wcat.data(), b1.data());
@@ -615,7 +614,7 @@ static int ensure_fast_weights(ethcnn_ctx* c, int plan) {
             }
     }
     float sw = 1.0f;
-    if (plan == 2) {
+    {
         // powers of two that put the largest possible |feature| and the largest |weight| at <= 2^14 (fp16 overflows at 65504): the
         // feature bound is a guarantee derived from the conv weights (|input| <= 1), not an observation
         float wmax = 0.0f;
@@ -629,10 +628,10 @@ static int ensure_fast_weights(ethcnn_ctx* c, int plan) {
     }
     std::vector<uint16_t> img(n16);
     pack_fc1_fast_image(wcat.data(), plan, sw, img.data());
-    if (!c->dw_fast[plan - 1]) HIPCHK(c, hipMalloc((void**)&c->dw_fast[plan - 1], n16 * 2));
+    if (!c->dw_fast) HIPCHK(c, hipMalloc((void**)&c->dw_fast, n16 * 2));
     HIPCHK(c, hipDeviceSynchronize());
-    HIPCHK(c, hipMemcpy(c->dw_fast[plan - 1], img.data(), n16 * 2, hipMemcpyHostToDevice));
-    c->dw.fc1_fast[plan - 1] = c->dw_fast[plan - 1];
+    HIPCHK(c, hipMemcpy(c->dw_fast, img.data(), n16 * 2, hipMemcpyHostToDevice));
+    c->dw.fc1_fast = c->dw_fast;
     return 0;
 }
 
@@ -774,8 +773,8 @@ extern "C" int ethcnn_set_fused_launch(ethcnn_ctx* c, int on) {
 
 extern "C" int ethcnn_set_fc1_plan(ethcnn_ctx* c, int plan) {
     if (!c) return ETHCNN_ERR_ARG;
-    if (plan < 0 || plan > 3)
-        return set_err(c, ETHCNN_ERR_ARG, "plan must be 0 (exact fp32, default), 1 (FC1 bf16 x 3), 2 (FC1 fp16 x 2) or 3 (FC1 and trunk fp16 x 2), got %d", plan);
+    if (plan != 0 && plan != 2 && plan != 3)  // (1 was round 4's bf16 x 3 form of FC1: removed, dominated by plan 2 in every metric)
+        return set_err(c, ETHCNN_ERR_ARG, "plan must be 0 (exact fp32, default), 2 (FC1 as fp16 x 2) or 3 (FC1, trunk and heads as fp16 x 2), got %d", plan);
     c->fc1_plan = plan;  // takes effect with the next pass enqueued
     return ETHCNN_OK;
 }
@@ -896,7 +895,8 @@ static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, lo
     // a previous pass long enough to hide anything under, and the cross-stream event costs ~10 us of a 75 us call
     // Plan 3 (round 5): the CTU-load stage is folded into the trunk's S branch (k1_trunk_f16_fold) -- no tile launch, nothing for a
     // side stream to run.  (Experiments build: ETHCNN_PLAN3_FOLD=0 keeps round 4's tile stage beside FC1 for the A/B.)
-    // 2 (default): the whole trunk behind one pass over the frames (k1_trunk_f16_foldall); 1: S branch folded, M / L as a second launch
+    // 2 (default): the whole trunk behind one pass over the frames (k1_trunk_f16_foldall; L tasks as a small second launch); 3: the same
+    // with the L task inside the block (first form); 1: S branch folded, M / L as a second launch
     static const int fold3_knob = [] { const char* e = dev_env("ETHCNN_PLAN3_FOLD"); return e ? std::atoi(e) : 2; }();
     const bool fold3 = c->fc1_plan == 3 && fold3_knob != 0 && c->tile_wait_rows == nullptr;
     const bool side_tile = c->overlap != 0 && n >= kPipelineMinCtus && !fold3;
@@ -970,7 +970,7 @@ static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, lo
           launch_trunk_f16(w, c->dw, n, c->stream, /*ml_only=*/true);
       } else if (fold3) {
           static const int bpc = [] { const char* e = dev_env("ETHCNN_PLAN3_FOLD_BLOCKS"); return e ? std::atoi(e) : 2; }();
-          launch_trunk_f16_foldall(d_luma, g, ctu0, n, w, c->dw, sync_words(n, (int)nchunks), c->stream, bpc);
+          launch_trunk_f16_foldall(d_luma, g, ctu0, n, w, c->dw, sync_words(n, (int)nchunks), c->stream, bpc, /*l_out=*/fold3_knob != 3);
       } else if (fast == 3) launch_trunk_f16(w, c->dw, n, c->stream);
       else launch_trunk(w, c->dw, n, false, c->stream, fast); }
     LAUNCH_OK("trunk");
@@ -979,7 +979,7 @@ static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, lo
     if (!c->debug_capture) wv.h2 = wv.logits = wv.raw = nullptr;
     if (fast) {
         { StageTimer t(c, ETHCNN_STAGE_FC1, n); launch_fc1_fast(w, c->dw, n, w.h1, fast == 3 ? 2 : fast, c->stream, c->cus); }
-        LAUNCH_OK("FC1 (plan 1 / 2)");
+        LAUNCH_OK("FC1 (16-bit pipe)");
         if (side_tile && c->tile_after_fc1) HIPCHK(c, hipEventRecord(c->e_fc1[p], c->stream));
         // plan 3: the heads on the 16-bit pipe as well (experiments build: ETHCNN_PLAN3_HEADS=0 keeps the exact heads for the A/B)
         static const bool heads16_knob = [] { const char* e = dev_env("ETHCNN_PLAN3_HEADS"); return !e || std::atoi(e) != 0; }();
@@ -1849,6 +1849,7 @@ static int ldp_step_begin(ethcnn_ctx* c, const uint8_t* luma, int w, int h, ptrd
     c->ldp.d_probs = d_probs;
     c->ldp.pbytes = pbytes;
     c->ldp.out = out;
+    c->ldp.in = in;
     c->ldp.nctu = nctu;
     return ETHCNN_OK;
 }
@@ -1868,7 +1869,9 @@ static int ldp_step_end(ethcnn_ctx* c) {
     }
     HIPCHK(c, stream_sync(c));
     if (c->ldp.streamed && __atomic_load_n(c->h_done + 1, __ATOMIC_ACQUIRE) == seq) {
-        c->state_cur = -1;  // computed on rows that never arrived
+        // computed on rows that never arrived: the output state is garbage, the INPUT state (the other buffer) is untouched and stays the
+        // resident one, so the caller may run the frame again (ethcnn_ldp_step on the by now complete buffer) with the same arguments
+        c->state_cur = c->ldp.in;
         return set_err(c, ETHCNN_ERR_DEVICE, "ethcnn_ldp_step_end: the kernels waited 1 s for luma rows that were never reported (ethcnn_rows_ready)");
     }
     if (c->ldp.d_probs == c->h_out[0]) std::memcpy(c->ldp.probs, c->ldp.d_probs, c->ldp.pbytes);
@@ -2038,14 +2041,13 @@ extern "C" int ethcnn_debug_fetch(ethcnn_ctx* c, int which, float* out, size_t n
     if (!src || nfloats > (size_t)c->last_n * per) return set_err(c, ETHCNN_ERR_ARG, "debug_fetch: last pass had %d CTUs", c->last_n);
     if (which != ETHCNN_DBG_FEATURES) return ethcnn_memcpy_d2h(c, out, src, nfloats * 4);
     if (c->last_fast) {
-        // plans 1 / 2: the trunk left every feature as 16-bit pieces: add them back (plan 1: the sum IS the feature, the split is
-        // exact; plan 2: (h0 + h1) / scale, equal to the feature to 2^-24 relative)
+        // plans 2 / 3: the trunk left every feature as two fp16 pieces: add them back, (h0 + h1) / scale (plan 2: equal to the feature to
+        // 2^-24 relative)
         const int plan = c->last_fast == 3 ? 2 : c->last_fast, np = fast_pieces(plan);  // (plan 3 writes plan 2's form)
         const size_t n = (nfloats + kNFeat - 1) / kNFeat, pairs = (n + 31) / 32;
         std::vector<uint16_t> rawb(pairs * (size_t)(fast_pair_bytes(plan) / 2));
         int rc = ethcnn_memcpy_d2h(c, rawb.data(), c->ws.featb, rawb.size() * 2);
         if (rc) return rc;
-        auto bf = [](uint16_t h) { const uint32_t u = (uint32_t)h << 16; float f; std::memcpy(&f, &u, 4); return f; };
         auto hf = [](uint16_t h) { return f16_f32(h); };
         const float inv = 1.0f / c->dw.fast_scale_a;
         for (size_t row = 0; row * kNFeat < nfloats; ++row)
@@ -2055,7 +2057,7 @@ extern "C" int ethcnn_debug_fetch(ethcnn_ctx* c, int which, float* out, size_t n
                         const size_t o = row * kNFeat + (size_t)fast_feature_k(ch, kh, idx);
                         if (o >= nfloats) continue;
                         const uint16_t* rec = rawb.data() + ((row / 32) * kFastChunks + ch) * np * 512 + (kh * 32 + row % 32) * 8 + idx;
-                        out[o] = plan == 1 ? (bf(rec[0]) + bf(rec[512])) + bf(rec[1024]) : (hf(rec[0]) + hf(rec[512])) * inv;
+                        out[o] = (hf(rec[0]) + hf(rec[512])) * inv;
                     }
         return ETHCNN_OK;
     }

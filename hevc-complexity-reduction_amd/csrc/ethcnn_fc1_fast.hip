@@ -1,22 +1,19 @@
-// ethcnn_fc1_fast.hip -- FC1 plans 1 and 2 (opt-in, ethcnn_set_fc1_plan): h1[N,448] = lrelu(feat[N,2688] . W1 + b1)
-// (net_CNN.py:156,164,177) on the 16-BIT matrix pipe of gfx950 (v_mfma_f32_32x32x16_{bf16,f16}: 16x the rate of the exact-fp32
+// ethcnn_fc1_fast.hip -- FC1 of plans 2 and 3 (opt-in, ethcnn_set_fc1_plan): h1[N,448] = lrelu(feat[N,2688] . W1 + b1)
+// (net_CNN.py:156,164,177) on the 16-BIT matrix pipe of gfx950 (v_mfma_f32_32x32x16_f16: 16x the rate of the exact-fp32
 // MFMA), with fp32 operands carried as SPLIT 16-bit pieces and fp32 accumulation.
 //
-// Arithmetic.
-//   plan 1  bf16 x 3.  Every fp32 feature a and weight w is three bf16 pieces, a = a0 + a1 + a2 and w = w0 + w1 + w2 EXACTLY
-//           (round to nearest even at each step; trunk epilogue ethcnn_trunk_task.h::store_pair_bf16x3, host
-//           ethcnn_weights.cpp::split_bf16x3).  A product of two bf16 values is exact in fp32 and |a_i w_j| <= 2^(-9 (i + j)) |a w|:
-//           the six terms with i + j <= 2 are issued, the three dropped ones are below 2^-27 |a w|.
-//   plan 2  fp16 x 2.  Features and weights are scaled by powers of two (exact; chosen at weight load so that no piece can
+// Arithmetic: fp16 x 2.  Features and weights are scaled by powers of two (exact; chosen at weight load so that no piece can
 //           overflow: fast_feature_bound) and carried as two fp16 pieces, a s = h0 + h1 to 2^-24 relative (two 11-bit significands,
 //           round to nearest even).  Three products: h0 g0, h1 g0, h0 g1 (the dropped h1 g1 is below 2^-22 |a w|); the result is
-//           scaled back in the epilogue (exact).  Half the MFMAs and two thirds of the bytes of plan 1.
-// Neither is narrower arithmetic in effect: measured against float64 both sums are as accurate as the exact-fp32 fmaf chain of
-// plan 0 (scripts/ubench/bf16x3_probe.hip -> profiles/r04_bf16x3_probe.txt, K = 2688: rms error fp32 chain 4.1e-7, bf16 x 3
-// 3.7e-7, fp16 x 2 2.6e-7, the last unchanged while the operand scale is moved over 12 octaves) -- the error of a long fp32 sum is
-// dominated by the roundings of the accumulation, not by 2^-24 representation errors of the terms.  What changes is the ORDER of
-// the fp32 additions (16 products are summed inside one MFMA; undocumented), so results are not bit-identical to plan 0 / the
-// oracle: both plans are held to the north star's 1e-4 and are never the default.
+//           scaled back in the epilogue (exact).
+// (Round 4 also shipped "plan 1", exact three-way bf16 splits with six products: slower than this form in every metric -- 47 vs 64
+// M CTU/s on C3 -- and no more accurate, rms error vs float64 3.7e-7 against 2.6e-7; removed in round 5, the probe stays:
+// scripts/ubench/bf16x3_probe.hip -> profiles/r04_bf16x3_probe.txt.)
+// Not narrower arithmetic in effect: measured against float64 the sum is as accurate as the exact-fp32 fmaf chain of plan 0 (K =
+// 2688: rms error fp32 chain 4.1e-7, fp16 x 2 2.6e-7, unchanged while the operand scale is moved over 12 octaves) -- the error of a
+// long fp32 sum is dominated by the roundings of the accumulation, not by 2^-24 representation errors of the terms.  What changes is
+// the ORDER of the fp32 additions (16 products are summed inside one MFMA; undocumented), so results are not bit-identical to plan
+// 0 / the oracle: the plan is held to the north star's 1e-4 and is never the default.
 //
 // Shape.  K is walked in 168 chunks of 16 (one MFMA k step).  A block = 8 waves = 256 CTUs (a wave owns one row tile of 32) x
 // NS = 7 column tiles of 32; per chunk a wave issues NS x NPROD MFMAs on NS accumulator tiles (16 registers each).  Operands
@@ -35,9 +32,9 @@
 // Stage reuse: chunk k + 2 lands in the stage chunk k - 1 used, last read in phase 2k - 1, and is first issued in phase 2k; it is
 // first read in phase 2k + 4, and every share of it has been waited for by the end of phase 2k + 3.
 //
-// What bounds it.  Not the issue rate: at this MFMA density the chip lowers its shader clock (plan 1: 1.74-1.95 GHz against
-// 2.38 GHz under plan 0, at a LOWER average socket power: scripts/power_probe.py -> profiles/r04_power_probe.txt), and keeps
-// it low for the neighbouring kernels of the step.  Fewer MFMAs per CTU (plan 2) is what moves the step, not a denser stream.
+// What bounds it.  Not the issue rate: at this MFMA density the chip lowers its shader clock (~2.0 GHz at the 1400 W cap against
+// 2.38 GHz under plan 0: scripts/power_probe.py -> profiles/r04_power_probe.txt), and keeps it low for the neighbouring kernels
+// of the step.  Fewer MFMAs per CTU is what moves the step, not a denser stream.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -48,19 +45,11 @@
 namespace ethcnn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kFastColTiles = kNVec / 32;  // 14
 
 template <int PLAN> struct FastPlan;
-template <> struct FastPlan<1> {
-    static constexpr int NP = 3, NPROD = 6;
-    using frag = bf16x8;
-    static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
-    // big terms first: (a piece, w piece)
-    static constexpr int PA[6] = {0, 1, 0, 2, 1, 0}, PB[6] = {0, 0, 1, 0, 1, 2};
-};
 template <> struct FastPlan<2> {
     static constexpr int NP = 2, NPROD = 3;
     using frag = f16x8;
@@ -76,7 +65,7 @@ struct FastShape {
     static constexpr int PIECES = NP * (ROWS + NS);        // 1 KiB pieces per stage
     static constexpr int PER = (PIECES + WM - 1) / WM;     // DMA instructions per wave per chunk (the tail repeats the last piece)
     static constexpr int STAGE = PIECES * 1024;
-    static constexpr int LDS_BYTES = NST * STAGE;          // plan 1: 135 KB, plan 2: 90 KB (96 KB with the ninth row tile)
+    static constexpr int LDS_BYTES = NST * STAGE;          // 90 KB (96 KB with the ninth row tile)
 };
 
 // M tiles of a launch.  k_fc1_fast keeps ONE block per CU, so a grid runs in rounds of `cus` blocks, and C3's 3188 row tiles of 32
@@ -258,13 +247,11 @@ __global__ __launch_bounds__(512) void k_fc1_fast(const char* __restrict__ featb
 
 void launch_fc1_fast(const Workspace& ws, const DeviceWeights& w, int n, float* out, int plan, hipStream_t s, int cus) {
     const char* fb = reinterpret_cast<const char*>(ws.featb);
-    const char* wf = reinterpret_cast<const char*>(w.fc1_fast[plan - 1]);
-    // plan 1 has no registers left for the ninth row tile's accumulator (238 of 256): it keeps the plain tiling
-    const FastTiles ft = fast_tiles((n + 31) / 32, cus, plan == 2);
+    const char* wf = reinterpret_cast<const char*>(w.fc1_fast);
+    (void)plan;  // (2: the only 16-bit form of FC1; plan 3 uses it as well)
+    const FastTiles ft = fast_tiles((n + 31) / 32, cus, true);
     const dim3 grid(((ft.tiles + 7) / 8) * 8 * 2);
-    if (plan == 1)
-        hipLaunchKernelGGL((k_fc1_fast<1, 7, false>), grid, dim3(512), 0, s, fb, wf, w.fc1_b, out, n, 1.0f, ft.tiles, 0);
-    else if (ft.extra > 0)
+    if (ft.extra > 0)
         hipLaunchKernelGGL((k_fc1_fast<2, 7, true>), grid, dim3(512), 0, s, fb, wf, w.fc1_b, out, n, 1.0f / (w.fast_scale_a * w.fast_scale_w), ft.tiles, ft.extra);
     else
         hipLaunchKernelGGL((k_fc1_fast<2, 7, false>), grid, dim3(512), 0, s, fb, wf, w.fc1_b, out, n, 1.0f / (w.fast_scale_a * w.fast_scale_w), ft.tiles, 0);

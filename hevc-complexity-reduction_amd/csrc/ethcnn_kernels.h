@@ -13,7 +13,7 @@ struct Workspace {
     uint4* xm = nullptr;     // [cap/4][8][64]    u16 2x2 pooled sums (M branch)
     uint4* xl = nullptr;     // [cap/16][8][64]   u16 4x4 pooled sums (L branch)
     float* feat = nullptr;   // [cap][2688]
-    uint16_t* featb = nullptr; // FC1 plan 1 only: [cap/32][168][3][512] bf16 pieces of the features (ethcnn_spec.h, kFastPairBytes)
+    uint16_t* featb = nullptr; // plans 2 / 3 only: [cap/32][168][2][512] fp16 pieces of the features (ethcnn_spec.h, kFastPairBytes)
     float* h1 = nullptr;     // [cap][448]
     float* h2 = nullptr;     // [cap][336]
     float* logits = nullptr; // [cap][21]
@@ -35,24 +35,24 @@ struct FrameGeom {
 // CTU rows hold wait_seq (ethcnn_tile.hip, TileWait); *gave_up = wait_seq if a block waited ~1 s in vain
 void launch_tile(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, const Workspace& ws, int n_flags,
                  hipStream_t s, int max_blocks = 0, const unsigned* wait_rows = nullptr, unsigned wait_seq = 0, unsigned* gave_up = nullptr);
-// k1: xs/xm/xl -> feat (fc1_plan 1 / 2: -> featb, every feature as three bf16 / two fp16 pieces in the 16-bit MFMA's operand order)
+// k1: xs/xm/xl -> feat (fc1_plan 2: -> featb, every feature as two fp16 pieces in the 16-bit MFMA's operand order)
 void launch_trunk(const Workspace& ws, const DeviceWeights& w, int n, bool resi, hipStream_t s, int fc1_plan = 0);
 // k1 with the CTU-load stage folded in (A/B form, experiments build: ethcnn_trunk.hip); needs small_pass_ok-style 16-byte alignment
 void launch_trunk_direct(const uint8_t* d_luma, const FrameGeom& g, long ctu0, const Workspace& ws, const DeviceWeights& w, int n, hipStream_t s);
 // k1, plan 3 (ethcnn_trunk_fast.hip): the same trunk with its convolutions on the 16-bit matrix pipe (fp16 x 2 splits) -> featb in plan 2's form
-void launch_trunk_f16(const Workspace& ws, const DeviceWeights& w, int n, hipStream_t s, bool ml_only = false);
+void launch_trunk_f16(const Workspace& ws, const DeviceWeights& w, int n, hipStream_t s, bool ml_only = false, bool l_only = false);
 // plan 3 with the CTU-load stage folded in: S tasks straight from the luma frames + the XM / XL records of the M / L tasks
 // (which follow as launch_trunk_f16(..., ml_only = true)); clears the pass's n_flags sync words like launch_tile
 void launch_trunk_f16_fold(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, const Workspace& ws, const DeviceWeights& w, int n_flags,
                            hipStream_t s);
-// the whole plan-3 trunk behind one pass over the frames (S, M and L tasks of a group in one block; no pixel records in HBM at all)
+// the whole plan-3 trunk behind one pass over the frames: S and M tasks of a group in one block (l_out: the L unit's records -- 512 B per
+// CTU -- go to ws.xl and its tasks follow as a small second launch; else wave 2 of the block runs it: no pixel records in HBM at all)
 void launch_trunk_f16_foldall(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, const Workspace& ws, const DeviceWeights& w, int n_flags,
-                              hipStream_t s, int blocks_per_cu = 2);
+                              hipStream_t s, int blocks_per_cu = 2, bool l_out = true);
 // k2: feat -> h1 (bias + leaky-ReLU fused); out may be ws.h1 or a caller buffer (resi vectors)
 void launch_fc1(const Workspace& ws, const DeviceWeights& w, int n, float* out, hipStream_t s);
-// k2, plans 1 / 2 (ethcnn_fc1_fast.hip): featb -> h1 on the 16-bit matrix pipe: six bf16 products per fp32 product (exact three-way
-// splits of both operands, terms i + j <= 2) or three fp16 products (two-way splits of the scaled operands), fp32 accumulate; same
-// bias + leaky-ReLU epilogue, same h1 layout
+// k2, plans 2 / 3 (ethcnn_fc1_fast.hip): featb -> h1 on the 16-bit matrix pipe: three fp16 products per fp32 product (two-way splits of
+// the scaled operands), fp32 accumulate; same bias + leaky-ReLU epilogue, same h1 layout
 void launch_fc1_fast(const Workspace& ws, const DeviceWeights& w, int n, float* out, int plan, hipStream_t s, int cus = 256);
 // k3+k4 fused: h1 -> h2 -> logits, raw probs, probs and per-chunk gate flags.  gate_nchunks > 0: the batch gates are applied
 // inside the launch (ws.flags = sync area: arrival counters behind the 2 * gate_nchunks predicates, zero on

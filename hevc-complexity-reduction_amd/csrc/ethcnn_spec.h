@@ -38,17 +38,17 @@ static_assert((long long)kMaxCtusPerPass * kNVec * 4 < (1ll << 31), "FC1 / heads
 static_assert((long long)kMaxCtusPerPass * kNOut * 4 < (1ll << 31), "heads / gate: probability byte offsets must fit int32");
 static_assert(2 * kMaxCtusPerPass < (1 << 24), "gate_chunk: r0 + ctu must be exact in float");
 
-// ---- FC1 plans 1 and 2 ("fast": split operands on the 16-bit matrix pipe, ethcnn_fc1_fast.hip).
-//   plan 1: every fp32 feature / weight as THREE bf16 pieces, a = a0 + a1 + a2 exactly; six products (i + j <= 2)
-//   plan 2: every fp32 feature / weight, scaled by a power of two, as TWO fp16 pieces, a 2^s = a0 + a1 to 2^-24 relative
-//           (two 11-bit significands, round to nearest even); three products (a0 w0, a1 w0, a0 w1)
-// Features of a plan with NP pieces, in v_mfma_f32_32x32x16_{bf16,f16} A-operand order:
+// ---- FC1 plan 2 ("fast": split operands on the 16-bit matrix pipe, ethcnn_fc1_fast.hip; plan 3 uses the same FC1).
+//   every fp32 feature / weight, scaled by a power of two, as TWO fp16 pieces, a 2^s = a0 + a1 to 2^-24 relative
+//   (two 11-bit significands, round to nearest even); three products (a0 w0, a1 w0, a0 w1)
+//   (plan 1 of round 4 -- three bf16 pieces, six products -- was removed in round 5: slower and no more accurate)
+// Features in v_mfma_f32_32x32x16_f16 A-operand order (NP = 2 pieces):
 //   featb[pair of groups = 32 CTUs][chunk of 16 k: 168][piece: NP][1 KiB = [k half: 2][row: 32][8 x 16 bit]].
 // Which feature sits in (chunk, k half, slot) is fast_feature_k below: the order in which the trunk's registers hold them.
 constexpr int kFastChunks = kNFeat / 16;                     // 168 K chunks of 16
-constexpr int fast_pieces(int plan) { return plan == 1 ? 3 : 2; }
-constexpr int fast_pair_bytes(int plan) { return kFastChunks * fast_pieces(plan) * 1024; }  // 504 KiB / 336 KiB per 32 CTUs
-constexpr int kFastPairBytes = fast_pair_bytes(1);           // the workspace is sized for the larger form
+constexpr int fast_pieces(int /*plan*/) { return 2; }
+constexpr int fast_pair_bytes(int plan) { return kFastChunks * fast_pieces(plan) * 1024; }  // 336 KiB per 32 CTUs
+constexpr int kFastPairBytes = fast_pair_bytes(2);
 static_assert((long long)(kMaxCtusPerPass / 32) * kFastPairBytes < (1ll << 31), "trunk / FC1 fast plans: pair image byte offset must fit int32");
 // feature index held by slot `idx` (0..7) of k half `kh` of chunk `c`: chunk = 8 T + 2 p + (g >> 1), kh = g & 1 for trunk task T
 // (unit position inside the group: 16 S, 4 M, 1 L), register pair p of the task and MFMA k-group g; slots 0..3 / 4..7 = the two quads of the pair
@@ -208,9 +208,9 @@ struct DeviceWeights {
     // the same weights in MFMA-operand order per 16-column tile: [28 tiles][168 sub-chunks of 16 k][64 lanes][4]: lane (col, g)
     // holds W1[16 u + 4 g + e][16 t + col], e = 0..3 -- one dwordx4 load per lane per sub-chunk, no LDS (single-launch pass)
     float* fc1_lane16 = nullptr;
-    // FC1 plans 1 / 2: W1 as NP 16-bit pieces in the 32x32x16 MFMA's B-operand order, [168 chunks][14 column tiles of 32][NP pieces]
-    // [1 KiB = [k half][32 columns][8]], k order = fast_feature_k (pack_fc1_fast_image); index = plan - 1
-    uint16_t* fc1_fast[2] = {nullptr, nullptr};
+    // FC1 plan 2 (and 3): W1 as two fp16 pieces in the 32x32x16 MFMA's B-operand order, [168 chunks][14 column tiles of 32][2 pieces]
+    // [1 KiB = [k half][32 columns][8]], k order = fast_feature_k (pack_fc1_fast_image)
+    uint16_t* fc1_fast = nullptr;
     uint16_t* trunk16_w = nullptr;  // plan 3: [3][kTrunk16Halves]
     float* trunk16_c = nullptr;     //         [3][kTrunk16Consts]
     Trunk16Scalars trunk16_s{};
@@ -233,7 +233,6 @@ void pack_fc1(const float* blob, float* w_out /*[2688][448]*/, float* b_out /*[4
 void pack_fc1_image(const float* w_cat /*[2688][448]*/, int bn, int bk, float* img_out /*[2688*448]*/);
 void pack_fc1_lane_image(const float* w_cat /*[2688][448]*/, float* img_out /*[2688*448]*/);
 void pack_fc1_fast_image(const float* w_cat /*[2688][448]*/, int plan, float scale_w, uint16_t* img_out /*[2688*448*NP]*/);
-void split_bf16x3(float x, uint16_t* p0, uint16_t* p1, uint16_t* p2);  // exact: x = p0 + p1 + p2, round to nearest even at each step
 void pack_fc2_lane_image(const float* w2 /*[n1+1][n2]*/, int n1, int n2, float* img_out /*[n1*n2]*/);
 void synth_blob(uint64_t seed, double head_gain, float* blob_out /*[kBlobFloats]*/);
 void synth_lstm_blob(uint64_t seed, double head_gain, float* blob_out /*[kLstmBlobFloats]*/);

@@ -88,10 +88,7 @@ void launch_trunk(const Workspace& ws, const DeviceWeights& w, int n, bool resi,
     static int per_cu = 0;
     if (!per_cu) { const char* e = dev_env("ETHCNN_TRUNK_BLOCKS_PER_CU"); per_cu = e ? atoi(e) : 3; }  // development knob
     const int bS = blocks(tS, TRUNK_SH_S * per_cu), bM = blocks(tM, TRUNK_SH_M * per_cu), bL = blocks(tL, TRUNK_SH_L * per_cu);
-    if (fc1_plan == 1)  // FC1 plan 1 (All-Intra passes only): features leave as bf16 x 3 pieces in ws.featb
-        hipLaunchKernelGGL((k1_trunk<false, 1>), dim3(bS + bM + bL), dim3(256), 0, s, ws.xs, ws.xm, ws.xl, n, bS, bM,
-                           w.trunk_w, w.trunk_b, reinterpret_cast<float*>(ws.featb), 1.0f);
-    else if (fc1_plan == 2)  // plan 2: fp16 x 2 pieces of the scaled features
+    if (fc1_plan == 2)  // plan 2 (All-Intra passes only): the features leave as fp16 x 2 pieces of the scaled values in ws.featb
         hipLaunchKernelGGL((k1_trunk<false, 2>), dim3(bS + bM + bL), dim3(256), 0, s, ws.xs, ws.xm, ws.xl, n, bS, bM,
                            w.trunk_w, w.trunk_b, reinterpret_cast<float*>(ws.featb), w.fast_scale_a);
     else if (resi)

@@ -49,35 +49,8 @@ struct DirectSrc {
     int n_total;    // CTUs in the pass
 };
 
-// FC1 plan 1 (ethcnn_fc1_fast.hip): a register pair of feature quads (8 values per lane) leaves the trunk as three bf16
-// pieces each, a = a0 + a1 + a2 EXACTLY (round to nearest even at every step: the remainder of an 8-bit rounding is
-// representable, and after two of them at most 8 significant bits are left), 16 bytes per piece and lane: the lane's slot of the
-// v_mfma_f32_32x32x16_bf16 A operand (ethcnn_spec.h: featb).  44 VALU per pair, 176 per task.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {  // v_cvt_pk_bf16_f32
-    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){lo, hi}, bf16x2));
-}
-template <bool SC1>
-__device__ __forceinline__ void store_pair_bf16x3(const f32x4& qa, const f32x4& qb, __amdgpu_buffer_rsrc_t rF, int voff) {
-    float r[8] = {qa[0], qa[1], qa[2], qa[3], qb[0], qb[1], qb[2], qb[3]};
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-        u32x4 P;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) P[i] = cvt_pk_bf16(r[2 * i], r[2 * i + 1]);
-        if (p < 2) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                r[2 * i] -= __builtin_bit_cast(float, P[i] << 16);
-                r[2 * i + 1] -= __builtin_bit_cast(float, P[i] & 0xffff0000u);
-            }
-        }
-        __builtin_amdgcn_raw_buffer_store_b128(P, rF, voff + p * 1024, 0, SC1 ? kAuxSc1 : 0);
-    }
-}
-
-// FC1 plan 2: the same register pair as two fp16 pieces of the SCALED value (scale = a power of two chosen at weight load so that
+// FC1 plan 2: a register pair of feature quads (8 values per lane) as two fp16 pieces of the SCALED value (scale = a power of two chosen at weight load so that
 // no feature can overflow fp16, ethcnn_weights.cpp::fast_feature_bound): h0 = fp16(a s), h1 = fp16(a s - h0), round to nearest
 // even: a s = h0 + h1 to 2^-24 relative.  ~32 VALU per pair.
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -100,10 +73,10 @@ __device__ __forceinline__ void store_pair_f16x2(const f32x4& qa, const f32x4& q
     }
 }
 
-// FAST = FC1 plan the features are written for: 0 fp32 group images (feat), 1 bf16 x 3 / 2 fp16 x 2 pieces (featb)
+// FAST = FC1 plan the features are written for: 0 fp32 group images (feat), 2 fp16 x 2 pieces (featb)
 template <int BR, bool RESI, bool DIRECT = false, bool SC1 = false, int FAST = 0>
 struct Trunk {
-    static constexpr int FCH = (FAST == 1 ? 3 : 2) * 1024;  // bytes of one chunk record of a pair image (pieces x 1 KiB)
+    static constexpr int FCH = 2 * 1024;  // bytes of one chunk record of a pair image (2 pieces x 1 KiB)
     static constexpr int POOL = (BR == 0) ? 1 : (BR == 1 ? 2 : 4);
     static constexpr float SCALE = 1.0f / (float)(POOL * POOL);
     static constexpr float C255S = (1.0f / 255.0f) * SCALE;  // exact: SCALE is a power of two
@@ -322,7 +295,7 @@ struct Trunk {
         // hazard recognizer assumes a register soffset removes the ">64-bit store data" hazard -- and on gfx950 lanes
         // 12..15 of every row then stored the overwritten value (profiles/r02_fc1_variants.txt, "buffer_store hazard").
         const int lane16 = lane * 16;
-        const int lane_off = FAST ? (g >> 1) * FCH + (g & 1) * 512 + col * 16  // plans 1 / 2: [chunk][piece][k half][row][8 x 16 bit]
+        const int lane_off = FAST ? (g >> 1) * FCH + (g & 1) * 512 + col * 16  // plan 2: [chunk][piece][k half][row][8 x 16 bit]
                                   : (col * 4 + g * 64) * 4;  // feature stores: [k/4][16 CTUs][4] -> g, col
         const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(X), 0, -1, 0x00020000);
         const __amdgpu_buffer_rsrc_t rF = __builtin_amdgcn_make_buffer_rsrc(F, 0, -1, 0x00020000);
@@ -349,12 +322,11 @@ struct Trunk {
             const bool valid = grp * 16 + col < N;
             // feature k of this lane's CTU: group image [(k/4)][16 CTUs][4]; k = k0 + 4 g with a uniform k0 % 4 == 0
             const int Fg = grp * (kNFeat * 16 * 4);  // uniform byte offset of the group image (< 2^31: <= 8192 groups)
-            // plan 1: this task's 8 chunks inside its pair image (unit position T: 16 S, 4 M, 1 L), rows 16 .. 31 for the odd group
+            // plan 2: this task's 8 chunks inside its pair image (unit position T: 16 S, 4 M, 1 L), rows 16 .. 31 for the odd group
             const int Tpos = (BR == 0) ? (task & 15) : (BR == 1 ? 16 + (task & 3) : 20);
             const int Fb = (grp >> 1) * (kFastChunks * FCH) + Tpos * 8 * FCH + (grp & 1) * 256;
             auto store_pair = [&](const f32x4& qa, const f32x4& qb, int pair) {
-                if (FAST == 1) store_pair_bf16x3<SC1>(qa, qb, rF, lane_off + Fb + pair * 2 * FCH);
-                else store_pair_f16x2<SC1>(qa, qb, fscale, rF, lane_off + Fb + pair * 2 * FCH);
+                store_pair_f16x2<SC1>(qa, qb, fscale, rF, lane_off + Fb + pair * 2 * FCH);
             };
 
             // conv1 of position q2: 4 patches (q1) x 4 k-steps (s = kx); lane supplies v[patch][ky=g][kx=s]
@@ -436,7 +408,7 @@ struct Trunk {
                     c3[1] = MFMA16(wA3[(24 + 4 * q2 + r) * 64], a2[q2][0][r], c3[1]);
                 }
             // phase B: channels 16..23, positions (2j, 2j+1) packed into the lower / upper lane halves
-            f32x4 zq[2];  // (plan 1: the packed quads are also the third register pair of the task)
+            f32x4 zq[2];  // (plan 2: the packed quads are also the third register pair of the task)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll

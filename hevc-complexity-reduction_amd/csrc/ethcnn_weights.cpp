@@ -216,7 +216,7 @@ void pack_fc1_lane_image(const float* w_cat, float* img) {
                 }
 }
 
-// ---- FC1 plan 1 (ethcnn_fc1_fast.hip): feature order and weight image of the bf16 x 3 form.
+// ---- FC1 plan 2 (ethcnn_fc1_fast.hip): feature order and weight image of the fp16 x 2 form.
 // The trunk wave of task T (ethcnn_trunk_task.h; lane = col + 16 g) ends up holding eight full quads of features in registers:
 //   n = 0..3  conv2 position q2 = n, channels 4 g + e           k = OFF2 + slot(q2) * 24 + 4 g + e
 //   n = 4, 5  conv2 channels 16..23 of positions 2 j, 2 j + 1   k = OFF2 + slot(2 j + (g >> 1)) * 24 + 16 + 4 (g & 1) + e   (j = n - 4)
@@ -237,27 +237,6 @@ int fast_feature_k(int chunk, int kh, int idx) {
     return kOff3[br] + (by * nb + bx) * 32 + 16 * (n - 6) + 4 * g + e;
 }
 
-static inline uint16_t bf16_rne(float x) {  // fp32 -> bf16, round to nearest even (what v_cvt_pk_bf16_f32 does for finite values)
-    uint32_t u;
-    std::memcpy(&u, &x, 4);
-    if ((u & 0x7f800000u) == 0x7f800000u) return (uint16_t)(u >> 16);  // inf / nan: truncate (not produced by finite weights)
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
-static inline float bf16_f32(uint16_t h) {
-    const uint32_t u = (uint32_t)h << 16;
-    float f;
-    std::memcpy(&f, &u, 4);
-    return f;
-}
-void split_bf16x3(float x, uint16_t* p0, uint16_t* p1, uint16_t* p2) {
-    *p0 = bf16_rne(x);
-    const float r1 = x - bf16_f32(*p0);  // exact (Sterbenz-like: the rounding error of an 8-bit rounding is representable)
-    *p1 = bf16_rne(r1);
-    const float r2 = r1 - bf16_f32(*p1);
-    *p2 = bf16_rne(r2);                  // exact: at most 8 significant bits are left
-}
-
 void pack_fc1_fast_image(const float* w_cat, int plan, float scale_w, uint16_t* img) {
     const int np = fast_pieces(plan);
     for (int c = 0; c < kFastChunks; ++c)
@@ -267,14 +246,10 @@ void pack_fc1_fast_image(const float* w_cat, int plan, float scale_w, uint16_t* 
                 const int n = lane & 31, kh = lane >> 5;
                 for (int idx = 0; idx < 8; ++idx) {
                     const float w = w_cat[(size_t)fast_feature_k(c, kh, idx) * kNVec + 32 * t + n];
-                    uint16_t p[3];
-                    if (plan == 1) {
-                        split_bf16x3(w, &p[0], &p[1], &p[2]);
-                    } else {  // fp16 x 2, round to nearest even at both steps (ethcnn_spec.h::f16_rne)
-                        const float ws = w * scale_w;  // exact: a power of two, no overflow / underflow by the choice of the scale
-                        p[0] = f16_rne(ws);
-                        p[1] = f16_rne(ws - f16_f32(p[0]));
-                    }
+                    uint16_t p[2];  // fp16 x 2, round to nearest even at both steps (ethcnn_spec.h::f16_rne)
+                    const float ws = w * scale_w;  // exact: a power of two, no overflow / underflow by the choice of the scale
+                    p[0] = f16_rne(ws);
+                    p[1] = f16_rne(ws - f16_f32(p[0]));
                     for (int q = 0; q < np; ++q) rec[q * 512 + lane * 8 + idx] = p[q];
                 }
             }

@@ -519,10 +519,9 @@ class EthCnn(object):
         self._chk(self.lib.ethcnn_measure_mfma_rate(self.h, float(seconds), ctypes.byref(v)))
         return v.value
 
-    def set_fc1_plan(self, plan=1):
-        """FC1 plan: 0 = exact fp32 (default, bit-identical to the oracle); 1 = exact three-way bf16 splits / 2 = two-way fp16
-        splits on the 16-bit matrix pipe for passes that take the multi-launch path, 3 = plan 2 with the trunk's convolutions
-        as fp16 x 2 as well (as accurate against float64, NOT bit-identical; include/ethcnn.h)."""
+    def set_fc1_plan(self, plan=3):
+        """arithmetic plan of big passes: 0 = exact fp32 (default, bit-identical to the oracle); 2 = FC1 as two-way fp16 splits on the
+        16-bit matrix pipe; 3 = trunk, FC1 and heads that way (as accurate against float64, NOT bit-identical; include/ethcnn.h)."""
         self._chk(self.lib.ethcnn_set_fc1_plan(self.h, int(plan)))
 
     def fc1_plan(self):

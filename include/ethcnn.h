@@ -180,7 +180,8 @@ int ethcnn_ldp_get_state(ethcnn_ctx* ctx, float* state_out, size_t nfloats /* nc
  *                           thread, any order, each CTU row once; may be called BEFORE ethcnn_ldp_step_begin of the same frame, but
  *                           not before the previous streamed step has ended.  Every CTU row [0, ceil(height / 64)) must be
  *                           reported: kernels that wait ~1 s for a row give up, and ethcnn_ldp_step_end then fails with
- *                           ETHCNN_ERR_DEVICE (the resident state is dropped; the GPU is not left hanging).
+ *                           ETHCNN_ERR_DEVICE (the GPU is not left hanging; the state that was resident BEFORE the step stays resident,
+ *                           so the frame can be run again with ethcnn_ldp_step once its buffer is complete).
  *   ethcnn_ldp_step_end     waits; probs (the pointer given to begin) and the resident state are final when it returns ETHCNN_OK.
  * Results are bit-identical to ethcnn_ldp_step's. */
 int ethcnn_ldp_step_begin(ethcnn_ctx* ctx, const uint8_t* luma, int width, int height, ptrdiff_t pitch, int qp, int i_frame,
@@ -254,26 +255,23 @@ int ethcnn_reset_stage_times(ethcnn_ctx* ctx);
  * are equal to 1 % slower than plan 0 (the matrix pipe has no idle time to give in FC1's drain, and agent-scope hand-offs cost
  * what the boundaries did: DESIGN.md section 3), so plan 0 stays the default. */
 int ethcnn_set_fused_launch(ethcnn_ctx* ctx, int mode);
-/* FC1 plan.  FC1 ([N,2688] x [2688,448]) is 78 % of the path's arithmetic.
+/* Arithmetic plan of the big (multi-launch) All-Intra passes.  FC1 ([N,2688] x
+ * [2688,448]) is 78 % of the path's arithmetic and the exact-fp32 MFMA runs at 1/16 of the 16-bit matrix rate.
  *   0 (default)  exact fp32 on v_mfma_f32_16x16x4_f32: every result of the library is bit-identical to oracle/ethcnn_oracle.c;
- *   1 ("fast", bf16 x 3)  passes that take the multi-launch path (more than 2304 CTUs, or rows that are not 16-byte aligned) run
- *                FC1 on the BF16 matrix pipe (16x the fp32 MFMA rate) with EXACT three-way bf16 splits of both operands: the trunk
- *                writes every feature as a0 + a1 + a2 (exactly the fp32 value), W1 is split the same way at load, and the six
- *                products a_i w_j with i + j <= 2 are accumulated in fp32 (the three dropped terms are below 2^-27 of the product);
- *   2 ("fast", fp16 x 2)  the same structure with TWO fp16 pieces per operand (power-of-two scaled so that no piece can overflow:
- *                the feature bound is derived from the conv weights at load, not observed) and THREE products: h0 + h1
- *                represents the scaled fp32 value to 2^-24 relative.  Half the matrix instructions and two thirds of the bytes of
- *                plan 1;
- *   3 ("fast", fp16 x 2 + trunk)  plan 2, and the trunk's three conv layers on the 16-bit pipe as well (ethcnn_trunk_fast.hip):
- *                conv1 on the exact integer pixel sums (mean removal folded into one fma per output), conv2 / conv3 with fp16 x 2
- *                splits of activations and weights; the split features conv2 / conv3 produce are at once FC1's operands.  The
- *                fastest plan.  Features then agree with the oracle's to ~1e-6 of their scale instead of bit for bit / 2^-23.
- * Measured against float64 the sums of plans 1 and 2 are as accurate as plan 0's fmaf chains (profiles/r04_bf16x3_probe.txt:
- * the error of a 2688-term fp32 sum is set by the roundings of its accumulation), but the ORDER of the fp32 additions differs,
- * so probabilities agree with plan 0 / the oracle to about 1e-6, not bit for bit (tests: <= 1e-4, the north star's tolerance;
- * thresholded decisions may differ on knife edges only).  Everything else (trunk convolutions, heads, gates) is computed
- * exactly as in plan 0 (plan 3: heads and gates).  The single-launch small pass and the LDP path always use plan 0.  Env ETHCNN_FC1_PLAN=1|2|3 starts
- * contexts in that plan.  Takes effect with the next pass enqueued. */
+ *   2 ("fast", FC1 as fp16 x 2)  passes that take the multi-launch path (more than 2304 CTUs, or rows that are not 16-byte
+ *                aligned) run FC1 on the 16-bit matrix pipe: both operands as TWO fp16 pieces of the power-of-two scaled fp32 value
+ *                (h0 + h1 represents it to 2^-24 relative; the feature scale comes from a bound derived from the conv weights at
+ *                load, not from observation, so no piece can overflow), THREE products, fp32 accumulation;
+ *   3 ("fast", everything as fp16 x 2)  plan 2, and the trunk's three conv layers (ethcnn_trunk_fast.hip: conv1 on the exact integer
+ *                pixel sums with the mean removal folded into one fma per output, conv2 / conv3 with fp16 x 2 splits; the CTU-load
+ *                stage is folded into the trunk: one pass over the luma frames, no pixel records in HBM) and the heads' FC2 / FC3
+ *                (ethcnn_heads_fast.hip, scaled residual pieces) on the 16-bit pipe as well.  The fastest plan.
+ *   (1 was round 4's bf16 x 3 form of FC1; removed in round 5 -- slower than plan 2 and no more accurate -- and now an argument error.)
+ * Measured against float64 these sums are as accurate as plan 0's fmaf chains (profiles/r04_bf16x3_probe.txt: the error of a 2688-
+ * term fp32 sum is set by the roundings of its accumulation), but the ORDER of the fp32 additions differs, so probabilities agree
+ * with plan 0 / the oracle to about 1e-6..1e-5, not bit for bit (tests: <= 1e-4, the north star's tolerance; thresholded decisions may
+ * differ on knife edges only).  The batch gates are computed exactly in every plan.  The single-launch small pass and the LDP path
+ * always use plan 0.  Env ETHCNN_FC1_PLAN=2|3 starts contexts in that plan.  Takes effect with the next pass enqueued. */
 int ethcnn_set_fc1_plan(ethcnn_ctx* ctx, int plan);
 int ethcnn_get_fc1_plan(const ethcnn_ctx* ctx);
 /* Single-launch small pass (default on): a pass of <= 2304 CTUs (up to one 3840x2160 picture) whose rows are 16-byte aligned (width, pitch, frame stride and

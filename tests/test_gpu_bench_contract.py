@@ -76,7 +76,7 @@ def test_box_calibration_is_a_plausible_mfma_rate(pkg):
 def test_one_gpu_line_states_the_north_star_ratio_and_the_fast_plans():
     """The default (N = 1) line on a short C2 run: contract keys, `roofline` + `cpu_baseline`, the north star's ratio
     (`vs_baseline` = S3 GPU / S3 oracle port, `vs_tf_cpu_proxy`, `north_star_10x`, each naming scope / cores / kind "port"),
-    and the two opt-in FC1 plans reported BESIDE the exact headline (`fast_plan` = bf16 x 3, `fast_plan_fp16x2`) -- the headline
+    and the two opt-in plans reported BESIDE the exact headline (`fast_plan_fp16x2`, `fast_plan_fp16x2_trunk`) -- the headline
     itself stays dtype f32 and bit-exact."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c2", "--steps", "4", "--warmup", "1", "--ramp-ms", "20",
                         "--cpu-seconds", "3"], capture_output=True, text=True, env=_env(), timeout=900, cwd=ROOT)
@@ -96,11 +96,18 @@ def test_one_gpu_line_states_the_north_star_ratio_and_the_fast_plans():
     hs = d["host_scopes"]
     assert abs(d["vs_baseline"] - hs["s3_file_to_file_ctus_per_s"] / next(
         b["value"] for b in d["cpu_baselines"] if b["name"].startswith("B1 oracle") and "file scope" in b["name"])) < 1e-9
-    for key, dtype_word in (("fast_plan", "bf16x3"), ("fast_plan_fp16x2", "fp16x2")):
+    assert "fast_plan" not in d  # (round 4's bf16 x 3 plan is gone)
+    for key, dtype_word in (("fast_plan_fp16x2", "fp16x2"), ("fast_plan_fp16x2_trunk", "fp16x2")):
         fp = d[key]
         assert dtype_word in fp["dtype"] and fp["value"] > 0 and fp["roofline"]["peak"] == 2500.0
         assert fp["gate_pattern_equal"] is False or fp["max_abs_vs_exact"] <= 1e-4  # north star's tolerance
         assert fp["flips_vs_exact"] <= 2
+    # every other single-GPU BASELINE config is driver-timed by the same run (short regions, parity-checked)
+    oc = d["other_configs"]
+    assert set(oc) == {"c3", "c4", "c5"}, oc.keys()
+    for k in ("c3", "c4"):
+        assert oc[k]["value"] > 1e6 and 0.5 < oc[k]["fc1_frac"] < 1.0 and oc[k]["parity_first_frame_bit_exact"] is True, oc[k]
+    assert 10.0 < oc["c5"]["us_per_frame"] < 500.0 and oc["c5"]["parity_first_frames_bit_exact"] is True, oc["c5"]
     # side measurement: one picture host -> host (the path the in-process hook and every caller with the picture in its own memory takes)
     h2h = d["single_picture_latency"]["host_to_host"]
     for name in ("1920x1080", "3840x2160"):

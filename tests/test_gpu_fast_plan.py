@@ -1,10 +1,10 @@
-"""-m gpu: FC1 plans 1 and 2 (ethcnn_set_fc1_plan: FC1 on the 16-bit matrix pipe with split operands -- exact three-way
-bf16 splits / two-way fp16 splits of power-of-two scaled values; csrc/ethcnn_fc1_fast.hip) against the oracle.  The plans
-are opt-in and NOT bit-identical to the oracle by design (the fp32 additions happen in another order), so their bar is the
-north star's: probabilities within 1e-4 (tolerance written in every assert below; measured ~1e-6), thresholded decisions
-equal except on knife edges -- plus what makes them "not narrower arithmetic": the trunk's split features add back to the
-oracle's features (plan 1: BIT FOR BIT; plan 2: to 2^-23 relative), and the error against the float64 restatement is no
-worse than twice the exact plan's."""
+"""-m gpu: plans 2 and 3 (ethcnn_set_fc1_plan: FC1 -- plan 3: trunk, FC1 and heads -- on the 16-bit matrix pipe with two-way fp16
+splits of power-of-two scaled values; csrc/ethcnn_fc1_fast.hip, ethcnn_trunk_fast.hip, ethcnn_heads_fast.hip) against the oracle.
+The plans are opt-in and NOT bit-identical to the oracle by design (the fp32 additions happen in another order), so their bar is
+the north star's: probabilities within 1e-4 (tolerance written in every assert below; measured ~1e-6 .. 1e-5), thresholded
+decisions equal except on knife edges -- plus what makes them "not narrower arithmetic": the trunk's split features add back to the
+oracle's features (plan 2: to 2^-23 relative), and the error against the float64 restatement is no worse than twice the exact
+plan's.  (Plan 1 of round 4, bf16 x 3, was removed: test_plan_1_is_gone.)"""
 import os
 
 import numpy as np
@@ -31,7 +31,7 @@ def _mixed_ctus(rng, n):
     return ctus
 
 
-@pytest.fixture(params=[1, 2, 3], ids=["bf16x3", "fp16x2", "fp16x2+trunk"])
+@pytest.fixture(params=[2, 3], ids=["fp16x2", "fp16x2+trunk+heads"])
 def fast_ctx(pkg, request):
     c = pkg.EthCnn(device=0)
     c.set_small_pass_launch(False)  # the fast plans live in the multi-launch path; small test batches must take it too
@@ -55,9 +55,7 @@ def test_stages_under_the_fast_plans(pkg, fast_ctx, oracle, n, gain, qp):
     got = c.predict_ctus(ctus, qp)
     F = oracle.features(blob, ctus, mode=0)
     gF = c.debug_fetch(e.DBG_FEATURES, n)  # the 16-bit pieces of every feature, added back on the host
-    if plan == 1:
-        assert np.array_equal(_bits(gF), _bits(F)), "the split features are not the oracle's features: max |d| = %g" % np.abs(gF - F).max()
-    elif plan == 2:  # two fp16 pieces: 2^-24 relative while the low piece is a normal number, 2^-25 of the scaled unit below that
+    if plan == 2:  # two fp16 pieces: 2^-24 relative while the low piece is a normal number, 2^-25 of the scaled unit below that
         assert np.all(np.abs(gF - F) <= np.abs(F) * 2.0 ** -23 + 2.0 ** -30), np.abs(gF - F).max()
     else:  # plan 3: the convolutions themselves run as fp16 x 2 products with other rounding points: fp32-class agreement, relative
         # to the scale of a CTU's features (a conv output is a signed sum: its own magnitude can be far below its terms')
@@ -81,7 +79,7 @@ def test_stages_under_the_fast_plans(pkg, fast_ctx, oracle, n, gain, qp):
         e_fast = np.abs(gH1.astype(np.float64) - h1_64).max()
         e_exact = np.abs(H1.astype(np.float64) - h1_64).max()
         assert e_fast <= 2.0 * e_exact + 1e-7 * scale, (e_fast, e_exact)
-    # back to plan 0 on the same context: bit-exact again, nothing of plan 1 is left behind
+    # back to plan 0 on the same context: bit-exact again, nothing of the fast plan is left behind
     c.set_fc1_plan(0)
     assert np.array_equal(_bits(c.predict_ctus(ctus, qp)), _bits(P))
     assert np.array_equal(_bits(c.debug_fetch(e.DBG_FC1, n)), _bits(H1))
@@ -91,8 +89,9 @@ def test_stages_under_the_fast_plans(pkg, fast_ctx, oracle, n, gain, qp):
 
 
 def test_reference_graph_golden_under_the_fast_plans(fast_ctx, oracle):
-    """All golden AI sets executed through the reference's serialized graphs (2,388 CTUs): plan 1 within 1e-4 of them
-    (plan 0's own bar on these vectors is 1e-5; plan 1 is asserted to that too since it measures ~4e-6)."""
+    """All golden AI sets executed through the reference's serialized graphs (2,388 CTUs): the fast plans within 1e-4 of them
+    (plan 0's own bar on these vectors is 1e-5; plan 2 is asserted to that too since it measures ~4e-6; plan 3, with the heads on the
+    16-bit pipe under the x8 head gain of sets b / d / e, to 3e-5)."""
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, here)
@@ -107,14 +106,14 @@ def test_reference_graph_golden_under_the_fast_plans(fast_ctx, oracle):
         want = gold[tag + "_probs"]
         got = c.predict_ctus(_ctus(gold, tag), int(qp))
         total += got.shape[0]
-        assert np.abs(got - want).max() <= 1e-5 <= TOL
+        assert np.abs(got - want).max() <= (1e-5 if c.fc1_plan() == 2 else 3e-5) <= TOL
         for thr in (0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8):
-            far = np.abs(want - thr) > 1e-5
+            far = np.abs(want - thr) > 3e-5
             assert np.array_equal((got > thr)[far], (want > thr)[far])
     assert total >= 2000
 
 
-@pytest.mark.parametrize("plan", [1, 2, 3])
+@pytest.mark.parametrize("plan", [2, 3])
 @pytest.mark.parametrize("w,h,frames,qp", [(3840, 2160, 3, 32), (1920, 1080, 6, 22), (4928, 3264, 1, 27), (200, 136, 2, 37),
                                            # >= 32768 CTUs in one pass: k_fc1_fast's M tiles are cut to whole rounds and the left-over row
                                            # tiles ride as a NINTH row tile of the first M tiles (plans 2 / 3; 34,680 CTUs: 60 of 128 tiles;
@@ -164,9 +163,25 @@ def test_frames_under_the_fast_plans(pkg, oracle, w, h, frames, qp, plan):
         assert edge, "gate patterns differ without a knife-edge sub-batch maximum"
 
 
-@pytest.mark.parametrize("plan", [1, 2, 3])
+def test_plan_1_is_gone(pkg):
+    """round 4's bf16 x 3 form of FC1 was removed (dominated by plan 2 in every metric): asking for it is an argument error, and the
+    environment variable no longer selects it"""
+    import subprocess
+    import sys
+    with pkg.EthCnn(device=0) as c:
+        with pytest.raises(pkg.EthCnnError):
+            c.set_fc1_plan(1)
+        assert c.fc1_plan() == 0
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import importlib, sys; sys.path.insert(0, %r); p = importlib.import_module('hevc-complexity-reduction_amd'); "
+            "c = p.EthCnn(device=0); print(c.fc1_plan())" % root)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ETHCNN_FC1_PLAN="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == "0", (r.stdout, r.stderr[-500:])
+
+
+@pytest.mark.parametrize("plan", [2, 3])
 def test_plan_env_and_file_entry(pkg, oracle, tmp_path, plan):
-    """ETHCNN_FC1_PLAN=1|2 starts contexts in that plan; the file entry point (staging ring, several passes) takes it."""
+    """ETHCNN_FC1_PLAN=2|3 starts contexts in that plan; the file entry point (staging ring, several passes) takes it."""
     import subprocess
     import sys
     import bench

@@ -339,12 +339,23 @@ def test_ldp_step_streamed_input(pkg, oracle, lstm):
             a.ldp_step_end()
         assert 0.5 < time.time() - t0 < 10.0
         with pytest.raises(e.EthCnnError):
-            a.ldp_step(luma, w, h, 27, 2)                                      # the state of that frame was dropped
+            a.ldp_step(luma, w, h, 27, 2)                                      # frame 1 had no state before it: none is resident now
         assert np.array_equal(_bits(a.ldp_step(luma, w, h, 27, 1)), _bits(b.ldp_step(luma, w, h, 27, 1)))
         a.rows_ready(0, (h + 63) // 64)                                    # streamed again, right behind the failure
         a.ldp_step_begin(pin, w, h, 27, 2, pprobs)
         a.ldp_step_end()
         assert np.array_equal(_bits(pprobs.reshape(nctu, 21)), _bits(b.ldp_step(luma, w, h, 27, 2)))
+        # ... and in the middle of a recurrence: the state that was resident BEFORE the failed step stays resident, so the frame can be run
+        # again the plain way once its buffer is complete (what the native daemon does when a row of resi.yuv comes > 1 s late)
+        luma3 = rng.integers(0, 256, size=(h, w), dtype=np.uint8)
+        pin[:] = luma3.reshape(-1)
+        a.ldp_step_begin(pin, w, h, 27, 3, pprobs)
+        a.rows_ready(1, (h + 63) // 64)
+        with pytest.raises(e.EthCnnError, match="never reported"):
+            a.ldp_step_end()
+        want3 = b.ldp_step(luma3, w, h, 27, 3)
+        assert np.array_equal(_bits(a.ldp_step(luma3, w, h, 27, 3)), _bits(want3))
+        assert np.array_equal(_bits(a.ldp_get_state(w, h)), _bits(b.ldp_get_state(w, h)))
     finally:
         a.close()
         b.close()

@@ -24,6 +24,10 @@ unsigned short t_f16(float x) { return ethcnn::f16_rne(x); }
 float t_f16_back(unsigned short h) { return ethcnn::f16_f32(h); }
 float t_bound(const float* blob) { return ethcnn::fast_feature_bound(blob); }
 void t_pack_trunk16(const float* blob, float sa, unsigned short* w, float* c, ethcnn::Trunk16Scalars* sc) { ethcnn::pack_trunk_f16(blob, sa, w, c, sc); }
+int t_pack_heads16(const float* blob, float fbound, unsigned short* img, ethcnn::Heads16Scalars* sc) { return ethcnn::pack_heads_f16(blob, fbound, img, sc) ? 1 : 0; }
+int t_heads16_halves() { return ethcnn::kHeads16Halves; }
+int t_heads16_fc2_at(int h) { return ethcnn::heads16_fc2_at(h); }
+int t_heads16_fc3_at(int h) { return ethcnn::heads16_fc3_at(h); }
 }
 """
 
@@ -139,32 +143,25 @@ def test_host_fp16_conversion_matches_numpy(packers):
             assert packers.t_f16_back(h) == float(w)
 
 
-@pytest.mark.parametrize("plan", [1, 2])
-def test_fc1_fast_image(packers, plan):
-    """[168 chunks][14 column tiles][NP pieces][k half 2][32 columns][8]: piece q of W1[fast_feature_k(c, kh, idx)][32 t + n];
-    plan 1: three bf16 pieces that add back to the weight EXACTLY; plan 2: two fp16 pieces of the scaled weight, to 2^-24 relative"""
+def test_fc1_fast_image(packers, plan=2):
+    """[168 chunks][14 column tiles][2 pieces][k half 2][32 columns][8]: piece q of W1[fast_feature_k(c, kh, idx)][32 t + n]:
+    two fp16 pieces of the scaled weight, to 2^-24 relative"""
     rng = np.random.default_rng(plan)
     w = (rng.standard_normal((2688, 448)) * 0.03).astype(np.float32)
     w[5, 7] = 0.0
-    npieces = 3 if plan == 1 else 2
-    scale = np.float32(2.0 ** 17) if plan == 2 else np.float32(1.0)
+    npieces = 2
+    scale = np.float32(2.0 ** 17)
     out = np.empty(2688 * 448 * npieces, np.uint16)
     packers.t_fc1_fast.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_int, ctypes.c_float, ctypes.POINTER(ctypes.c_ushort)]
     packers.t_fc1_fast(_fp(w), plan, float(scale), out.ctypes.data_as(ctypes.POINTER(ctypes.c_ushort)))
     img = out.reshape(168, 14, npieces, 2, 32, 8)
     km = _fast_kmap(packers)  # [168][2][8]
     src = w[km][:, :, :, :].reshape(168, 2, 8, 14, 32).transpose(0, 3, 1, 4, 2)  # -> [c][t][kh][n][idx]
-    if plan == 1:
-        pieces = (img.astype(np.uint32) << 16).view(np.float32)
-        back = (pieces[:, :, 0] + pieces[:, :, 1]) + pieces[:, :, 2]
-        assert np.array_equal(back.view(np.uint32), src.view(np.uint32))
-        assert np.array_equal(pieces[:, :, 0], ((src.view(np.uint32) + 0x7fff + ((src.view(np.uint32) >> 16) & 1)) & 0xffff0000).view(np.float32))
-    else:
-        h = img.view(np.float16).astype(np.float32)
-        ws = src * scale
-        assert np.array_equal(h[:, :, 0], ws.astype(np.float16).astype(np.float32))
-        assert np.array_equal(h[:, :, 1], (ws - h[:, :, 0]).astype(np.float16).astype(np.float32))
-        assert np.abs((h[:, :, 0] + h[:, :, 1]) - ws).max() <= np.abs(ws).max() * 2.0 ** -23
+    h = img.view(np.float16).astype(np.float32)
+    ws = src * scale
+    assert np.array_equal(h[:, :, 0], ws.astype(np.float16).astype(np.float32))
+    assert np.array_equal(h[:, :, 1], (ws - h[:, :, 0]).astype(np.float16).astype(np.float32))
+    assert np.abs((h[:, :, 0] + h[:, :, 1]) - ws).max() <= np.abs(ws).max() * 2.0 ** -23
 
 
 def test_feature_bound_holds_on_random_ctus(packers):
@@ -256,3 +253,72 @@ def test_trunk_f16_images(packers):
                 co = 16 * t + ch
                 assert np.allclose(c[8 + t * 4 + r], np.where(co < 24, float(sa) * B2[np.minimum(co, 23)], 0.0), rtol=1e-7)
                 assert np.allclose(c[16 + t * 4 + r], float(sa) * B3[co], rtol=1e-7)
+
+
+def test_heads_f16_images(packers):
+    """plan 3 (csrc/ethcnn_heads_fast.hip): FC2 / FC3 A operands as fp16 pieces with a SCALED residual (w sw = hi + lo 2^-11) in the
+    16x16x32 MFMA's order, against the checkpoint layout; every scale a power of two; the activation scales come from bounds that hold
+    on what the oracle computes (|h1| S1 and |h2| S2 stay below 2^14: no piece can overflow); degenerate weights are refused."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ethcnn_np as oracle
+
+    class Sc(ctypes.Structure):
+        _fields_ = [("S1", ctypes.c_float * 3), ("U2", ctypes.c_float * 3), ("S2", ctypes.c_float * 3), ("U3", ctypes.c_float * 3)]
+    packers.t_bound.restype = ctypes.c_float
+    blob = oracle.synth_blob(7, 8.0)
+    tv = oracle.tensor_views(blob)
+    n_halves = packers.t_heads16_halves()
+    img = np.zeros(n_halves, np.uint16)
+    sc = Sc()
+    fb = packers.t_bound(_fp(blob))
+    packers.t_pack_heads16.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_float, ctypes.POINTER(ctypes.c_ushort), ctypes.POINTER(Sc)]
+    assert packers.t_pack_heads16(_fp(blob), fb, img.ctypes.data_as(ctypes.POINTER(ctypes.c_ushort)), ctypes.byref(sc)) == 1
+
+    def pow2(x):
+        m, _ = np.frexp(np.float64(x))
+        return m == 0.5
+    rng = np.random.default_rng(9)
+    ctus = rng.integers(0, 256, size=(64, 64, 64), dtype=np.uint8)
+    ctus[:8] = (rng.integers(0, 2, size=(8, 64, 64)) * 255).astype(np.uint8)
+    r = oracle.forward64(blob, ctus, 51)
+    lane, i = np.meshgrid(np.arange(64), np.arange(8), indexing="ij")
+    row, kg = lane & 15, lane >> 4
+    o1 = 0
+    for h, tag in enumerate(("64", "32", "16")):
+        n1, n2, n3 = 64 << h, 48 << h, (1, 4, 16)[h]
+        nt = n2 // 16
+        W2, W3 = tv["h_fc2__%s__w" % tag], tv["y_conv_flat__%s__w" % tag]
+        S1, U2, S2, U3 = sc.S1[h], sc.U2[h], sc.S2[h], sc.U3[h]
+        assert all(pow2(v) for v in (S1, U2, S2, U3))
+        sw2, sw3 = 1.0 / (U2 * S1), 1.0 / (U3 * S2)
+        assert np.abs(W2[:n1]).max() * sw2 <= 2.0 ** 14 < np.abs(W2[:n1]).max() * sw2 * 2
+        assert np.abs(W3[:n2]).max() * sw3 <= 2.0 ** 14 < np.abs(W3[:n2]).max() * sw3 * 2
+        # the guaranteed bounds: what the float64 restatement computes stays below 2^14 after scaling
+        h1 = r["H1"][:, o1:o1 + n1]
+        assert np.abs(h1).max() * S1 <= 2.0 ** 14
+        qn = 51.0 / 51.0
+        h2 = np.concatenate([h1, np.full((len(h1), 1), qn)], 1) @ W2.astype(np.float64) + tv["h_fc2__%s__b" % tag]
+        h2 = np.maximum(0.2 * h2, h2)
+        assert np.abs(h2).max() * S2 <= 2.0 ** 14
+        f2 = img[packers.t_heads16_fc2_at(h):packers.t_heads16_fc2_at(h) + n1 * n2 * 2].view(np.float16).astype(np.float64).reshape(n1 // 32, nt, 2, 64, 8)
+        for c in range(n1 // 32):
+            for j in range(nt):
+                want = W2[32 * c + 8 * kg + i, 16 * j + row].astype(np.float64) * sw2
+                hi, lo = f2[c, j, 0], f2[c, j, 1]
+                assert np.array_equal(hi, want.astype(np.float32).astype(np.float16).astype(np.float64))
+                assert np.abs(hi + lo / 2048.0 - want).max() <= 2.0 ** 14 * 2.0 ** -22
+        steps = (nt + 1) // 2
+        f3 = img[packers.t_heads16_fc3_at(h):packers.t_heads16_fc3_at(h) + steps * 1024].view(np.float16).astype(np.float64).reshape(steps, 2, 64, 8)
+        for p in range(steps):
+            tile = 2 * p + (i >> 2)
+            k = 16 * tile + 4 * kg + (i & 3)
+            ok = (row < n3) & (tile < nt)
+            want = np.where(ok, W3[np.minimum(k, n2 - 1), np.minimum(row, n3 - 1)].astype(np.float64) * sw3, 0.0)
+            assert np.abs(f3[p, 0] + f3[p, 1] / 2048.0 - want).max() <= 2.0 ** 14 * 2.0 ** -22
+            assert (f3[p, 0][~ok] == 0).all() and (f3[p, 1][~ok] == 0).all()
+        o1 += n1
+    # degenerate weights (an all-zero FC3 matrix): refused -- the library then keeps the exact heads
+    z = blob.copy()
+    oracle.tensor_views(z)["y_conv_flat__16__w"][:] = 0.0
+    assert packers.t_pack_heads16(_fp(z), fb, img.ctypes.data_as(ctypes.POINTER(ctypes.c_ushort)), ctypes.byref(sc)) == 0

@@ -12,7 +12,10 @@
  * CLOCKS_PER_SEC printed with %.3f) and was the only encoder-side number so far -- against any daemon that serves the
  * protocol in the working directory (the Python daemon resi_to_cu_depth_LDP.py, the native tools/resi_to_cu_depth_ldp).
  *
- *   ldp_client <workdir> <width> <height> <qp> <frames> [--seed N] [--gap-us N] [--digest FILE] [--keep-resi]
+ *   ldp_client <workdir> <width> <height> <qp> <frames> [--seed N] [--gap-us N] [--digest FILE] [--keep-resi] [--slow-us T]
+ *
+ * --slow-us T: every handshake longer than T microseconds is printed with its phases and CLOCK_MONOTONIC stamps ("slow POC n: ...",
+ * on stderr) so that it can be laid beside the daemon's own record of the same frame (resi_to_cu_depth_ldp --trace-slow).
  *
  * Frames are seeded synthetic residual pictures (8-bit, Laplace-like around 128; a new one per frame unless --keep-resi).
  * Output: one line "ldp_client WxH frames N: handshake p50 .. p90 .. p99 .. max .. us (command.dat -> cu_depth.dat read);
@@ -62,6 +65,7 @@ int main(int argc, char** argv) {
     const char* dir = argv[1];
     const int w = atoi(argv[2]), h = atoi(argv[3]), qp = atoi(argv[4]), frames = atoi(argv[5]);
     long gap_us = 0;
+    double slow_us = 0.0;
     const char* digest = NULL;
     int keep_resi = 0;
     rng_state = 12345;
@@ -70,6 +74,7 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--gap-us") && i + 1 < argc) gap_us = atol(argv[++i]);
         else if (!strcmp(argv[i], "--digest") && i + 1 < argc) digest = argv[++i];
         else if (!strcmp(argv[i], "--keep-resi")) keep_resi = 1;
+        else if (!strcmp(argv[i], "--slow-us") && i + 1 < argc) slow_us = atof(argv[++i]);
         else { fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
     }
     if (w <= 0 || h <= 0 || frames <= 0) { fprintf(stderr, "bad geometry / frame count\n"); return 2; }
@@ -101,6 +106,7 @@ int main(int argc, char** argv) {
         if (!fp) { fprintf(stderr, "cannot write command.dat\n"); return 1; }
         fprintf(fp, "%d %d %d %d [end]", poc, w, h, qp);
         fclose(fp);
+        const double t_cmd = now_us();
         FILE* fs = fopen("pred_start.sig", "w+");
         if (!fs) { fprintf(stderr, "cannot create pred_start.sig\n"); return 1; }
         fclose(fs);
@@ -110,6 +116,7 @@ int main(int argc, char** argv) {
         while ((fe = fopen("pred_end.sig", "r")) == NULL) {
             if ((++spins & 0xfff) == 0 && now_us() - t_wait0 > 30e6) { fprintf(stderr, "no answer from the daemon for 30 s (POC %d)\n", poc); return 3; }
         }
+        const double t_seen = now_us();
         int rr = -1;
         while (rr < 0) {
             if (fe) { fclose(fe); fe = NULL; }
@@ -123,6 +130,10 @@ int main(int argc, char** argv) {
         if (got != nctu * 21) { fprintf(stderr, "cu_depth.dat holds %zu floats, expected %zu (POC %d)\n", got, nctu * 21, poc); return 3; }
         t_hand[f] = t2 - t1;
         t_full[f] = t2 - t0;
+        if (slow_us > 0.0 && f >= 5 && t2 - t1 > slow_us)
+            fprintf(stderr, "slow POC %d: handshake %.0f us = remove + command.dat %.0f | create pred_start.sig %.0f | wait for pred_end.sig %.0f | "
+                            "remove it + read cu_depth.dat %.0f ; monotonic us: pred_start.sig created %.0f, pred_end.sig seen %.0f\n",
+                    poc, t2 - t1, t_cmd - t1, t_wait0 - t_cmd, t_seen - t_wait0, t2 - t_seen, t_wait0, t_seen);
         if (fd) {
             uint64_t hsh = 1469598103934665603ull;
             const uint8_t* b = (const uint8_t*)depth;

@@ -29,7 +29,7 @@
  *     ONLY when --accept-stale is given; otherwise the daemon reports the error, answers nothing and exits non-zero
  *     (the Python daemon does the same: a silently wrong recurrence is worse than a stopped encode).
  *
- *   resi_to_cu_depth_ldp [--max-frames N] [--idle-timeout SECONDS] [--quiet] [--accept-stale] [--trace] [--spin] [--no-stream]   (cwd = HM-LDP's bin/)
+ *   resi_to_cu_depth_ldp [--max-frames N] [--idle-timeout SECONDS] [--quiet] [--accept-stale] [--trace] [--trace-slow US] [--spin] [--no-stream]   (cwd = HM-LDP's bin/)
  *
  * Environment as the Python daemon: ETHCNN_SYNTHETIC_SEED / ETHCNN_HEAD_GAIN (seeded weights when a trained blob is absent:
  * model_LDP_2000000_qp22~37.dat.data is not in the reference repository), ETHCNN_DEVICE.
@@ -299,15 +299,18 @@ int main(int argc, char** argv) {
     int quiet = 0, accept_stale = 0, trace = 0, no_stream_opt = 0, streamed_frames = 0, spin = 0;
     int sig_pending = 0; /* a frame has been accepted whose pred_start.sig is still there (it is removed off the critical path) */
     int n_trace = 0;
+    double trace_slow = 0.0; /* --trace-slow US: frames that took this daemon longer than US microseconds are printed stage by stage */
+    double bad_cmd_since = -1.0;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--max-frames") && i + 1 < argc) max_frames = atol(argv[++i]);
         else if (!strcmp(argv[i], "--idle-timeout") && i + 1 < argc) idle_timeout = atof(argv[++i]);
         else if (!strcmp(argv[i], "--quiet")) quiet = 1;
         else if (!strcmp(argv[i], "--accept-stale")) accept_stale = 1;
         else if (!strcmp(argv[i], "--trace")) trace = 1;
+        else if (!strcmp(argv[i], "--trace-slow") && i + 1 < argc) trace_slow = atof(argv[++i]) * 1e-6;
         else if (!strcmp(argv[i], "--spin")) spin = 1; /* busy-wait for pred_start.sig as the reference's daemon does (a core at 100 %) */
         else if (!strcmp(argv[i], "--no-stream")) no_stream_opt = 1; /* read resi.yuv first, then predict (A/B runs) */
-        else { fprintf(stderr, "usage: resi_to_cu_depth_ldp [--max-frames N] [--idle-timeout S] [--quiet] [--accept-stale] [--trace] [--spin] [--no-stream]\n"); return 2; }
+        else { fprintf(stderr, "usage: resi_to_cu_depth_ldp [--max-frames N] [--idle-timeout S] [--quiet] [--accept-stale] [--trace] [--trace-slow US] [--spin] [--no-stream]\n"); return 2; }
     }
     ethcnn_ctx* ctx = NULL;
     ethcnn_options opt;
@@ -358,7 +361,15 @@ int main(int argc, char** argv) {
         }
         int i_frame, w, h, qp;
         const double ts0 = now_s();
-        if (get_command(&i_frame, &w, &h, &qp) != 0 || i_frame < 0) continue; /* command.dat still being written */
+        if (get_command(&i_frame, &w, &h, &qp) != 0 || i_frame < 0) {
+            /* command.dat still being written -- or never going to be right: do not burn a core on it forever, and let --idle-timeout end
+             * the daemon */
+            if (bad_cmd_since < 0.0) bad_cmd_since = ts0;
+            if (idle_timeout >= 0.0 && ts0 - bad_cmd_since > idle_timeout) break;
+            if (ts0 - bad_cmd_since > 1e-3) { struct timespec ts = {0, 20000}; nanosleep(&ts, NULL); }
+            continue;
+        }
+        bad_cmd_since = -1.0;
         const int qp_last = qp_seq;
         qp_seq = qp;
         sig_pending = 1;
@@ -434,6 +445,13 @@ int main(int argc, char** argv) {
         if (sidecar(tagbuf) != 0 || prepare_cu_depth(nctu * 21 * sizeof(float)) != 0) { fprintf(stderr, "resi_to_cu_depth_ldp: cannot write state.dat.idx / cu_depth.dat: %s\n", strerror(errno)); if (step_rc == ETHCNN_OK && !no_stream) (void)ethcnn_ldp_step_end(ctx); goto out; }
         if (step_rc == ETHCNN_OK) step_rc = no_stream ? ethcnn_ldp_step(ctx, luma, w, h, w, qp_seq, i_frame, state_in, probs) : ethcnn_ldp_step_end(ctx);
         if (read_rc != 0) { fprintf(stderr, "resi_to_cu_depth_ldp: resi.yuv: short read (%zu luma bytes wanted)\n", npx); goto out; }
+        if (step_rc != ETHCNN_OK && !no_stream) {
+            /* streamed frame: a row came more than ~1 s late (a cold or remote resi.yuv) and the kernels gave up.  The buffer is complete by
+             * now and the library kept the previous frame's state resident: answer the frame the plain way instead of leaving HM spinning
+             * on pred_end.sig */
+            fprintf(stderr, "resi_to_cu_depth_ldp: frame %d: %s -- running it again on the complete picture\n", i_frame, ethcnn_last_error(ctx));
+            step_rc = ethcnn_ldp_step(ctx, luma, w, h, w, qp_seq, i_frame, state_in, probs);
+        }
         if (step_rc != ETHCNN_OK) {
             fprintf(stderr, "resi_to_cu_depth_ldp: frame %d: %s\n", i_frame, ethcnn_last_error(ctx));
             goto out;
@@ -459,6 +477,11 @@ int main(int argc, char** argv) {
         state_sig = sig_of("state.dat");
         ++n_total;
         streamed_frames += stream;
+        if (trace_slow > 0.0 && n_total > 5 && ts5 - ts0 > trace_slow)
+            fprintf(stderr, "slow frame %d: %.0f us from detection to the ending signal = command.dat + buffers %.0f | state %.0f | resi.yuv read %.0f "
+                            "(begin %.0f) | sidecar + step %.0f | cu_depth.dat + pred_end.sig %.0f ; monotonic us: detected %.0f, ending signal %.0f\n",
+                    i_frame, 1e6 * (ts5 - ts0), 1e6 * (ts1 - ts0), 1e6 * (ts2 - ts1), 1e6 * (ts3 - ts2), 1e6 * (ts2b - ts2), 1e6 * (ts4 - ts3),
+                    1e6 * (ts5 - ts4), 1e6 * ts0, 1e6 * ts5);
         if (n_total > 5 && n_trace < TRACE_N) {
             const double ts6 = now_s();
             const double v[7] = {ts1 - ts0, ts2 - ts1, ts3 - ts2, ts2b - ts2, ts4 - ts3, ts5 - ts4, ts6 - ts5};
