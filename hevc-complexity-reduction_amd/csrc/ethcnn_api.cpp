@@ -895,8 +895,7 @@ static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, lo
     // a previous pass long enough to hide anything under, and the cross-stream event costs ~10 us of a 75 us call
     // Plan 3 (round 5): the CTU-load stage is folded into the trunk's S branch (k1_trunk_f16_fold) -- no tile launch, nothing for a
     // side stream to run.  (Experiments build: ETHCNN_PLAN3_FOLD=0 keeps round 4's tile stage beside FC1 for the A/B.)
-    // 2 (default): the whole trunk behind one pass over the frames (k1_trunk_f16_foldall; L tasks as a small second launch); 3: the same
-    // with the L task inside the block (first form); 1: S branch folded, M / L as a second launch
+    // 2 (default): the whole trunk behind one pass over the frames (k1_trunk_f16_foldall); 1: S branch folded, M / L as a second launch
     static const int fold3_knob = [] { const char* e = dev_env("ETHCNN_PLAN3_FOLD"); return e ? std::atoi(e) : 2; }();
     const bool fold3 = c->fc1_plan == 3 && fold3_knob != 0 && c->tile_wait_rows == nullptr;
     const bool side_tile = c->overlap != 0 && n >= kPipelineMinCtus && !fold3;
@@ -970,7 +969,7 @@ static int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, lo
           launch_trunk_f16(w, c->dw, n, c->stream, /*ml_only=*/true);
       } else if (fold3) {
           static const int bpc = [] { const char* e = dev_env("ETHCNN_PLAN3_FOLD_BLOCKS"); return e ? std::atoi(e) : 2; }();
-          launch_trunk_f16_foldall(d_luma, g, ctu0, n, w, c->dw, sync_words(n, (int)nchunks), c->stream, bpc, /*l_out=*/fold3_knob != 3);
+          launch_trunk_f16_foldall(d_luma, g, ctu0, n, w, c->dw, sync_words(n, (int)nchunks), c->stream, bpc);
       } else if (fast == 3) launch_trunk_f16(w, c->dw, n, c->stream);
       else launch_trunk(w, c->dw, n, false, c->stream, fast); }
     LAUNCH_OK("trunk");

@@ -40,15 +40,14 @@ void launch_trunk(const Workspace& ws, const DeviceWeights& w, int n, bool resi,
 // k1 with the CTU-load stage folded in (A/B form, experiments build: ethcnn_trunk.hip); needs small_pass_ok-style 16-byte alignment
 void launch_trunk_direct(const uint8_t* d_luma, const FrameGeom& g, long ctu0, const Workspace& ws, const DeviceWeights& w, int n, hipStream_t s);
 // k1, plan 3 (ethcnn_trunk_fast.hip): the same trunk with its convolutions on the 16-bit matrix pipe (fp16 x 2 splits) -> featb in plan 2's form
-void launch_trunk_f16(const Workspace& ws, const DeviceWeights& w, int n, hipStream_t s, bool ml_only = false, bool l_only = false);
+void launch_trunk_f16(const Workspace& ws, const DeviceWeights& w, int n, hipStream_t s, bool ml_only = false);
 // plan 3 with the CTU-load stage folded in: S tasks straight from the luma frames + the XM / XL records of the M / L tasks
 // (which follow as launch_trunk_f16(..., ml_only = true)); clears the pass's n_flags sync words like launch_tile
 void launch_trunk_f16_fold(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, const Workspace& ws, const DeviceWeights& w, int n_flags,
                            hipStream_t s);
-// the whole plan-3 trunk behind one pass over the frames: S and M tasks of a group in one block (l_out: the L unit's records -- 512 B per
-// CTU -- go to ws.xl and its tasks follow as a small second launch; else wave 2 of the block runs it: no pixel records in HBM at all)
+// the whole plan-3 trunk behind one pass over the frames (S, M and L tasks of a group in one block; no pixel records in HBM at all)
 void launch_trunk_f16_foldall(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, const Workspace& ws, const DeviceWeights& w, int n_flags,
-                              hipStream_t s, int blocks_per_cu = 2, bool l_out = true);
+                              hipStream_t s, int blocks_per_cu = 2);
 // k2: feat -> h1 (bias + leaky-ReLU fused); out may be ws.h1 or a caller buffer (resi vectors)
 void launch_fc1(const Workspace& ws, const DeviceWeights& w, int n, float* out, hipStream_t s);
 // k2, plans 2 / 3 (ethcnn_fc1_fast.hip): featb -> h1 on the 16-bit matrix pipe: three fp16 products per fp32 product (two-way splits of

@@ -352,21 +352,19 @@ __global__ __launch_bounds__(256) void k1_trunk_f16_fold(const uint8_t* __restri
 
 // ---- the whole trunk of plan 3 behind ONE pass over the luma frames (round 5).  k1_trunk_f16_fold above still writes and re-reads
 // 2,560 B of XM / XL records per CTU and pays a second launch for the M / L tasks.  Here a block takes a whole GROUP: it walks the four
-// slabs, every wave runs the slab's S task of its unit column, and the pooled records of the M units are built from the same LDS slab
-// straight into the registers of the wave that will run that task.
-//   LOUT = false (first form): waves 0 / 1 take the M units (uy, ux = w) after slabs 1 and 3, wave 2 the L unit after slab 3: 21 tasks
-//           in 24 wave slots per group (the block's slab cadence is its busiest wave's: 6 task times per group).
-//   LOUT = true (shipped): every wave takes ONE M unit -- waves 0 / 1 those of the upper quadrants after slab 1, waves 2 / 3 the lower
-//           ones after slab 3 -- five tasks each, no idle slot; the L unit's records (512 B per CTU, 1/8 of what the S / M records
-//           were) go to XL as in the tile stage and the L tasks follow as a small second launch (k1_trunk_f16 with only L blocks).
-// HBM traffic of the trunk: 4,096 B in, 10,752 B of feature pieces out per CTU (+ 2 x 512 B of XL records with LOUT).  77.5 KB of LDS
-// (three / two branches' fragments + the slab), 255 VGPRs: two blocks per CU.
-template <bool FAST, bool LOUT>
+// slabs, every wave runs the slab's S task of its unit column, and the pooled records of the M / L units are built from the same LDS slab
+// straight into the registers of the wave that will run that task -- waves 0 / 1 the M units (uy, ux = w) after slabs 1 and 3, wave 2
+// the L unit after slab 3.  HBM traffic of the trunk: 4,096 B in, 10,752 B of feature pieces out per CTU (1.51 GB per C3 step against
+// 2.87 GB for tile stage + trunk in round 4).  21 tasks in 24 wave slots per group; 77.5 KB of LDS (three branches' fragments + the
+// slab), 255 VGPRs: two blocks per CU.
+// (Measured and not kept, profiles/r05_plan3_fold.txt: one M task per wave -- 20 tasks in 20 slots -- with the L unit's records written
+// to XL and its tasks as a small second launch: the second launch costs more than the idle slots, trunk 0.436 against 0.410 ms.)
+template <bool FAST>
 __global__ __launch_bounds__(256) void k1_trunk_f16_foldall(const uint8_t* __restrict__ luma, int width, int height, long pitch, long frame_stride,
-                                                            int cw, int nctu, int f0, int r0, int N, uint4* __restrict__ XL,
-                                                            int* __restrict__ gate_flags, int n_flags, const uint16_t* __restrict__ wimg,
-                                                            const float* __restrict__ cfrag, Trunk16Scalars sc, char* __restrict__ F) {
-    __shared__ __attribute__((aligned(16))) char lds[LOUT ? 2 : 3][20 * 1024];
+                                                            int cw, int nctu, int f0, int r0, int N, int* __restrict__ gate_flags, int n_flags,
+                                                            const uint16_t* __restrict__ wimg, const float* __restrict__ cfrag, Trunk16Scalars sc,
+                                                            char* __restrict__ F) {
+    __shared__ __attribute__((aligned(16))) char lds[3][20 * 1024];
     __shared__ uint32_t tile[16 * kSlabCtuPitch];
     if (blockIdx.x == 0)  // (what the tile stage does on the way: the pass's sync area, read by the heads / gate launches behind us)
         for (int i = threadIdx.x; i < n_flags; i += 256) gate_flags[i] = 0;
@@ -374,26 +372,22 @@ __global__ __launch_bounds__(256) void k1_trunk_f16_foldall(const uint8_t* __res
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     Trunk16<0>::stage(wimg, lds[0]);
     Trunk16<1>::stage(wimg + kTrunk16Halves, lds[1]);
-    if (!LOUT) Trunk16<2>::stage(wimg + 2 * kTrunk16Halves, lds[LOUT ? 0 : 2]);
+    Trunk16<2>::stage(wimg + 2 * kTrunk16Halves, lds[2]);
     Trunk16<0> tk;
     tk.load_consts(wimg, cfrag, sc.C1[0], sc.U2[0], sc.U3[0], F, N, lds[0]);
     __syncthreads();
     const int ngroups = (N + 15) >> 4;
     int grp = blockIdx.x;
     if (grp >= ngroups) return;
-    const __amdgpu_buffer_rsrc_t rL = __builtin_amdgcn_make_buffer_rsrc(XL, 0, -1, 0x00020000);
     SlabLoader L;
     uint4 pre[4];
     L.init32(t, luma, width, frame_stride, cw, nctu, f0, r0, N, grp * 16);
     L.template load<FAST>(0, pre, width, height, pitch);
 #pragma unroll 1
     for (; grp < ngroups; grp += gridDim.x) {
-        uint4 rawx[8];  // the record of this wave's M unit, rebuilt per slab pair (first form, wave 2: the L unit's, over the four slabs)
+        uint4 rawx[8];  // waves 0 / 1: the record of M unit (uy, w), rebuilt per slab pair; wave 2: the L unit's, over the four slabs
 #pragma unroll 1
         for (int uy = 0; uy < 2; ++uy) {
-            // which M unit of this slab pair (quadrant row uy) the wave builds and runs: LOUT: waves 2 uy, 2 uy + 1; else waves 0, 1
-            const bool m_role = LOUT ? ((w >> 1) == uy) : (w < 2);
-            const int m_ux = LOUT ? (w & 1) : w;
 #pragma unroll
             for (int sh = 0; sh < 2; ++sh) {
                 const int s = 2 * uy + sh;
@@ -402,21 +396,16 @@ __global__ __launch_bounds__(256) void k1_trunk_f16_foldall(const uint8_t* __res
                 uint4 raw[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) raw[j] = slab_xs_record(tile, tk.col, tk.g, j, w);
-                if (m_role) {
+                if (w < 2) {
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) rawx[4 * sh + jj] = slab_xm_record(tile, tk.col, tk.g, 4 * sh + jj, m_ux);
-                } else if (!LOUT && w == 2) {
+                    for (int jj = 0; jj < 4; ++jj) rawx[4 * sh + jj] = slab_xm_record(tile, tk.col, tk.g, 4 * sh + jj, w);
+                } else if (w == 2) {
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {  // record j = 4 uy + 2 m + sh (the columns depend on m only)
                         const uint4 rec = slab_xl_record(tile, tk.col, tk.g, 2 * m + sh);
                         if (uy == 0) rawx[2 * m + sh] = rec;
                         else rawx[4 + 2 * m + sh] = rec;
                     }
-                }
-                if (LOUT && t < 128) {  // the slab's two XL records, as the tile stage writes them (threads 0..127: m = t >> 6)
-                    const int lane = t & 63, j = 4 * uy + 2 * (t >> 6) + sh;
-                    const uint4 v = slab_xl_record(tile, lane & 15, lane >> 4, j);
-                    __builtin_amdgcn_raw_buffer_store_b128((u32x4_t){v.x, v.y, v.z, v.w}, rL, (grp * 512 + 64 * j + lane) * 16, 0, 0);
                 }
                 __syncthreads();  // the slab is consumed: the next one may overwrite it
                 tk.task(raw, grp * 16 + 4 * s + w, [&]() {
@@ -431,31 +420,25 @@ __global__ __launch_bounds__(256) void k1_trunk_f16_foldall(const uint8_t* __res
                     }
                 });
             }
-            if (m_role) {
+            if (w < 2) {
                 Trunk16<1> tm;
                 tm.load_consts(wimg + kTrunk16Halves, cfrag + kTrunk16Consts, sc.C1[1], sc.U2[1], sc.U3[1], F, N, lds[1]);
-                tm.task(rawx, grp * 4 + 2 * uy + m_ux, []() {});
+                tm.task(rawx, grp * 4 + 2 * uy + w, []() {});
             }
         }
-        if (!LOUT && w == 2) {
+        if (w == 2) {
             Trunk16<2> tl;
-            tl.load_consts(wimg + 2 * kTrunk16Halves, cfrag + 2 * kTrunk16Consts, sc.C1[2], sc.U2[2], sc.U3[2], F, N, lds[LOUT ? 0 : 2]);
+            tl.load_consts(wimg + 2 * kTrunk16Halves, cfrag + 2 * kTrunk16Consts, sc.C1[2], sc.U2[2], sc.U3[2], F, N, lds[2]);
             tl.task(rawx, grp, []() {});
         }
     }
 }
 
-void launch_trunk_f16(const Workspace& ws, const DeviceWeights& w, int n, hipStream_t s, bool ml_only, bool l_only) {
+void launch_trunk_f16(const Workspace& ws, const DeviceWeights& w, int n, hipStream_t s, bool ml_only) {
     // tasks per group: 16 S, 4 M, 1 L; blocks per CU by registers (see the resource remark of the build); same branch shares as k1_trunk
     const int groups = (n + 15) / 16, tS = groups * 16, tM = groups * 4, tL = groups;
     auto blocks = [](int tasks, int budget) { int b = (tasks + 3) / 4; return b < budget ? b : budget; };
     constexpr int per_cu = 4;
-    if (l_only) {  // (the S and M tasks ran in k1_trunk_f16_foldall<.., true>): the L tasks alone, three resident blocks per CU
-        const int bL = blocks(tL, 256 * 3);
-        hipLaunchKernelGGL(k1_trunk_f16, dim3(bL), dim3(256), 0, s, ws.xs, ws.xm, ws.xl, n, 0, 0, w.trunk16_w, w.trunk16_c, w.trunk16_s,
-                           reinterpret_cast<char*>(ws.featb));
-        return;
-    }
     // ml_only (the S branch ran in k1_trunk_f16_fold): the whole grid to the M / L tasks, 4 : 1, three resident blocks per CU (~8 tasks
     // per wave: a fourth, non-resident block per CU would be a second round for a quarter of the work)
     const int bS = ml_only ? 0 : blocks(tS, 193 * per_cu), bM = blocks(tM, ml_only ? 205 * 3 : 50 * per_cu), bL = blocks(tL, ml_only ? 51 * 3 : 13 * per_cu);
@@ -464,21 +447,18 @@ void launch_trunk_f16(const Workspace& ws, const DeviceWeights& w, int n, hipStr
 }
 
 void launch_trunk_f16_foldall(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, const Workspace& ws, const DeviceWeights& w, int n_flags,
-                              hipStream_t s, int blocks_per_cu, bool l_out) {
+                              hipStream_t s, int blocks_per_cu) {
     const int groups = (n + 15) / 16;
     const int cap = 256 * (blocks_per_cu > 0 ? blocks_per_cu : 2);
     const int blocks = groups < cap ? groups : cap;
     const bool fast = (g.width % 16 == 0) && (g.pitch % 16 == 0) && (g.frame_stride % 16 == 0) && (reinterpret_cast<uintptr_t>(d_luma) % 16 == 0);
     const int f0 = (int)(ctu0 / g.nctu), r0 = (int)(ctu0 % g.nctu);
-#define FOLDALL(FASTV, LOUTV)                                                                                                              \
-    hipLaunchKernelGGL((k1_trunk_f16_foldall<FASTV, LOUTV>), dim3(blocks), dim3(256), 0, s, d_luma, g.width, g.height, g.pitch, g.frame_stride, \
-                       g.cw, g.nctu, f0, r0, n, ws.xl, ws.flags, n_flags, w.trunk16_w, w.trunk16_c, w.trunk16_s, reinterpret_cast<char*>(ws.featb))
-    if (fast && l_out) FOLDALL(true, true);
-    else if (fast) FOLDALL(true, false);
-    else if (l_out) FOLDALL(false, true);
-    else FOLDALL(false, false);
-#undef FOLDALL
-    if (l_out) launch_trunk_f16(ws, w, n, s, false, /*l_only=*/true);
+    if (fast)
+        hipLaunchKernelGGL(k1_trunk_f16_foldall<true>, dim3(blocks), dim3(256), 0, s, d_luma, g.width, g.height, g.pitch, g.frame_stride, g.cw, g.nctu,
+                           f0, r0, n, ws.flags, n_flags, w.trunk16_w, w.trunk16_c, w.trunk16_s, reinterpret_cast<char*>(ws.featb));
+    else
+        hipLaunchKernelGGL(k1_trunk_f16_foldall<false>, dim3(blocks), dim3(256), 0, s, d_luma, g.width, g.height, g.pitch, g.frame_stride, g.cw, g.nctu,
+                           f0, r0, n, ws.flags, n_flags, w.trunk16_w, w.trunk16_c, w.trunk16_s, reinterpret_cast<char*>(ws.featb));
 }
 
 void launch_trunk_f16_fold(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, const Workspace& ws, const DeviceWeights& w, int n_flags,
