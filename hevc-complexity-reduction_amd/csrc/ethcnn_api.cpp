@@ -179,12 +179,12 @@ struct ethcnn_ctx {
     bool lgate_clean = false;
     int lgate_n = -1;        // frame size the area's layout was last zeroed for
     int lstm_epoch = 0;      // claim tag of the one-launch frame kernel (ethcnn_lstm.hip)
-    int lstm_one_launch = 1; // cells + heads of an LDP frame as ONE dataflow launch (env ETHCNN_LSTM_ONE_LAUNCH=0: two launches)
+    int lstm_one_launch = 1; // cells + heads of an LDP frame as ONE dataflow launch (experiments build only: env ETHCNN_LSTM_ONE_LAUNCH=0: two launches)
     int tile_blocks = 256;   // blocks of the side-stream tile stage: one per CU (ETHCNN_TILE_BLOCKS)
     unsigned pass_idx = 0;   // parity selects the buffer set
     int last_parity = 0;     // of the last pass (debug_fetch reads its h1)
     int small_launch = 1;    // 1 = a small pass (one picture) is ONE launch (ethcnn_small.hip); 0 = tile / trunk / FC1 / heads / gate
-                             // launches (ethcnn_set_small_pass_launch, env ETHCNN_SMALL=0)
+                             // launches (ethcnn_set_small_pass_launch, experiments build only: env ETHCNN_SMALL=0)
     bool luma_over_pcie = false;  // set around a call whose luma pointer is page-locked HOST memory used in place (ethcnn_ldp_step, one
                                   // picture through ethcnn_predict_luma): the single-launch pass's direct gather reads every pixel three
                                   // times (S / M / L units) in 8-16 byte pieces -- fine in HBM, slow across PCIe -- so such a call runs the
@@ -202,7 +202,7 @@ struct ethcnn_ctx {
     uint16_t* dw_trunk16 = nullptr;             // plan 3: the trunk's A operands as fp16 x 2 pieces + its per-lane constants (one allocation)
     uint16_t* dw_heads16 = nullptr;             // plan 3: FC2 / FC3 A operands as fp16 x 2 pieces (kHeads16Halves)
     int last_fast = 0;       // the FC1 plan of the last pass (debug_fetch reads the features of plans 1 / 2 from ws.featb)
-    int fused = 0;           // 1 = big passes run FC1 + heads + gates as ONE launch (ethcnn_set_fused_launch, env ETHCNN_FUSED=1).
+    int fused = 0;           // 1 = big passes run FC1 + heads + gates as ONE launch (ethcnn_set_fused_launch, experiments build only: env ETHCNN_FUSED=1).
                              // Off by default: measured equal-to-1 % slower than the separate launches
     // completion word (page-locked host memory): the last block of a latency-path launch stores the launch's sequence number
     // there and the host spins on it instead of calling hipStreamSynchronize (~5 us sooner, scripts/ubench/launch_rtt.hip)
@@ -221,14 +221,14 @@ struct ethcnn_ctx {
     struct LumaPending { bool open = false, direct = false; float* probs = nullptr; size_t out_bytes = 0; } ai;  // ethcnn_predict_luma_begin ... _end
     unsigned done_seq = 0;     // last number handed out
     unsigned done_armed = 0;   // != 0: the LAST operation enqueued on the main stream stores this number when all its outputs are final
-    int done_sync = 1;         // env ETHCNN_DONE_WORD=0: always hipStreamSynchronize (A/B runs)
+    int done_sync = 1;         // experiments build only: env ETHCNN_DONE_WORD=0: always hipStreamSynchronize (A/B runs)
     int cus = 0;             // compute units of the device
     int gate_fold = 0;       // 1 = the heads launch applies the gates itself (sub-batch arrival counters); 0 = k5_gate launch behind it.
-                             // Off by default: measured equal (single pictures) to 0.4 % slower (C3) than the separate launch (env ETHCNN_GATE_FOLD=1)
+                             // Off by default: measured equal (single pictures) to 0.4 % slower (C3) than the separate launch (experiments build only: env ETHCNN_GATE_FOLD=1)
     bool main_dirty = false; // main-stream work since e_main was last recorded (single-picture passes, LDP steps): the event is
                              // recorded lazily, by the next PIPELINED pass -- not as a barrier packet behind every small call
     int overlap = 1;         // 1 = pass pipeline on (tile stage on its own stream, beside FC1 of the previous pass);
-                             // 0 = every stage on the main stream (ethcnn_set_pass_pipeline, env ETHCNN_OVERLAP=0)
+                             // 0 = every stage on the main stream (ethcnn_set_pass_pipeline, experiments build only: env ETHCNN_OVERLAP=0)
     int max_ctus = kMaxCtusPerPass;
     int host_threads_opt = 0;  // ethcnn_options.host_threads (0 = automatic, see host_pool)
     int last_n = 0;  // CTUs of the last pass (debug_fetch)

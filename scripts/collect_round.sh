@@ -2,7 +2,7 @@
 # copies the judged summaries of the last scripts/gpu_round.sh call from gpurun_out/ (scratch) to profiles/ (tracked)
 # usage: scripts/collect_round.sh r02
 set -eu
-R=${1:-r04}
+R=${1:-r05}
 cd "$(dirname "$0")/.."
 for wl in c2 c3 c4 c5; do [ -s gpurun_out/bench_$wl.json ] && cp gpurun_out/bench_$wl.json profiles/${R}_bench_$wl.json; done
 for wl in c2 c3; do
@@ -23,6 +23,7 @@ if [ -s gpurun_out/latency_mid_now.txt ]; then { grep "^#" profiles/${R}_latency
 [ -s gpurun_out/dist_smoke.json ] && cp gpurun_out/dist_smoke.json profiles/${R}_dist_smoke_2ranks_1gpu.json
 [ -s gpurun_out/power_probe.txt ] && cp gpurun_out/power_probe.txt profiles/${R}_power_probe.txt
 if [ -s gpurun_out/ldp_handshake.txt ]; then { grep "^#" gpurun_out/ldp_handshake.txt; grep "^# native\|^# first form\|^#   \|^#    \|^# Boxes" profiles/${R}_ldp_handshake.txt 2>/dev/null; grep -v "^#" gpurun_out/ldp_handshake.txt; } > /tmp/_hs.txt && cp /tmp/_hs.txt profiles/${R}_ldp_handshake.txt; fi
+[ -s gpurun_out/step_traffic.json ] && cp gpurun_out/step_traffic.json profiles/step_traffic.json
 python - "$R" <<'PY'
 import csv, glob, collections, json, sys
 R = sys.argv[1]

@@ -70,15 +70,15 @@ if fe is not None and wr is not None:
                 "bytes_per_launch": int(fe*1024*2 + wr*1024), "fetch_size_kb_reported": fe, "write_size_kb_reported": wr,
                 "steps_averaged": n1, "algorithmic_bytes_per_launch": n*2688*4 + 2688*448*4 + n*448*4,
                 "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of `python bench.py --workload %s --no-cpu-baseline --no-host-scopes --steps 5 --warmup 1` (scripts/gpu_round.sh), summed over the FC1 dispatches of a step; FETCH_SIZE x2 (gfx950 correction)" % wl}}
-    # the fast plans' FC1 kernel (bench.py runs all three plans): one dispatch per step each
-    for plan in (1, 2):
+    # the fast plans' FC1 kernel (bench.py runs plans 2 and 3, both with k_fc1_fast<2, ..>): one dispatch per step each
+    for plan in (2,):
         def fast(tag, counter):
             v = [float(r["Counter_Value"]) for f in glob.glob("gpurun_out/pmc_%s_%s/**/*counter_collection.csv" % (wl, tag), recursive=True)
                  for r in csv.DictReader(open(f)) if "k_fc1_fast<%d" % plan in r["Kernel_Name"] and r["Counter_Name"] == counter]
             return (sum(v) / len(v), len(v)) if v else (None, 0)
         (ffe, k1), (fwr, k2) = fast("FETCH_SIZE", "FETCH_SIZE"), fast("WRITE_SIZE", "WRITE_SIZE")
         if ffe is not None and fwr is not None:
-            npieces = 3 if plan == 1 else 2
+            npieces = 2
             out["%s_plan%d" % (wl, plan)] = {"kernel_source_blob": bench.fc1_fast_source_stamp(),
                 "bytes_per_launch": int(ffe*1024*2 + fwr*1024), "fetch_size_kb_reported": ffe, "write_size_kb_reported": fwr, "steps_averaged": k1,
                 "algorithmic_bytes_per_launch": n*2688*2*npieces + 2688*448*2*npieces + n*448*4,
@@ -88,6 +88,8 @@ PY
 }
 PMCS=("FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA"); pmc_passes
 if [ "$WL" = c3 ]; then WL=c2; PMCS=("FETCH_SIZE" "WRITE_SIZE"); pmc_passes; WL=c3; fi
+# whole-step HBM traffic per plan (bench.py's `hbm` object reads the committed copy)
+bash scripts/gpu_step_traffic.sh 2>&1 | tail -4
 head -12 gpurun_out/prof_$WL/${WL}_kernel_stats.csv
 python - <<'PY'
 import csv, glob, collections
