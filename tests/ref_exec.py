@@ -41,7 +41,7 @@ import tf_shim
 tf_shim.install()
 script = %(script)r
 def _report(*a):
-    json.dump({"ops": sorted(tf_shim.OPS_USED), "restored": tf_shim.RESTORED}, open("shim_report.json", "w"))
+    json.dump({"ops": sorted(tf_shim.OPS_USED), "restored": tf_shim.RESTORED, "kernels": tf_shim.KERNELS}, open("shim_report.json", "w"))
     if a:
         os._exit(0)
 signal.signal(signal.SIGTERM, _report)
@@ -54,9 +54,10 @@ finally:
 """
 
 
-def _child(script, argv, cwd, **popen):
+def _child(script, argv, cwd, kernels="numpy", **popen):
     code = _BOOT % {"tests": HERE, "script": script, "argv": [str(a) for a in argv]}
-    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")  # never leave .pyc files next to the reference's sources
+    # never leave .pyc files next to the reference's sources; kernels: tf_shim's op kernels (numpy restatements | torch's own)
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", TF_SHIM_KERNELS=kernels, OMP_NUM_THREADS="4")
     return subprocess.Popen([sys.executable, "-c", code], cwd=cwd, env=env, **popen)
 
 
@@ -66,7 +67,7 @@ def write_cnn_bundle(prefix, blob):
     write_bundle(prefix, [(n, np.array(v)) for n, v in oracle.tensor_views(np.asarray(blob, dtype=np.float32)).items()])
 
 
-def run_ai(workdir, yuv_bytes, w, h, qp, thr_text, blobs_by_band):
+def run_ai(workdir, yuv_bytes, w, h, qp, thr_text, blobs_by_band, kernels="numpy"):
     """blobs_by_band: {22|27|32|37: float32 blob} -> bundles under the four names video_to_cu_depth.py:126-133 restores.
     Returns (cu_depth.dat as float32 [n,21], report dict, stdout text)."""
     os.makedirs(workdir, exist_ok=True)
@@ -79,7 +80,7 @@ def run_ai(workdir, yuv_bytes, w, h, qp, thr_text, blobs_by_band):
     for stale in ("cu_depth.dat", "shim_report.json"):
         if os.path.exists(os.path.join(workdir, stale)):
             os.remove(os.path.join(workdir, stale))
-    p = _child(os.path.join(REF_AI_BIN, "video_to_cu_depth.py"), ["in.yuv", w, h, qp], workdir,
+    p = _child(os.path.join(REF_AI_BIN, "video_to_cu_depth.py"), ["in.yuv", w, h, qp], workdir, kernels=kernels,
                stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     out, _ = p.communicate(timeout=1800)
     text = out.decode(errors="replace")
@@ -92,7 +93,7 @@ def run_ai(workdir, yuv_bytes, w, h, qp, thr_text, blobs_by_band):
 class LdpDaemon(object):
     """the reference's resi_to_cu_depth_LDP.py daemon in `workdir`, driven as HM-LDP drives it"""
 
-    def __init__(self, workdir, thr_text, cnn_blob, lstm_prefixes):
+    def __init__(self, workdir, thr_text, cnn_blob, lstm_prefixes, kernels="numpy"):
         """lstm_prefixes: {file name the daemon restores: existing bundle prefix} (symlinked into workdir)"""
         self.dir = workdir
         os.makedirs(workdir, exist_ok=True)
@@ -108,7 +109,7 @@ class LdpDaemon(object):
             if os.path.exists(self._p(stale)):
                 os.remove(self._p(stale))
         self.log = open(self._p("daemon.log"), "wb")
-        self.proc = _child(os.path.join(REF_LDP_BIN, "resi_to_cu_depth_LDP.py"), [], workdir,
+        self.proc = _child(os.path.join(REF_LDP_BIN, "resi_to_cu_depth_LDP.py"), [], workdir, kernels=kernels,
                            stdout=self.log, stderr=subprocess.STDOUT)
 
     def _p(self, name):

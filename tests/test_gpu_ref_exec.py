@@ -1,6 +1,7 @@
 """-m gpu: the HIP path against what THE REFERENCE'S OWN PYTHON FILES wrote (tests/golden/ref_exec_golden.npz, produced
 in the build container by running video_to_cu_depth.py / resi_to_cu_depth_LDP.py over tests/tf_shim.py -- see
-tests/test_ref_exec.py for what that does and does not pin).  Nothing here reads /root/reference.
+tests/test_ref_exec.py for what that does and does not pin; ref_exec_golden_torch.npz = the same runs with PyTorch's own
+fp32 CPU kernels inside the tf.* calls, checked beside it at 3e-5).  Nothing here reads /root/reference.
 
 AI: the drop-in command line in a directory holding Thr_info.txt and the four model bundles, exactly the reference's
 file contract -> cu_depth.dat.  LDP: ethcnn_ldp_step over the recurrence (state resident in HBM), the reference's real
@@ -13,7 +14,7 @@ import sys
 import numpy as np
 import pytest
 
-from test_ref_exec import AI_TAGS, GOLDEN, TOL, ai_case, gen, ldp_inputs, thr13
+from test_ref_exec import AI_TAGS, GOLDEN, GOLDEN_TORCH, TOL, TOL_TORCH, ai_case, gen, ldp_inputs, thr13
 from tfckpt_writer import write_bundle
 
 pytestmark = pytest.mark.gpu
@@ -28,6 +29,11 @@ AI_MODEL_NAMES = {22: "model_2000000_qp20~25.dat", 27: "model_2000000_qp25~30.da
 @pytest.fixture(scope="module")
 def gold():
     return np.load(GOLDEN)
+
+
+@pytest.fixture(scope="module")
+def gold_torch():
+    return np.load(GOLDEN_TORCH)
 
 
 @pytest.fixture(scope="module")
@@ -49,7 +55,7 @@ def _workdir(tmp_path, model_dir, thr_text, luma_frames):
 
 
 @pytest.mark.parametrize("tag", AI_TAGS)
-def test_drop_in_command_line_matches_the_reference_scripts_output(gold, oracle, model_dir, tmp_path, tag):
+def test_drop_in_command_line_matches_the_reference_scripts_output(gold, gold_torch, oracle, model_dir, tmp_path, tag):
     w, h, nf, qp, luma, blob = ai_case(gold, tag)
     _workdir(tmp_path, model_dir, str(gold[tag + "_thr"]), luma)
     # the Python launcher HM's unchanged hook runs; for the big frames also the C99 tool over the same ABI
@@ -64,6 +70,9 @@ def test_drop_in_command_line_matches_the_reference_scripts_output(gold, oracle,
         assert got.shape == want.shape
         assert np.array_equal(got == 0, want == 0), "gate pattern differs from the reference run"
         assert np.abs(got - want).max() <= TOL
+        # the same run of the reference's script with torch's fp32 kernels behind the tf.* calls
+        assert str(gold_torch[tag + "_thr"]) == str(gold[tag + "_thr"])
+        assert np.array_equal(got == 0, gold_torch[tag + "_probs"] == 0) and np.abs(got - gold_torch[tag + "_probs"]).max() <= TOL_TORCH
         # and the usual bar: bit-exact against the oracle on the same inputs
         t1, t2 = thr13(gold, tag)
         ora = oracle.predict_frames(blob, luma, w, h, nf, qp, t1, t2)
@@ -71,7 +80,7 @@ def test_drop_in_command_line_matches_the_reference_scripts_output(gold, oracle,
 
 
 @pytest.mark.parametrize("tag", ["ldp_a", "ldp_b"])
-def test_ldp_step_matches_the_reference_daemon(pkg, gold, tag):
+def test_ldp_step_matches_the_reference_daemon(pkg, gold, gold_torch, tag):
     w, h, qp, cnn, lstm, frames, i_frames = ldp_inputs(gold)
     t1, t2 = thr13(gold, tag)
     with pkg.EthCnn(device=0) as c:
@@ -83,9 +92,12 @@ def test_ldp_step_matches_the_reference_daemon(pkg, gold, tag):
             want = gold[tag + "_probs"][k]
             assert np.array_equal(P == 0, want == 0), (tag, i_frame)
             assert np.abs(P - want).max() <= TOL, (tag, i_frame)
+            wt = gold_torch[tag + "_probs"][k]
+            assert np.array_equal(P == 0, wt == 0) and np.abs(P - wt).max() <= TOL_TORCH, (tag, i_frame)
             if tag == "ldp_a":
                 S = c.ldp_get_state(w, h)
                 assert np.abs(S.reshape(-1) - gold["ldp_a_state"][k].reshape(-1)).max() <= TOL, i_frame
+                assert np.abs(S.reshape(-1) - gold_torch["ldp_a_state"][k].reshape(-1)).max() <= TOL_TORCH, i_frame
 
 
 @pytest.mark.parametrize("native", [False, True])
