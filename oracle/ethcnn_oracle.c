@@ -9,6 +9,15 @@
  * TensorFlow binary*.  The reference's arithmetic lives in TensorFlow 1.x (not vendored, not
  * installed here, no network), every trained ETH-CNN weight blob is absent from /root/reference
  * (.MISSING_LARGE_BLOBS) and the reference holds no golden vectors for this path.  What IS pinned:
+ *   - THE REFERENCE'S OWN PYTHON FILES, EXECUTED in the build container (tests/ref_exec.py runs
+ *     video_to_cu_depth.py as __main__ with its real argv and resi_to_cu_depth_LDP.py as the daemon it is,
+ *     over tests/tf_shim.py, a stand-in for the ~30 TensorFlow calls they make): every line between
+ *     `import tensorflow` and the output bytes -- zero pad, tiling loop, 1024 sub-batching, layer wiring,
+ *     qp / efs columns, both tf.cond gates, QP-band restore, LSTM state slicing, the protocol -- is the
+ *     reference's; the arithmetic inside each tf.* op is a stand-in, twice: numpy restatements
+ *     (tests/golden/ref_exec_golden.npz; this file <= 2.4e-6) and PyTorch's own fp32 CPU kernels
+ *     (ref_exec_golden_torch.npz; this file <= 1.2e-5 canonical, 4.3e-6 literal), identical gate patterns
+ *     (tests/test_ref_exec.py).  What stays unpinned is TensorFlow's own op kernels, nothing else;
  *   - the MetaGraphDefs TF 1.4.1 wrote from the authors' graphs (the .meta files next to the
  *     checkpoints), executed node by node without TensorFlow by tests/meta_graph.py: golden
  *     vectors tests/golden/meta_exec_golden.npz (gen_meta_exec_golden.py); this file agrees to
