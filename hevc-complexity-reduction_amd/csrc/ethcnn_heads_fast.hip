@@ -184,7 +184,7 @@ __device__ __forceinline__ void head_pass_f16(char* smem, const float* __restric
 }
 
 template <bool GATE>
-__global__ __launch_bounds__(256) void k_heads_f16(const float* __restrict__ H1, HeadsParams hp, Heads16Params fp, float qn, int N, GateIndex gi,
+__global__ __launch_bounds__(256, 3) void k_heads_f16(const float* __restrict__ H1, HeadsParams hp, Heads16Params fp, float qn, int N, GateIndex gi,
                                                    float thr1, float thr2, float* __restrict__ H2, float* __restrict__ logits,
                                                    float* __restrict__ raw, float* __restrict__ probs, int* __restrict__ flags, int nchunks) {
     __shared__ __attribute__((aligned(16))) char smem[kHeads16Stages * kHeads16Stage];  // 48 KB

@@ -10,9 +10,10 @@
 // positions.
 //   conv1 (K = 16 taps): the pixel SUMS themselves are the B operand -- small integers, exact in fp16 (S: bytes, M: 2x2 sums
 //          <= 1020; L: 4x4 sums <= 4080 as two digits 16 hi + lo) -- of v_mfma_f32_16x16x16_f16; weights as two fp16 pieces: every
-//          product is exact, and  sum w (c s - mean) + b  =  c sum(w s) - mean sum(w) + b  is applied to the accumulator with one
-//          fma per value (sum(w) per channel is a constant of the weights).  No per-pixel conversion arithmetic beyond building
-//          the halves (one v_perm / v_or + one v_pk_add_f16 per two pixels).
+//          product is exact, and  sum w (c s - mean) + b  =  sum((c w) s) + (b - mean sum(w)):  the pieces are those of c w (one
+//          rounding of the weight) and the accumulator starts at the per-task constant, so conv1 costs no VALU per output at all
+//          (sum(w) per channel is a constant of the weights).  No per-pixel conversion arithmetic beyond building the halves (one
+//          v_perm / v_or + one v_pk_add_f16 per two pixels).
 //   conv2 (K = 64) / conv3 (K = 96): activations scaled by a power of two and split into two fp16 pieces (hi = fp16(v),
 //          lo = fp16(v - hi): 2^-24 relative), weights likewise at load; three products per k step (hi W0, lo W0, hi W1).
 //          conv2's outputs ARE features: their pieces (feature scale of plan 2) are at once conv3's B operand and what is
@@ -29,6 +30,27 @@
 
 namespace ethcnn {
 
+#ifdef TRUNK16_STAMPS  // probe build only (scripts/ubench/trunk16_probe.hip): shader-clock stamps of one wave's way through the kernel
+__device__ unsigned long long g_t16_stamps[2][4][512];
+__device__ int g_t16_block[2] = {0, 1};
+struct T16Stamper {
+    unsigned long long* p = nullptr;
+    int n = 0;
+    __device__ __forceinline__ void init() {
+        const int sel = (int)blockIdx.x == g_t16_block[0] ? 0 : ((int)blockIdx.x == g_t16_block[1] ? 1 : -1);
+        if (sel >= 0 && (threadIdx.x & 63) == 0) p = g_t16_stamps[sel][threadIdx.x >> 6];
+    }
+    __device__ __forceinline__ void operator()(int tag) {
+        if (p && n < 512) p[n++] = ((unsigned long long)tag << 56) | (__builtin_readcyclecounter() & 0x00ffffffffffffffull);
+    }
+};
+#define T16_STAMP(st, tag) (st)(tag)
+#define T16_TASK_STAMP(tag) do { if (stp) (*stp)(tag); } while (0)
+#else
+#define T16_STAMP(st, tag)
+#define T16_TASK_STAMP(tag)
+#endif
+
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -42,7 +64,8 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo
         const f16x2 h = __builtin_convertvector((f32x2){v[2 * i], v[2 * i + 1]}, f16x2);
         hi[i] = __builtin_bit_cast(unsigned, h);
         // v - hi with the half read straight out of the packed register (v_fma_mix_f32: hi * -1.0 + v, exact like the subtraction):
-        // one instruction instead of v_cvt_f32_f16 + v_sub_f32
+        // one instruction instead of v_cvt_f32_f16 + v_sub_f32.  (v_fma_mixlo_f16 / v_fma_mixhi_f16 -- the difference rounded to half in the
+        // same instruction, one instruction less per pair, same bits -- measured SLOWER: trunk 0.425 against 0.40 ms, profiles/r05_trunk16_issue_bound.txt)
         float r0, r1;
         asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi[i]), "v"(v[2 * i]));
         asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi[i]), "v"(v[2 * i + 1]));
@@ -51,6 +74,25 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo
     }
 }
 __device__ __forceinline__ float lrelu1(float h) { return fmaxf(0.2f * h, h); }
+// four accumulator values -> leaky-ReLU(acc * u + b) with the affine step and the 0.2 h product as packed fp32 instructions
+// (v_pk_fma_f32 / v_pk_mul_f32: two values per issue slot; same IEEE results as the scalar forms) -- the task is bound by VALU issue
+// v_max_f32 as it is: fmaxf() on a raw MFMA result makes the compiler canonicalise the operand first (one more v_max per value)
+__device__ __forceinline__ float vmax(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ void affine_lrelu4(const f32x4 acc, const float u, const float (&b)[4], float* v) {
+    const f32x2 uu = {u, u};
+    const f32x2 h01 = __builtin_elementwise_fma((f32x2){acc[0], acc[1]}, uu, (f32x2){b[0], b[1]});
+    const f32x2 h23 = __builtin_elementwise_fma((f32x2){acc[2], acc[3]}, uu, (f32x2){b[2], b[3]});
+    const f32x2 t01 = h01 * 0.2f, t23 = h23 * 0.2f;
+    v[0] = vmax(t01[0], h01[0]); v[1] = vmax(t01[1], h01[1]); v[2] = vmax(t23[0], h23[0]); v[3] = vmax(t23[1], h23[1]);
+}
+__device__ __forceinline__ void lrelu4(const f32x4 h, float* v) {
+    const f32x2 t01 = (f32x2){h[0], h[1]} * 0.2f, t23 = (f32x2){h[2], h[3]} * 0.2f;
+    v[0] = vmax(t01[0], h[0]); v[1] = vmax(t01[1], h[1]); v[2] = vmax(t23[0], h[2]); v[3] = vmax(t23[1], h[3]);
+}
 
 // two packed 16-bit integers n < 1024 -> two halves holding n exactly: 0x6400 | n is the half 1024 + n
 __device__ __forceinline__ unsigned minus_1024(unsigned two_halves) {
@@ -74,6 +116,9 @@ struct Trunk16 {
     int lane, col, g, lane_off, N;
     float C1, U2, U3;
     __amdgpu_buffer_rsrc_t rF;
+#ifdef TRUNK16_STAMPS
+    T16Stamper* stp = nullptr;
+#endif
 
     // conv2 / conv3 A fragments of the branch -> LDS (20 KB); every thread of the 256-thread block; the caller puts a barrier behind it
     static __device__ __forceinline__ void stage(const uint16_t* __restrict__ wimg, char* lds) {
@@ -121,12 +166,17 @@ struct Trunk16 {
         T += __shfl_xor(T, 16);
         T += __shfl_xor(T, 32);
         const float mean = px_value<false>(T, 256 * POOL * POOL) * (SCALE * (1.0f / 256.0f));  // the exact plan's block mean
-        float hb[4];
+        f32x4 hb;  // S1 (b1 - mean sum(w)): conv1's accumulators START here (the weight pieces carry c255 S1, ethcnn_weights.cpp), so that
+                   // what the matrix pipe leaves in them is conv1's output before the leaky-ReLU -- no affine step per value
 #pragma unroll
-        for (int r = 0; r < 4; ++r) hb[r] = fmaf(mean, m1[r], b1s[r]);  // S1 (b1 - mean sum(w))
+        for (int r = 0; r < 4; ++r) hb[r] = fmaf(mean, m1[r], b1s[r]);
 
         const int grp = (BR == 0) ? (task >> 4) : (BR == 1 ? (task >> 2) : task);  // wave-uniform
+#ifdef TRUNK16_PROBE_NO_STORE  // probe build only (scripts/build_variant.sh): the whole task without its feature stores (N < 0 never holds)
+        const bool valid = grp * 16 + col < N && N < 0;
+#else
         const bool valid = grp * 16 + col < N;
+#endif
         const int Tpos = (BR == 0) ? (task & 15) : (BR == 1 ? 16 + (task & 3) : 20);
         const int Fb = (grp >> 1) * (kFastChunks * FCH) + Tpos * 8 * FCH + (grp & 1) * 256;
 
@@ -137,7 +187,7 @@ struct Trunk16 {
             f32x4 acc1[4];
 #pragma unroll
             for (int q1 = 0; q1 < 4; ++q1) {
-                acc1[q1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                acc1[q1] = hb;
                 if (BR == 0) {
                     const unsigned wq = q1 == 0 ? raw[q2].x : (q1 == 1 ? raw[q2].y : (q1 == 2 ? raw[q2].z : raw[q2].w));
                     // bytes kx = 0..3 of row ky = g -> halves 1024 + byte (v_perm with the constant 0x64 as high bytes), then - 1024
@@ -167,8 +217,8 @@ struct Trunk16 {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 float v[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = lrelu1(fmaf(acc1[2 * s + (i >> 2)][i & 3], C1, hb[i & 3]));
+                lrelu4(acc1[2 * s], v);
+                lrelu4(acc1[2 * s + 1], v + 4);
                 split8(v, bhi[s], blo[s]);
             }
             // ---- conv2 of position q2: two M tiles (channels 0..15, 16..23 + pad), two k steps, three products each
@@ -184,11 +234,15 @@ struct Trunk16 {
                     acc2[t] = MFMA32H(w1, __builtin_bit_cast(h8, bhi[s]), acc2[t]);
                 }
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) a2f[q2][t][r] = lrelu1(fmaf(acc2[t][r], U2, b2s[t][r]));  // features, in plan 2's feature scale
+            for (int t = 0; t < 2; ++t) {  // features, in plan 2's feature scale
+                float v[4];
+                affine_lrelu4(acc2[t], U2, b2s[t], v);
+                a2f[q2][t] = (f32x4){v[0], v[1], v[2], v[3]};
+            }
         }
+        T16_TASK_STAMP(3);
         mid();  // the raw registers are dead now: the next record is fetched under the rest
+        T16_TASK_STAMP(4);
         // ---- the task's four register pairs (ethcnn_weights.cpp::fast_feature_k): split once -- stored for FC1 AND fed to conv3
         u32x4 phi[3], plo[3];
 #pragma unroll
@@ -215,6 +269,7 @@ struct Trunk16 {
                 __builtin_amdgcn_raw_buffer_store_b128(plo[p], rF, lane_off + Fb + p * 2 * FCH + 1024, 0, 0);
             }
         }
+        T16_TASK_STAMP(5);
         // ---- conv3: k steps 0, 1 = channels 0..15 of positions (0, 1), (2, 3); k step 2 = the packed quads
         f32x4 acc3[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -229,10 +284,8 @@ struct Trunk16 {
             }
         {
             float v[8];
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[4 * t + r] = lrelu1(fmaf(acc3[t][r], U3, b3s[t][r]));
+            affine_lrelu4(acc3[0], U3, b3s[0], v);
+            affine_lrelu4(acc3[1], U3, b3s[1], v + 4);
             u32x4 h3, l3;
             split8(v, h3, l3);
             if (valid) {
@@ -360,7 +413,7 @@ __global__ __launch_bounds__(256) void k1_trunk_f16_fold(const uint8_t* __restri
 // (Measured and not kept, profiles/r05_plan3_fold.txt: one M task per wave -- 20 tasks in 20 slots -- with the L unit's records written
 // to XL and its tasks as a small second launch: the second launch costs more than the idle slots, trunk 0.436 against 0.410 ms.)
 template <bool FAST>
-__global__ __launch_bounds__(256) void k1_trunk_f16_foldall(const uint8_t* __restrict__ luma, int width, int height, long pitch, long frame_stride,
+__global__ __launch_bounds__(256, 2) void k1_trunk_f16_foldall(const uint8_t* __restrict__ luma, int width, int height, long pitch, long frame_stride,
                                                             int cw, int nctu, int f0, int r0, int N, int* __restrict__ gate_flags, int n_flags,
                                                             const uint16_t* __restrict__ wimg, const float* __restrict__ cfrag, Trunk16Scalars sc,
                                                             char* __restrict__ F) {
@@ -375,6 +428,11 @@ __global__ __launch_bounds__(256) void k1_trunk_f16_foldall(const uint8_t* __res
     Trunk16<2>::stage(wimg + 2 * kTrunk16Halves, lds[2]);
     Trunk16<0> tk;
     tk.load_consts(wimg, cfrag, sc.C1[0], sc.U2[0], sc.U3[0], F, N, lds[0]);
+#ifdef TRUNK16_STAMPS
+    T16Stamper st;
+    st.init();
+    tk.stp = &st;
+#endif
     __syncthreads();
     const int ngroups = (N + 15) >> 4;
     int grp = blockIdx.x;
@@ -385,21 +443,26 @@ __global__ __launch_bounds__(256) void k1_trunk_f16_foldall(const uint8_t* __res
     L.template load<FAST>(0, pre, width, height, pitch);
 #pragma unroll 1
     for (; grp < ngroups; grp += gridDim.x) {
+        const int r = w;  // (rotating the M / L roles over the waves from group to group -- SIMDs 0 / 1 run 6 tasks per group, SIMD 3 four -- was
+                          // measured: no change, profiles/r05_trunk16_issue_bound.txt)
         uint4 rawx[8];  // waves 0 / 1: the record of M unit (uy, w), rebuilt per slab pair; wave 2: the L unit's, over the four slabs
 #pragma unroll 1
         for (int uy = 0; uy < 2; ++uy) {
 #pragma unroll
             for (int sh = 0; sh < 2; ++sh) {
                 const int s = 2 * uy + sh;
+                T16_STAMP(st, 0);
                 L.to_lds(tile, pre);
+                T16_STAMP(st, 1);
                 __syncthreads();
+                T16_STAMP(st, 2);
                 uint4 raw[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) raw[j] = slab_xs_record(tile, tk.col, tk.g, j, w);
-                if (w < 2) {
+                if (r < 2) {
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) rawx[4 * sh + jj] = slab_xm_record(tile, tk.col, tk.g, 4 * sh + jj, w);
-                } else if (w == 2) {
+                    for (int jj = 0; jj < 4; ++jj) rawx[4 * sh + jj] = slab_xm_record(tile, tk.col, tk.g, 4 * sh + jj, r);
+                } else if (r == 2) {
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {  // record j = 4 uy + 2 m + sh (the columns depend on m only)
                         const uint4 rec = slab_xl_record(tile, tk.col, tk.g, 2 * m + sh);
@@ -408,7 +471,11 @@ __global__ __launch_bounds__(256) void k1_trunk_f16_foldall(const uint8_t* __res
                     }
                 }
                 __syncthreads();  // the slab is consumed: the next one may overwrite it
+                T16_STAMP(st, 6);
                 tk.task(raw, grp * 16 + 4 * s + w, [&]() {
+#ifdef TRUNK16_PROBE_NO_LOAD  // probe build only: the pixels of the first slab over and over (how much of the task waits for the next slab?)
+                    if (N < 0)
+#endif
                     if (s < 3) {
                         L.template load<FAST>(s + 1, pre, width, height, pitch);
                     } else {
@@ -420,16 +487,20 @@ __global__ __launch_bounds__(256) void k1_trunk_f16_foldall(const uint8_t* __res
                     }
                 });
             }
-            if (w < 2) {
+            if (r < 2) {
                 Trunk16<1> tm;
                 tm.load_consts(wimg + kTrunk16Halves, cfrag + kTrunk16Consts, sc.C1[1], sc.U2[1], sc.U3[1], F, N, lds[1]);
-                tm.task(rawx, grp * 4 + 2 * uy + w, []() {});
+                T16_STAMP(st, 7);
+                tm.task(rawx, grp * 4 + 2 * uy + r, []() {});
+                T16_STAMP(st, 8);
             }
         }
-        if (w == 2) {
+        if (r == 2) {
             Trunk16<2> tl;
             tl.load_consts(wimg + 2 * kTrunk16Halves, cfrag + 2 * kTrunk16Consts, sc.C1[2], sc.U2[2], sc.U3[2], F, N, lds[2]);
+            T16_STAMP(st, 9);
             tl.task(rawx, grp, []() {});
+            T16_STAMP(st, 10);
         }
     }
 }

@@ -322,19 +322,22 @@ void pack_trunk_f16(const float* blob, float scale_a, uint16_t* w_out, float* c_
             bound1 = std::max(bound1, sabs);  // |input| <= 1
         }
         // conv1 weights are multiplied by pixel SUMS up to 255 (S), 1020 (M), 255 / 15 (L digits): exact products need no headroom,
-        // only the scaled pieces must stay finite: 2^10 leaves room for the x 16 copy of the L branch
-        const float s1w = std::exp2f(10.0f - std::ceil(std::log2((float)m1)));
+        // only the pieces must stay finite.  They are the pieces of  w * (c255 / pool^2 * S1)  (one rounding of the weight): the
+        // accumulator then holds conv1's output in the activation scale S1 without an affine step per value (ethcnn_trunk_fast.hip);
+        // |w| c255 S1 <= bound1 S1 / 255 <= 2^14 / 255, so the x 16 copy of the L branch stays far below 65504
         const float s2w = pow2_scale(m2), s3w = pow2_scale(m3);
         const float S1 = pow2_scale(bound1 * 1.0001);
         const int pool = br == 0 ? 1 : (br == 1 ? 2 : 4);
         const float c255s = (1.0f / 255.0f) * (1.0f / (float)(pool * pool));
-        sc->C1[br] = c255s * (1.0f / s1w) * S1;  // powers of two around c255s: exact
+        const float k1 = c255s * S1;  // S1 a power of two: exact
+        sc->C1[br] = k1;
+        (void)m1;
         sc->U2[br] = scale_a / (S1 * s2w);
         sc->U3[br] = 1.0f / s3w;
         for (int lane = 0; lane < 64; ++lane) {
             const int row = lane & 15, kb = lane >> 4;
             for (int i = 0; i < 4; ++i) {  // conv1: k = 4 kb + i = (ky = kb, kx = i)
-                const float v = W1[(kb * 4 + i) * 16 + row] * s1w;
+                const float v = W1[(kb * 4 + i) * 16 + row] * k1;
                 uint16_t hi, lo, hi16, lo16;
                 f16x2(v, &hi, &lo);
                 f16x2(v * 16.0f, &hi16, &lo16);

@@ -183,8 +183,8 @@ def test_feature_bound_holds_on_random_ctus(packers):
 
 def test_trunk_f16_images(packers):
     """plan 3 (csrc/ethcnn_trunk_fast.hip): the trunk's A operands as fp16 x 2 pieces in MFMA order, the per-lane constants and the
-    per-branch scalars of pack_trunk_f16 against the checkpoint layout: every scale a power of two, pieces add back to the scaled
-    weight to 2^-22, fragment (lane, slot) -> (tap / patch / channel) maps as the kernel's comments say, constants = -S1 sum(w),
+    per-branch scalars of pack_trunk_f16 against the checkpoint layout: every scale a power of two (conv1's pieces carry c255 / pool^2
+    times the activation scale S1 instead: the accumulator is conv1's output), pieces add back to the scaled weight to 2^-22, fragment (lane, slot) -> (tap / patch / channel) maps as the kernel's comments say, constants = -S1 sum(w),
     S1 b1, sa b2, sa b3."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -219,9 +219,11 @@ def test_trunk_f16_images(packers):
         w = halves[br * H:(br + 1) * H]
         c = cimg[br * C:(br + 1) * C].reshape(24, 64).astype(np.float64)
         S1 = c[4, 0] / B1[0]
-        s1w, s2w, s3w = float(c255s) * S1 / sc.C1[br], float(sa) / (S1 * sc.U2[br]), 1.0 / sc.U3[br]
-        for v in (S1, s1w, s2w, s3w):
+        s2w, s3w = float(sa) / (S1 * sc.U2[br]), 1.0 / sc.U3[br]
+        for v in (S1, s2w, s3w):
             assert pow2(v), (br, v)
+        s1w = float(np.float32(c255s) * np.float32(S1))  # conv1: w * (c255 / pool^2 * S1), rounded once to fp32, then split
+        assert sc.C1[br] == s1w
         assert np.abs(W1).max() * s1w * 16 < 65504 and np.abs(W2).max() * s2w <= 2 ** 14 and np.abs(W3).max() * s3w <= 2 ** 14
         f1 = w[:4 * 64 * 4].reshape(4, 64, 4)
         lane = np.arange(64)
