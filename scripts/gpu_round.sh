@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round evidence in one gpurun call: gpu tests, smoke, benches, rocprofv3 kernel-trace stats and the
 # HBM-traffic / MFMA-busy PMC passes of the DEFAULT bench workload (c3 = 3840x2160 QP32 x 50).
-# Everything lands in gpurun_out/; scripts/collect_round.sh copies the judged summaries to profiles/.
+# Everything lands in gpurun_out/; scripts/collect_round.sh copies the judged summaries to profiles/.  The FETCH / WRITE counter passes run before the
+# benches and refresh profiles/fc1_traffic.json + profiles/step_traffic.json on the box, so that the evidence lines carry current traffic numbers.
 #   SKIP_TESTS=1  skip pytest (when the call is about numbers only)
 set -u
 mkdir -p gpurun_out
@@ -13,31 +14,7 @@ if [ -z "${SKIP_TESTS:-}" ]; then
   python __graft_entry__.py smoke 2>&1 | tail -3
 fi
 bash scripts/gpu_dist_smoke.sh 2>&1 | tail -6
-python bench.py > gpurun_out/bench_c3.json 2> gpurun_out/bench_c3.err || tail -5 gpurun_out/bench_c3.err
-python bench.py --workload c2 --no-cpu-baseline > gpurun_out/bench_c2.json 2> gpurun_out/bench_c2.err || tail -5 gpurun_out/bench_c2.err
-python bench.py --workload c4 --no-cpu-baseline --steps 5 > gpurun_out/bench_c4.json 2> gpurun_out/bench_c4.err || tail -5 gpurun_out/bench_c4.err
-python bench.py --workload c5 --steps 200 --warmup 20 --cpu-seconds 8 > gpurun_out/bench_c5.json 2> gpurun_out/bench_c5.err || tail -5 gpurun_out/bench_c5.err
-python scripts/summarize.py "gpurun_out/bench_c*.json"
-python - <<'PY'
-import json
-d = json.load(open("gpurun_out/bench_c3.json"))
-for e in d.get("cpu_baselines", []): print("cpu:", {k: e.get(k) for k in ("name", "value", "cores", "scope")})
-print("host_scopes:", d.get("host_scopes"))
-PY
-python scripts/latency.py > gpurun_out/latency.txt 2>&1; cat gpurun_out/latency.txt
-# (development knobs are read by the experiments build only: ETHCNN_LIB selects it)
-EXP=$REPO/hevc-complexity-reduction_amd/lib_exp/libethcnn.so
-{ echo "# the same with the single-launch small pass OFF (experiments build, ETHCNN_SMALL=0: tile / trunk / FC1 / heads / gate launches)"; ETHCNN_LIB=$EXP ETHCNN_SMALL=0 python scripts/latency.py; } > gpurun_out/latency_five_launches.txt 2>&1; cat gpurun_out/latency_five_launches.txt
-python scripts/power_probe.py 2500 > gpurun_out/power_probe.txt 2>&1; tail -70 gpurun_out/power_probe.txt
-python scripts/ldp_handshake.py 1000 > gpurun_out/ldp_handshake.txt 2>&1; cut -c1-200 gpurun_out/ldp_handshake.txt
-python scripts/latency_ldp.py --cpu > gpurun_out/latency_ldp.txt 2>&1; cat gpurun_out/latency_ldp.txt
-python scripts/latency_ldp_stream.py > gpurun_out/latency_ldp_stream.txt 2>&1; cat gpurun_out/latency_ldp_stream.txt
-python scripts/latency_hook.py 2>&1 | grep -v "^ethcnn (in-process)" > gpurun_out/latency_hook.txt; cat gpurun_out/latency_hook.txt
-{ python scripts/latency_host.py; echo "# --- the same with ETHCNN_PULL=0 (experiments build): copy engine first, banded above 1024 CTUs (the round's first form)"; ETHCNN_LIB=$EXP ETHCNN_PULL=0 python scripts/latency_host.py; } > gpurun_out/latency_host.txt 2>&1; cat gpurun_out/latency_host.txt
-bash scripts/gpu_pull_probe.sh > /dev/null 2>&1; grep -E "^===|launch" gpurun_out/pull_timeline.txt | cut -c1-200
-cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_$WL -o $WL -- python $REPO/bench.py --workload $WL --no-cpu-baseline --no-host-scopes > $REPO/gpurun_out/prof_$WL.log 2>&1
-cd $REPO
+# the counter passes FIRST: the bench lines below carry roofline.traffic and hbm only when the committed numbers were taken at these kernel sources
 # HBM traffic of FC1 (and, for the default workload, the MFMA-busy pass): c3, then the FETCH / WRITE passes of c2 as well, so that
 # profiles/fc1_traffic.json carries a current stamp for both
 pmc_passes() {
@@ -52,7 +29,7 @@ WL=$WL python - <<'PY'
 # remainder dispatch) from the FETCH_SIZE / WRITE_SIZE passes (KB as reported; FETCH x2 on gfx950)
 import csv, glob, json, os
 wl = os.environ["WL"]
-n = json.load(open("gpurun_out/bench_%s.json" % wl))["config"]["ctus_per_step_per_gpu"]
+n = {"c3": 102000, "c2": 25500}[wl]  # CTUs per step (bench.py WORKLOADS)
 def per_step(tag, counter):
     tot, steps = 0.0, 0
     for f in glob.glob("gpurun_out/pmc_%s_%s/**/*counter_collection.csv" % (wl, tag), recursive=True):
@@ -83,13 +60,46 @@ if fe is not None and wr is not None:
                 "bytes_per_launch": int(ffe*1024*2 + fwr*1024), "fetch_size_kb_reported": ffe, "write_size_kb_reported": fwr, "steps_averaged": k1,
                 "algorithmic_bytes_per_launch": n*2688*2*npieces + 2688*448*2*npieces + n*448*4,
                 "source": "the same passes, dispatches of k_fc1_fast<%d, 7, ...> (FETCH_SIZE x2)" % plan}
-    json.dump(out, open("gpurun_out/fc1_traffic_%s.json" % wl,"w"), indent=1); print("fc1 traffic:", out)
+    json.dump(out, open("gpurun_out/fc1_traffic_%s.json" % wl,"w"), indent=1); print("fc1 traffic:", {k: v["bytes_per_launch"] for k, v in out.items()})
+    # ... and into the copy bench.py reads on THIS box (profiles/fc1_traffic.json; scripts/collect_round.sh takes the same numbers home)
+    try:
+        cur = json.load(open("profiles/fc1_traffic.json"))
+    except Exception:
+        cur = {}
+    cur.update(out)
+    json.dump(cur, open("profiles/fc1_traffic.json", "w"), indent=1)
 PY
 }
 PMCS=("FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA"); pmc_passes
 if [ "$WL" = c3 ]; then WL=c2; PMCS=("FETCH_SIZE" "WRITE_SIZE"); pmc_passes; WL=c3; fi
-# whole-step HBM traffic per plan (bench.py's `hbm` object reads the committed copy)
+# whole-step HBM traffic per plan (bench.py's `hbm` object reads profiles/step_traffic.json: refreshed here, on the box, in front of the benches)
 bash scripts/gpu_step_traffic.sh 2>&1 | tail -4
+[ -s gpurun_out/step_traffic.json ] && cp gpurun_out/step_traffic.json profiles/step_traffic.json
+python bench.py > gpurun_out/bench_c3.json 2> gpurun_out/bench_c3.err || tail -5 gpurun_out/bench_c3.err
+python bench.py --workload c2 --no-cpu-baseline > gpurun_out/bench_c2.json 2> gpurun_out/bench_c2.err || tail -5 gpurun_out/bench_c2.err
+python bench.py --workload c4 --no-cpu-baseline --steps 5 > gpurun_out/bench_c4.json 2> gpurun_out/bench_c4.err || tail -5 gpurun_out/bench_c4.err
+python bench.py --workload c5 --steps 200 --warmup 20 --cpu-seconds 8 > gpurun_out/bench_c5.json 2> gpurun_out/bench_c5.err || tail -5 gpurun_out/bench_c5.err
+python scripts/summarize.py "gpurun_out/bench_c*.json"
+python - <<'PY'
+import json
+d = json.load(open("gpurun_out/bench_c3.json"))
+for e in d.get("cpu_baselines", []): print("cpu:", {k: e.get(k) for k in ("name", "value", "cores", "scope")})
+print("host_scopes:", d.get("host_scopes"))
+PY
+python scripts/latency.py > gpurun_out/latency.txt 2>&1; cat gpurun_out/latency.txt
+# (development knobs are read by the experiments build only: ETHCNN_LIB selects it)
+EXP=$REPO/hevc-complexity-reduction_amd/lib_exp/libethcnn.so
+{ echo "# the same with the single-launch small pass OFF (experiments build, ETHCNN_SMALL=0: tile / trunk / FC1 / heads / gate launches)"; ETHCNN_LIB=$EXP ETHCNN_SMALL=0 python scripts/latency.py; } > gpurun_out/latency_five_launches.txt 2>&1; cat gpurun_out/latency_five_launches.txt
+python scripts/power_probe.py 2500 > gpurun_out/power_probe.txt 2>&1; tail -70 gpurun_out/power_probe.txt
+python scripts/ldp_handshake.py 1000 > gpurun_out/ldp_handshake.txt 2>&1; cut -c1-200 gpurun_out/ldp_handshake.txt
+python scripts/latency_ldp.py --cpu > gpurun_out/latency_ldp.txt 2>&1; cat gpurun_out/latency_ldp.txt
+python scripts/latency_ldp_stream.py > gpurun_out/latency_ldp_stream.txt 2>&1; cat gpurun_out/latency_ldp_stream.txt
+python scripts/latency_hook.py 2>&1 | grep -v "^ethcnn (in-process)" > gpurun_out/latency_hook.txt; cat gpurun_out/latency_hook.txt
+{ python scripts/latency_host.py; echo "# --- the same with ETHCNN_PULL=0 (experiments build): copy engine first, banded above 1024 CTUs (the round's first form)"; ETHCNN_LIB=$EXP ETHCNN_PULL=0 python scripts/latency_host.py; } > gpurun_out/latency_host.txt 2>&1; cat gpurun_out/latency_host.txt
+bash scripts/gpu_pull_probe.sh > /dev/null 2>&1; grep -E "^===|launch" gpurun_out/pull_timeline.txt | cut -c1-200
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_$WL -o $WL -- python $REPO/bench.py --workload $WL --no-cpu-baseline --no-host-scopes > $REPO/gpurun_out/prof_$WL.log 2>&1
+cd $REPO
 head -12 gpurun_out/prof_$WL/${WL}_kernel_stats.csv
 python - <<'PY'
 import csv, glob, collections
