@@ -60,7 +60,9 @@ float fast_feature_bound(const float* blob);
 // Per branch, A operands as fp16 pieces in MFMA order (halves): [conv1: 4 fragments x 64 lanes x 4 = piece 0, piece 1, 16 x piece 0,
 // 16 x piece 1 (the last two for the L branch's high pixel-sum digits)][conv2: (t, s, piece) 8 fragments x 64 x 8][conv3: (t, s,
 // piece) 12 fragments x 64 x 8]; per-lane constants (floats): [24 slots x 64 lanes]: conv1 -S1 Wsum (4), S1 b1 (4), conv2 sa b2
-// (t, r: 8), conv3 sa b3 (t, r: 8); scalars per branch: C1 = c255 2^-p 2^-sw1 S1, U2 = sa / (S1 2^sw2), U3 = 2^-sw3.
+// (t, r: 8), conv3 sa b3 (t, r: 8); scalars per branch: C1 = c255 2^-p S1 -- the factor conv1's weight pieces CARRY (pieces of fl(w C1): the
+// accumulator, started at S1 (b1 - mean Wsum), is conv1's output in the activation scale S1; the kernel does not multiply by it) --,
+// U2 = sa / (S1 2^sw2), U3 = 2^-sw3.
 constexpr int kTrunk16Halves = 4 * 64 * 4 + 8 * 64 * 8 + 12 * 64 * 8;  // 11,264 per branch
 constexpr int kTrunk16Conv2At = 4 * 64 * 4, kTrunk16Conv3At = kTrunk16Conv2At + 8 * 64 * 8;
 constexpr int kTrunk16Consts = 24 * 64;
