@@ -210,3 +210,15 @@ def test_plan_env_and_file_entry(pkg, oracle, tmp_path, plan):
             c.set_fc1_plan(7)
         finally:
             c.close()
+
+
+def test_fast_plans_geometry_fuzz():
+    """a slice of scripts/fuzz_plan3.py in the driver-run suite: 60 random geometries / pitches / strides / base alignments above
+    2304 CTUs (the multi-launch path: aligned rows -> the fast loaders, ragged ones -> the byte-wise ones), plans 2 and 3 at 1e-4
+    with gates open or closed, plan 0 bit-exact on the same inputs (profiles/r05_fuzz.txt: 2000 cases, worst 8.1e-6)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_plan3.py")], env=dict(os.environ, CASES="60", SEED="2025"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "60 cases, 0 mismatches" in r.stdout, (r.stdout[-1500:], r.stderr[-800:])
