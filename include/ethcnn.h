@@ -263,7 +263,8 @@ int ethcnn_set_fused_launch(ethcnn_ctx* ctx, int mode);
  *                (h0 + h1 represents it to 2^-24 relative; the feature scale comes from a bound derived from the conv weights at
  *                load, not from observation, so no piece can overflow), THREE products, fp32 accumulation;
  *   3 ("fast", everything as fp16 x 2)  plan 2, and the trunk's three conv layers (ethcnn_trunk_fast.hip: conv1 on the exact integer
- *                pixel sums with the mean removal folded into one fma per output, conv2 / conv3 with fp16 x 2 splits; the CTU-load
+ *                pixel sums -- its weight pieces carry the pixel scale and its accumulators start at the mean-removal constant, so no
+ *                arithmetic per output beyond the leaky-ReLU --, conv2 / conv3 with fp16 x 2 splits; the CTU-load
  *                stage is folded into the trunk: one pass over the luma frames, no pixel records in HBM) and the heads' FC2 / FC3
  *                (ethcnn_heads_fast.hip, scaled residual pieces) on the 16-bit pipe as well.  The fastest plan.
  *   (1 was round 4's bf16 x 3 form of FC1; removed in round 5 -- slower than plan 2 and no more accurate -- and now an argument error.)
