@@ -18,8 +18,8 @@
 //          lo = fp16(v - hi): 2^-24 relative), weights likewise at load; three products per k step (hi W0, lo W0, hi W1).
 //          conv2's outputs ARE features: their pieces (feature scale of plan 2) are at once conv3's B operand and what is
 //          stored for FC1 -- the 128 VALU of plan 2's split epilogue are not paid twice.
-// 98 matrix instructions of 16 cycles per task instead of 240 of 32; the task is VALU-bound now (~680 VALU: affine + leaky-ReLU +
-// split of the 64 conv1 outputs per lane is half of it).
+// 98 matrix instructions of 16 cycles per task instead of 240 of 32; the task is bound by instruction ISSUE now (~590 VALU of ~800
+// instructions: leaky-ReLU + split of the 64 conv1 outputs per lane is half of them; profiles/r05_trunk16_issue_bound.txt).
 // Numerics: not bit-identical to the oracle (different rounding points), fp32-class: the features agree with the oracle's to
 // ~1e-6 relative to their scale; probabilities within the north star's 1e-4 (tests/test_gpu_fast_plan.py, plan 3).
 #include <hip/hip_runtime.h>
