@@ -6,6 +6,7 @@ decisions equal except on knife edges -- plus what makes them "not narrower arit
 oracle's features (plan 2: to 2^-23 relative), and the error against the float64 restatement is no worse than twice the exact
 plan's.  (Plan 1 of round 4, bf16 x 3, was removed: test_plan_1_is_gone.)"""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -222,3 +223,36 @@ def test_fast_plans_geometry_fuzz():
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_plan3.py")], env=dict(os.environ, CASES="60", SEED="2025"),
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "60 cases, 0 mismatches" in r.stdout, (r.stdout[-1500:], r.stderr[-800:])
+
+
+@pytest.mark.parametrize("plan", [2, 3])
+def test_fast_plans_under_every_launch_plan(pkg, oracle, plan):
+    """ethcnn_set_fused_launch x ethcnn_set_fc1_plan: the launch plan changes which launch applies the gates (k5_gate behind the heads, or the
+    heads launch itself: k_heads<true> / k_heads_f16<true>), never the arithmetic -- under a fast plan the three launch plans give
+    bit-identical outputs (mode 1, the fused FC1 + heads launch, is an exact-plan form and falls back to separate launches), within 1e-4
+    of the oracle, with mixed gate states per sub-batch (2560 x 1920: 1024 + 176 CTUs per frame, the second sub-batch flat)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import ctu_gen
+    w, h, frames, qp = 2560, 1920, 3, 32
+    luma = np.stack([ctu_gen.make_frame(700 + k, w, h, flat_from_ctu=1024 if k != 1 else None) for k in range(frames)])
+    blob = oracle.synth_blob(1, 8.0)
+    can = oracle.predict_frames(blob, luma, w, h, frames, qp, -1.0, -1.0, mode=0).reshape(frames, -1, 21)
+    # thresholds between the flat sub-batch's constant outputs and the textured sub-batch's maxima: gates differ inside a frame
+    flat64, flat32 = float(can[0, 1024:, 0].max()), float(can[0, 1024:, 1:5].max())
+    t1 = 0.5 * (flat64 + float(can[0, :1024, 0].max()))
+    t2 = 0.5 * (flat32 + float(can[0, :1024, 1:5].max()))
+    want = oracle.predict_frames(blob, luma, w, h, frames, qp, t1, t2, mode=0)
+    outs = []
+    for mode in (0, 1, 2):
+        c = pkg.EthCnn(device=0)
+        c.load_blob(blob)
+        c.set_small_pass_launch(False)
+        c.set_thresholds(t1, t2)
+        c.set_fused_launch(mode)
+        c.set_fc1_plan(plan)
+        outs.append(c.predict_luma(luma, w, h, frames, qp))
+        c.close()
+    assert np.array_equal(outs[0] == 0.0, want == 0.0) and np.abs(outs[0] - want).max() <= TOL
+    assert (outs[0].reshape(frames, -1, 21)[0, 1024:, 1:] == 0.0).all() and (outs[0].reshape(frames, -1, 21)[0, :1024] != 0.0).all()
+    for mode in (1, 2):
+        assert np.array_equal(_bits(outs[mode]), _bits(outs[0])), mode
