@@ -272,7 +272,9 @@ int ethcnn_set_fused_launch(ethcnn_ctx* ctx, int mode);
  * term fp32 sum is set by the roundings of its accumulation), but the ORDER of the fp32 additions differs, so probabilities agree
  * with plan 0 / the oracle to about 1e-6..1e-5, not bit for bit (tests: <= 1e-4, the north star's tolerance; thresholded decisions may
  * differ on knife edges only).  The batch gates are computed exactly in every plan.  The single-launch small pass and the LDP path
- * always use plan 0.  Env ETHCNN_FC1_PLAN=2|3 starts contexts in that plan.  Takes effect with the next pass enqueued. */
+ * always use plan 0 -- which includes ONE picture handed to ethcnn_predict_luma (the host entry's latency path: a picture with 16-byte
+ * aligned rows runs as single-launch passes, whole or in 1024-CTU pieces): the plans show in ethcnn_predict_luma_device, the file /
+ * multi-frame host entries and the streamed entries of pictures above 2304 CTUs (tests/test_gpu_fast_plan.py).  Env ETHCNN_FC1_PLAN=2|3 starts contexts in that plan.  Takes effect with the next pass enqueued. */
 int ethcnn_set_fc1_plan(ethcnn_ctx* ctx, int plan);
 int ethcnn_get_fc1_plan(const ethcnn_ctx* ctx);
 /* Single-launch small pass (default on): a pass of <= 2304 CTUs (up to one 3840x2160 picture) whose rows are 16-byte aligned (width, pitch, frame stride and

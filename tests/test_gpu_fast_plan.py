@@ -256,3 +256,54 @@ def test_fast_plans_under_every_launch_plan(pkg, oracle, plan):
     assert (outs[0].reshape(frames, -1, 21)[0, 1024:, 1:] == 0.0).all() and (outs[0].reshape(frames, -1, 21)[0, :1024] != 0.0).all()
     for mode in (1, 2):
         assert np.array_equal(_bits(outs[mode]), _bits(outs[0])), mode
+
+
+@pytest.mark.parametrize("plan", [2, 3])
+def test_streamed_input_under_the_fast_plans(pkg, oracle, plan):
+    """ethcnn_predict_luma_begin / rows_ready / end on a picture too big for the single-launch pass (4928 x 3264: 3927 CTUs) under a fast plan:
+    the pass runs with a WAITING tile stage in front (plan 3: k1_trunk_f16 on its records instead of the trunk that reads the frames itself) --
+    the same arithmetic, so bit-identical to the device entry under the same plan, and within 1e-4 of the oracle"""
+    import threading
+    import time
+    w, h, qp = 4928, 3264, 27
+    nctu, nrows = pkg.ethcnn.ctus_per_frame(w, h), (h + 63) // 64
+    rng = np.random.default_rng(91)
+    blob = oracle.synth_blob(10, 4.0)
+    luma = rng.integers(0, 256, size=(1, h, w), dtype=np.uint8)
+    want = oracle.predict_frames(blob, luma, w, h, 1, qp, 0.6, 0.4, mode=0)
+    c = pkg.EthCnn(0)
+    try:
+        c.load_blob(blob)
+        c.set_thresholds(0.6, 0.4)
+        c.set_fc1_plan(plan)
+        # (the HOST entry would not do as the comparison: a single picture below 8192 CTUs takes the latency path there -- bands of
+        # single-launch passes, which always compute exactly)
+        d_in, d_out = c.alloc(luma.nbytes), c.alloc(nctu * 84)
+        d_in.upload(luma)
+        c.predict_luma_device(d_in, w, h, 1, qp, d_out)
+        c.synchronize()
+        plain = d_out.download(np.float32, nctu * 21).reshape(-1, 21)
+        assert not np.array_equal(_bits(plain), _bits(want.reshape(-1, 21)))  # the plan is in force: not the exact bits
+        pin = c.host_buffer(w * h)
+        pprobs = c.host_buffer(nctu * 84).view(np.float32)
+        for rep in range(2):
+            order = rng.permutation(nrows)
+            pin[:] = 0x55
+
+            def filler():
+                time.sleep(0.001)
+                for cy in order:
+                    cy = int(cy)
+                    pin[cy * 64 * w:min(h, cy * 64 + 64) * w] = luma[0, cy * 64:cy * 64 + 64].reshape(-1)
+                    c.rows_ready(cy, cy + 1)
+            t = threading.Thread(target=filler)
+            t.start()
+            c.predict_luma_begin(pin, w, h, qp, pprobs)
+            t.join()
+            c.predict_luma_end()
+            got = pprobs.reshape(-1, 21)
+            assert np.array_equal(_bits(got), _bits(plain.reshape(-1, 21))), rep
+        if np.array_equal(plain == 0.0, want.reshape(-1, 21) == 0.0):
+            assert np.abs(plain - want.reshape(-1, 21)).max() <= TOL
+    finally:
+        c.close()
