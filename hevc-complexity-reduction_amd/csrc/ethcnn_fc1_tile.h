@@ -1,5 +1,5 @@
 // ethcnn_fc1_tile.h -- device code of the FC1 tile (see ethcnn_dense.hip for the design notes): shared by the FC1 kernels
-// (ethcnn_dense.hip) and the fused FC1 + heads + gate launch (ethcnn_fused.hip).
+// (ethcnn_dense.hip) and the single-launch small pass (ethcnn_small.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -64,7 +64,7 @@ __device__ __forceinline__ void fc1_block_to_tile(unsigned bid, int& mt, int& nb
 
 // one output tile: M tile `mt` (rows mt * BM ..), column block `nb`; smem: >= Fc1Shape<...>::LDS_FLOATS floats.
 // COHERENT: the h1 stores are agent-scope (sc1: written through this XCD's L2), for a consumer that runs in the SAME launch
-// on another XCD (the heads blocks of the fused launch, ethcnn_fused.hip); results are identical.
+// on another XCD (the heads blocks of the single-launch small pass, ethcnn_small.hip); results are identical.
 // A_SC1: the features were written earlier in the SAME launch (single-launch small pass): fetched with agent-scope loads.
 template <int MS, int NS, int WM, int NSUB, int NST, bool COHERENT = false, bool A_SC1 = false>
 __device__ __forceinline__ void fc1_tile_at(float* __restrict__ smem, const float* __restrict__ feat, const float* __restrict__ Wimg,

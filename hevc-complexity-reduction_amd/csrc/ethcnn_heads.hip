@@ -22,16 +22,14 @@
 
 namespace ethcnn {
 
-// GATE: the tf.cond gates are applied inside this launch, per sub-batch, by the block that completes it (arrival counters
-// behind the predicates, zeroed with them by the pass's tile stage) instead of by a k5_gate launch behind it: one launch and one kernel
-// boundary less per pass, which is what a single-picture call (5 dependent launches of 10-20 us) feels most.
-template <bool GATE>
+// (The tf.cond gates are applied by k5_gate behind this launch.  A form that applied them inside it, per sub-batch, by the block that
+// completes the sub-batch, measured equal to 0.4 % slower and was removed in round 6; the single-launch small pass keeps that scheme:
+// heads_gates_arrive in ethcnn_heads_pass.h.)
 __global__ __launch_bounds__(256) void k_heads(const float* __restrict__ H1, HeadsParams hp, float qn, int N, GateIndex gi,
                                                float thr1, float thr2, float* __restrict__ H2,
                                                float* __restrict__ logits, float* __restrict__ raw,
-                                               float* __restrict__ probs, int* __restrict__ flags, int nchunks) {
+                                               float* __restrict__ probs, int* __restrict__ flags) {
     __shared__ __attribute__((aligned(16))) float smem[kHeadsStages * kHeadsStage];  // 24 KB
-    __shared__ GateArrive s_ga;
     HEADS_STAMP(0);
     const int lane = threadIdx.x & 63;
     const unsigned wvu = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -48,17 +46,16 @@ __global__ __launch_bounds__(256) void k_heads(const float* __restrict__ H1, Hea
     // column slice of h1), so they run as separate blocks -- head 16 (16 K chunks) is dispatched first,
     // the short heads 32 / 64 fill in behind it.  A third of the per-block latency, three times the blocks.
     if (head_ == 0)
-        head_pass<2, false, GATE>(smem, H1, hp, qn, lane, wvu, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
+        head_pass<2>(smem, H1, hp, qn, lane, wvu, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
     else if (head_ == 1)
-        head_pass<1, false, GATE>(smem, H1, hp, qn, lane, wvu, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
+        head_pass<1>(smem, H1, hp, qn, lane, wvu, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
     else
-        head_pass<0, false, GATE>(smem, H1, hp, qn, lane, wvu, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
+        head_pass<0>(smem, H1, hp, qn, lane, wvu, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
     HEADS_STAMP(4);
-    if (GATE) heads_gates_arrive(flags, flags + 2 * nchunks, gi, N, tile_ * 64, thr2, probs, &s_ga);
 }
 
 void launch_heads(const Workspace& ws, const DeviceWeights& w, int n, float qn, int nctu, long ctu0, float thr1,
-                  float thr2, float* d_probs, hipStream_t s, int gate_nchunks) {
+                  float thr2, float* d_probs, hipStream_t s) {
     HeadsParams hp;
     for (int h = 0; h < 3; ++h) {
         hp.w2[h] = w.fc2_w[h];
@@ -69,12 +66,7 @@ void launch_heads(const Workspace& ws, const DeviceWeights& w, int n, float qn, 
     }
     const GateIndex gi = make_gate_index(nctu, ctu0);
     const dim3 grid((n + 63) / 64, 3);
-    if (gate_nchunks > 0)
-        hipLaunchKernelGGL(k_heads<true>, grid, dim3(256), 0, s, ws.h1, hp, qn, n, gi, thr1, thr2, ws.h2, ws.logits, ws.raw, d_probs,
-                           ws.flags, gate_nchunks);
-    else
-        hipLaunchKernelGGL(k_heads<false>, grid, dim3(256), 0, s, ws.h1, hp, qn, n, gi, thr1, thr2, ws.h2, ws.logits, ws.raw, d_probs,
-                           ws.flags, 0);
+    hipLaunchKernelGGL(k_heads, grid, dim3(256), 0, s, ws.h1, hp, qn, n, gi, thr1, thr2, ws.h2, ws.logits, ws.raw, d_probs, ws.flags);
 }
 
 }  // namespace ethcnn

@@ -55,7 +55,7 @@ struct Heads16Params {
 constexpr int kHeads16Stage = 24 * 1024;  // bytes: the widest chunk (head 16: 12 tiles x 2 pieces x 1 KiB)
 constexpr int kHeads16Stages = 2;
 
-template <int H, bool P_SC1>
+template <int H>
 __device__ __forceinline__ void head_pass_f16(char* smem, const float* __restrict__ H1, const HeadsParams& hp, const Heads16Params& fp, float qn,
                                               int lane, unsigned wvu, bool valid, int ctu, float* __restrict__ h2row, float* __restrict__ logits,
                                               float* __restrict__ raw, float* __restrict__ probs, int* flag32, int* flag16, float thr1, float thr2) {
@@ -173,8 +173,7 @@ __device__ __forceinline__ void head_pass_f16(char* smem, const float* __restric
             const size_t idx = (size_t)ctu * kNOut + D::O3 + o;
             if (logits) logits[idx] = zz;  // introspection copies (ethcnn_set_debug_capture), null in production
             if (raw) raw[idx] = p;
-            if (P_SC1) __hip_atomic_store(&probs[idx], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else probs[idx] = p;
+            probs[idx] = p;
             if (H == 0 && p > thr1 && __hip_atomic_load(flag32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
                 __hip_atomic_store(flag32, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // any(y64 > THR_L1_LOWER)
             if (H == 1 && p > thr2 && __hip_atomic_load(flag16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
@@ -183,12 +182,10 @@ __device__ __forceinline__ void head_pass_f16(char* smem, const float* __restric
     }
 }
 
-template <bool GATE>
 __global__ __launch_bounds__(256, 3) void k_heads_f16(const float* __restrict__ H1, HeadsParams hp, Heads16Params fp, float qn, int N, GateIndex gi,
                                                    float thr1, float thr2, float* __restrict__ H2, float* __restrict__ logits,
-                                                   float* __restrict__ raw, float* __restrict__ probs, int* __restrict__ flags, int nchunks) {
+                                                   float* __restrict__ raw, float* __restrict__ probs, int* __restrict__ flags) {
     __shared__ __attribute__((aligned(16))) char smem[kHeads16Stages * kHeads16Stage];  // 48 KB
-    __shared__ GateArrive s_ga;
     const int lane = threadIdx.x & 63;
     const unsigned wvu = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int col = lane & 15;
@@ -200,16 +197,15 @@ __global__ __launch_bounds__(256, 3) void k_heads_f16(const float* __restrict__ 
     int* fl = flags;
     if (head_ != 0) fl += 2 * gate_chunk(gi, ctu);
     if (head_ == 0)
-        head_pass_f16<2, GATE>(smem, H1, hp, fp, qn, lane, wvu, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
+        head_pass_f16<2>(smem, H1, hp, fp, qn, lane, wvu, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
     else if (head_ == 1)
-        head_pass_f16<1, GATE>(smem, H1, hp, fp, qn, lane, wvu, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
+        head_pass_f16<1>(smem, H1, hp, fp, qn, lane, wvu, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
     else
-        head_pass_f16<0, GATE>(smem, H1, hp, fp, qn, lane, wvu, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
-    if (GATE) heads_gates_arrive(flags, flags + 2 * nchunks, gi, N, tile_ * 64, thr2, probs, &s_ga);
+        head_pass_f16<0>(smem, H1, hp, fp, qn, lane, wvu, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
 }
 
 void launch_heads_f16(const Workspace& ws, const DeviceWeights& w, int n, float qn, int nctu, long ctu0, float thr1, float thr2,
-                      float* d_probs, hipStream_t s, int gate_nchunks) {
+                      float* d_probs, hipStream_t s) {
     HeadsParams hp;
     for (int h = 0; h < 3; ++h) {
         hp.w2[h] = w.fc2_w[h];
@@ -223,12 +219,7 @@ void launch_heads_f16(const Workspace& ws, const DeviceWeights& w, int n, float 
     fp.sc = w.heads16_s;
     const GateIndex gi = make_gate_index(nctu, ctu0);
     const dim3 grid((n + 63) / 64, 3);
-    if (gate_nchunks > 0)
-        hipLaunchKernelGGL(k_heads_f16<true>, grid, dim3(256), 0, s, ws.h1, hp, fp, qn, n, gi, thr1, thr2, ws.h2, ws.logits, ws.raw, d_probs,
-                           ws.flags, gate_nchunks);
-    else
-        hipLaunchKernelGGL(k_heads_f16<false>, grid, dim3(256), 0, s, ws.h1, hp, fp, qn, n, gi, thr1, thr2, ws.h2, ws.logits, ws.raw, d_probs,
-                           ws.flags, 0);
+    hipLaunchKernelGGL(k_heads_f16, grid, dim3(256), 0, s, ws.h1, hp, fp, qn, n, gi, thr1, thr2, ws.h2, ws.logits, ws.raw, d_probs, ws.flags);
 }
 
 }  // namespace ethcnn

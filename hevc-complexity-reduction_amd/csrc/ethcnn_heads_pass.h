@@ -1,6 +1,6 @@
 // ethcnn_heads_pass.h -- device code of one head (FC2 + FC3 + sigmoid + gate predicates) for a wave's 16 CTUs; see
-// ethcnn_heads.hip for the design notes.  Shared by k_heads (ethcnn_heads.hip) and the fused FC1 + heads + gate launch
-// (ethcnn_fused.hip).
+// ethcnn_heads.hip for the design notes.  Shared by k_heads (ethcnn_heads.hip), the single-launch small pass (ethcnn_small.hip)
+// and the LSTM heads (ethcnn_lstm.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -84,11 +84,9 @@ constexpr int kHeadsStages = 2;  // prefetch distance 1: 24 KB of LDS, < 80 VGPR
 // drains nor counts it), explicit vmcnt + raw barrier -- the FC1 pipeline of ethcnn_dense.hip at the heads' sizes;
 // occupancy, not depth, covers the DMA latency (3 stages / 3 blocks per CU measured 7 % slower on 102,000 CTUs;
 // 6 blocks per CU instead of 4: stage alone 143.6 -> 131.2 us, in the pipeline 0.157 -> 0.148 ms).
-// H1_SC1 (the fused launch, ethcnn_fused.hip): h1 was written by FC1 blocks of the SAME launch, possibly on another XCD ->
-// every h1 read is an agent-scope load (sc1).  P_SC1 (gates applied inside the launch): the probabilities are agent-scope
-// stores -- the block that applies the gates at the end of the launch may run on another XCD and overwrites them.
-// Results are identical in every combination.
-template <int H, bool H1_SC1 = false, bool P_SC1 = false>
+// (Round 3's two merged launch plans -- FC1 + heads + gates as one launch, and the gates applied by the heads launch -- read h1 /
+// stored the probabilities with agent-scope accesses here; measured equal to 1 % slower than the separate launches, removed in round 6.)
+template <int H>
 __device__ __forceinline__ void head_pass(float* smem, const float* __restrict__ H1, const HeadsParams& hp, float qn,
                                           int lane, unsigned wvu, bool valid, int ctu, float* __restrict__ h2row,
                                           float* __restrict__ logits, float* __restrict__ raw, float* __restrict__ probs,
@@ -131,22 +129,12 @@ __device__ __forceinline__ void head_pass(float* smem, const float* __restrict__
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" \
                      : "=&s"(keep_) : "v"(voff), "s"(sbase), "s"(dst_) : "memory");                      \
     }
-#define HP_DMA_SC1(voff, sbase, lds_byte_off)                                                            \
-    {                                                                                                    \
-        unsigned keep_;                                                                                  \
-        const unsigned dst_ = __builtin_amdgcn_readfirstlane(lds_base + (lds_byte_off));                 \
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1\n\ts_mov_b32 m0, %0" \
-                     : "=&s"(keep_) : "v"(voff), "s"(sbase), "s"(dst_) : "memory");                      \
-    }
 #define HP_ISSUE(kc, st)                                                                                 \
     {                                                                                                    \
         _Pragma("unroll") for (int i = 0; i < D::B_PER; ++i)                                             \
             HP_DMA(b_off[i], W2 + (size_t)(kc) * 16 * D::N2,                                             \
                    4u * ((st) * kHeadsStage + min(wvu + i * 4, (unsigned)(D::B_INST - 1)) * 256));       \
-        if (!D::H1REG) {                                                                                 \
-            if (H1_SC1) HP_DMA_SC1(a_off, H1 + (kc) * 16, 4u * ((st) * kHeadsStage + D::H1_AT + wvu * 256))  \
-            else HP_DMA(a_off, H1 + (kc) * 16, 4u * ((st) * kHeadsStage + D::H1_AT + wvu * 256))         \
-        }                                                                                                \
+        if (!D::H1REG) HP_DMA(a_off, H1 + (kc) * 16, 4u * ((st) * kHeadsStage + D::H1_AT + wvu * 256))   \
     }
 #define HP_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
@@ -155,7 +143,7 @@ __device__ __forceinline__ void head_pass(float* smem, const float* __restrict__
     for (int j = 0; j < D::NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const __amdgpu_buffer_rsrc_t rH1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(H1), 0, -1, 0x00020000);
-    constexpr int kH1Aux = H1_SC1 ? kAuxSc1 : 0;
+    constexpr int kH1Aux = 0;
     f32x4 avr = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (D::H1REG) avr = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rH1, a_off, 0, kH1Aux));
     __builtin_amdgcn_s_barrier();  // the previous head's last stage has been consumed by every wave
@@ -193,7 +181,6 @@ __device__ __forceinline__ void head_pass(float* smem, const float* __restrict__
         avr = avn;
     }
 #undef HP_DMA
-#undef HP_DMA_SC1
 #undef HP_ISSUE
 #undef HP_WAIT
     HEADS_STAMP(3);
@@ -245,8 +232,7 @@ __device__ __forceinline__ void head_pass(float* smem, const float* __restrict__
             const size_t idx = (size_t)ctu * kNOut + D::O3 + o;
             if (logits) logits[idx] = zz;  // introspection copies (ethcnn_set_debug_capture), null in production
             if (raw) raw[idx] = p;
-            if (P_SC1) __hip_atomic_store(&probs[idx], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else probs[idx] = p;
+            probs[idx] = p;
             if (H == 0 && p > thr1 && __hip_atomic_load(flag32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
                 __hip_atomic_store(flag32, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // any(y64 > THR_L1_LOWER)
             if (H == 1 && p > thr2 && __hip_atomic_load(flag16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)

@@ -18,7 +18,7 @@ struct Workspace {
     float* h2 = nullptr;     // [cap][336]
     float* logits = nullptr; // [cap][21]
     float* raw = nullptr;    // [cap][21] ungated probabilities
-    int* flags = nullptr;    // sync area: [chunks][2] gate predicates, [chunks] sub-batch arrival counters, (fused launch) tile completion counters
+    int* flags = nullptr;    // the pass's gate predicates: [chunks][2] (+ 8 spare words), sync_words(chunks)
     int flags_cap = 0;       // in ints
 };
 
@@ -53,21 +53,14 @@ void launch_fc1(const Workspace& ws, const DeviceWeights& w, int n, float* out, 
 // k2, plans 2 / 3 (ethcnn_fc1_fast.hip): featb -> h1 on the 16-bit matrix pipe: three fp16 products per fp32 product (two-way splits of
 // the scaled operands), fp32 accumulate; same bias + leaky-ReLU epilogue, same h1 layout
 void launch_fc1_fast(const Workspace& ws, const DeviceWeights& w, int n, float* out, int plan, hipStream_t s, int cus = 256);
-// k3+k4 fused: h1 -> h2 -> logits, raw probs, probs and per-chunk gate flags.  gate_nchunks > 0: the batch gates are applied
-// inside the launch (ws.flags = sync area: arrival counters behind the 2 * gate_nchunks predicates, zero on
-// entry); 0: probs are left ungated for launch_gate
+// k3+k4 fused: h1 -> h2 -> logits, raw probs, probs (left ungated for launch_gate) and per-chunk gate predicates
 void launch_heads(const Workspace& ws, const DeviceWeights& w, int n, float qn, int nctu_per_frame,
-                  long ctu0, float thr1, float thr2, float* d_probs, hipStream_t s, int gate_nchunks = 0);
+                  long ctu0, float thr1, float thr2, float* d_probs, hipStream_t s);
 // the same heads on the 16-bit matrix pipe (plan 3; ethcnn_heads_fast.hip): fp16 x 2 splits of h1 / h2 and of W2 / W3 (w.heads16_w)
 void launch_heads_f16(const Workspace& ws, const DeviceWeights& w, int n, float qn, int nctu_per_frame, long ctu0, float thr1, float thr2,
-                      float* d_probs, hipStream_t s, int gate_nchunks = 0);
-// FC1 + heads + gates of a big pass as ONE launch (ethcnn_fused.hip): the heads blocks are appended to FC1's grid and wait on
-// per-M-tile completion counters; the last heads block applies the gates.  ws.flags = the pass's sync area
-// [2 * nchunks gate predicates][nchunks sub-batch arrival counters][tile counters], sync_words(n, nchunks) ints, ZERO on entry (the tile stage clears it).
-bool fc1_heads_fusable(int n);
-void launch_fc1_heads(const Workspace& ws, const DeviceWeights& w, int n, float qn, int nctu_per_frame, long ctu0, float thr1,
-                      float thr2, float* d_probs, int nchunks, hipStream_t s);
-inline int sync_words(int n, int nchunks) { return 3 * nchunks + (n + 63) / 64 + 8; }
+                      float* d_probs, hipStream_t s);
+// ints of ws.flags a pass of `nchunks` gate sub-batches uses; ZERO on entry (the tile stage / the folded plan-3 trunk clears them)
+inline int sync_words(int nchunks) { return 2 * nchunks + 8; }
 // A small pass (<= kSmallPassMaxCtus CTUs: up to one 3840x2160 picture; 16-byte aligned rows) as ONE launch (ethcnn_small.hip): CTU load + trunk -> FC1 ->
 // heads -> gates as a dataflow inside one grid (per-group / per-tile completion counters).  resi: the LDP front-end (stops
 // after FC1, fc1_out = the 448-vectors).  d_sync: small_pass_sync_words(n, nchunks) ints, zeroed once; counters and flags are

@@ -25,7 +25,7 @@
 // are co-resident anyway).  When several processes share the GPU that is not enough -- two such launches can fill each other's
 // XCDs with waiting blocks -- hence CLAIM OR EXECUTE (do_fc1_item / the heads role below): a consumer that has waited too long
 // executes the unclaimed items it depends on itself.  All hand-offs are agent-scope (sc1) stores / loads, completed
-// (s_waitcnt vmcnt(0)) before the producer's counter moves -- the fused big-pass launch's scheme (ethcnn_fused.hip, DESIGN.md
+// (s_waitcnt vmcnt(0)) before the producer's counter moves -- the scheme of round 3's fused big-pass launch (removed in round 6; DESIGN.md
 // "hand-offs inside a launch") -- with the signalling shaped for LATENCY (see SmallSync below): finisher-notifies-private-flag
 // instead of polled counters.  The stages' launch overheads, weight staging and drains overlap instead of adding up.
 // The sync area is ZERO between launches by construction: every word is reset by its unique last user.

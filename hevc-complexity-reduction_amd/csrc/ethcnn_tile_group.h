@@ -19,7 +19,7 @@ constexpr int kRowPitch = 17;                    // dwords per CTU row in LDS (1
 //   XL  j = 4 (s >> 1) + 2 m + (s & 1), m = 0, 1          2 j x 64 lanes
 // so a block walks s = 0..3 with the next slab's pixels already in flight in registers.  Small enough to be co-resident
 // with three FC1 blocks per CU (138 KB + 17.5 KB <= 160 KB): this is what lets the CTU-load stage of pass i+1 run UNDER
-// the MFMA-bound FC1 of pass i (csrc/ethcnn_api.cpp run_pass, profiles/r02_overlap_trace.txt).
+// the MFMA-bound FC1 of pass i (csrc/ethcnn_pass.cpp run_pass, profiles/r02_overlap_trace.txt).
 constexpr int kSlabCtuPitch = 16 * kRowPitch + 1;  // 273 dwords: 17 c mod 32 puts the 16 CTUs on 16 different banks
 
 // streaming accesses: the records are read by the NEXT pass's trunk, long after; kept out of the L2 lines FC1 (running

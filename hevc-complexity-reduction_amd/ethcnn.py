@@ -63,7 +63,6 @@ SIGNATURES = {
     "ethcnn_get_thresholds": (_i, [_vp, _fp, _fp]),
     "ethcnn_predict_luma_device": (_i, [_vp, _vp, _i, _i, _pd, _pd, _i, _i, _vp]),
     "ethcnn_set_pass_pipeline": (_i, [_vp, _i]),
-    "ethcnn_set_fused_launch": (_i, [_vp, _i]),
     "ethcnn_set_small_pass_launch": (_i, [_vp, _i]),
     "ethcnn_set_fc1_plan": (_i, [_vp, _i]),
     "ethcnn_get_fc1_plan": (_i, [_vp]),
@@ -507,11 +506,6 @@ class EthCnn(object):
     def set_pass_pipeline(self, on=True):
         """CTU-load stage of pass i+1 beside FC1 of pass i (default on); off = one stream, stage timings do not overlap"""
         self._chk(self.lib.ethcnn_set_pass_pipeline(self.h, 1 if on else 0))
-
-    def set_fused_launch(self, mode=1):
-        """launch plan of FC1 / heads / gates: 0 = three launches (default), 1 = one fused launch for big passes,
-        2 = FC1 + a heads launch that applies the gates itself.  Same results in every mode."""
-        self._chk(self.lib.ethcnn_set_fused_launch(self.h, int(mode)))
 
     def measure_mfma_rate(self, seconds=0.05):
         """TFLOP/s of pure exact-fp32 MFMAs this GPU sustains (box calibration for reading roofline fractions)"""

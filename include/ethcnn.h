@@ -243,18 +243,6 @@ int ethcnn_get_stage_times(ethcnn_ctx* ctx, ethcnn_stage_times* out); /* synchro
  * with the pipeline on the stage intervals overlap.  Synchronizes.  Environment: ETHCNN_OVERLAP=0 starts contexts with it off. */
 int ethcnn_set_pass_pipeline(ethcnn_ctx* ctx, int on);
 int ethcnn_reset_stage_times(ethcnn_ctx* ctx);
-/* Launch plan of the FC1 / heads / gate stages of a pass (results never depend on it: same accumulation chains):
- *   0 (default)  FC1 launch, heads launch, k5_gate launch;
- *   1            passes of >= 73,728 CTUs run FC1, the three heads and the gates as ONE launch (heads blocks appended to FC1's
- *                grid behind per-tile completion counters, gates applied per sub-batch by the block that completes it; time
- *                booked under ETHCNN_STAGE_FC1); env ETHCNN_FUSED=1 starts contexts in it.  Its waiting blocks have no
- *                claim-or-execute path (the single-launch small pass has): do NOT use it when several processes share the GPU;
- *   2            FC1 launch + heads launch that applies the gates itself (ETHCNN_STAGE_GATE counts no launches); env
- *                ETHCNN_GATE_FOLD=1.
- * Plans 1 and 2 were built in round 3 to remove launch boundaries and to fill FC1's draining rounds; measured on MI355X they
- * are equal to 1 % slower than plan 0 (the matrix pipe has no idle time to give in FC1's drain, and agent-scope hand-offs cost
- * what the boundaries did: DESIGN.md section 3), so plan 0 stays the default. */
-int ethcnn_set_fused_launch(ethcnn_ctx* ctx, int mode);
 /* Arithmetic plan of the big (multi-launch) All-Intra passes.  FC1 ([N,2688] x
  * [2688,448]) is 78 % of the path's arithmetic and the exact-fp32 MFMA runs at 1/16 of the 16-bit matrix rate.
  *   0 (default)  exact fp32 on v_mfma_f32_16x16x4_f32: every result of the library is bit-identical to oracle/ethcnn_oracle.c;

@@ -1,8 +1,8 @@
-"""GPU: the three launch plans of the FC1 / heads / gate stages (ethcnn_set_fused_launch: 0 = three launches, the default;
-1 = FC1 + heads + gates as one launch, csrc/ethcnn_fused.hip, passes of >= 73,728 CTUs; 2 = the heads launch applies the gates
-itself) against the oracle and against each other: bit-identical probabilities with open, closed and mixed gates
-(thresholds exactly at a sub-batch maximum), a ragged last 64-CTU tile, several passes per call, and a pass that starts in
-the middle of a frame (sub-batch index offset c0 != 0 in the gate block's inverse chunk map)."""
+"""GPU: big (multi-launch) passes of the device entry against the oracle: bit-identical probabilities with open, closed and mixed
+gates (thresholds exactly at a sub-batch maximum), a ragged last 64-CTU tile, several passes per call, a pass that starts in the
+middle of a frame (sub-batch index offset c0 != 0 in the gate kernel's chunk map), and back-to-back asynchronous calls through the
+pass pipeline.  (Round 3's merged launch plans -- FC1 + heads + gates as one launch, gates inside the heads launch -- were tested
+here against the separate launches; they measured equal to 1 % slower and were removed in round 6: one launch sequence per plan.)"""
 import os
 import sys
 
@@ -37,8 +37,7 @@ def _strip(nctu, nframes, seed):
     return pool[idx].reshape(nframes, nctu * 64, 64)
 
 
-def _run(c, luma, nctu, nframes, qp, plan):
-    c.set_fused_launch(int(plan))
+def _run(c, luma, nctu, nframes, qp):
     d_in, d_out = c.alloc(luma.nbytes), c.alloc(nframes * nctu * 21 * 4)
     d_in.upload(luma)
     c.predict_luma_device(d_in, 64, 64 * nctu, nframes, qp, d_out)
@@ -49,15 +48,15 @@ def _run(c, luma, nctu, nframes, qp, plan):
     return out
 
 
-def test_fused_launch_matches_oracle_and_separate_launches(pkg, oracle):
-    nctu, nframes, qp = 1100, 68, 32            # 74,800 CTUs: one fused pass; 74,800 = 1168 x 64 + 48 (ragged last tile)
+def test_one_big_pass_matches_oracle_in_every_gate_state(pkg, oracle):
+    nctu, nframes, qp = 1100, 68, 32            # 74,800 CTUs: one pass; 74,800 = 1168 x 64 + 48 (ragged last tile)
     blob = oracle.synth_blob(5, 2.0)
     luma = _strip(nctu, nframes, 77)
     c = pkg.EthCnn(device=0)
     c.load_blob(blob)
     try:
         c.set_thresholds(-1.0, -1.0)
-        raw = _run(c, luma, nctu, nframes, qp, True)
+        raw = _run(c, luma, nctu, nframes, qp)
         want_raw = oracle.predict_frames(blob, luma, 64, 64 * nctu, nframes, qp, -1.0, -1.0, mode=0)
         assert np.array_equal(_bits(raw), _bits(want_raw))
         st = c.stage_times()
@@ -67,30 +66,24 @@ def test_fused_launch_matches_oracle_and_separate_launches(pkg, oracle):
         for t1, t2 in ((0.5, 0.5), (m64, 0.5), (0.55, m32), (2.0, -0.5), (2.0, 0.0), (float(np.median(raw[:, 0])), 0.6)):
             c.set_thresholds(t1, t2)
             want = gates_ref.gate_frames(raw, nctu, t1, t2)          # independent gate evaluation on the ungated values
-            for plan in (1, 0, 2):
-                assert np.array_equal(_bits(_run(c, luma, nctu, nframes, qp, plan)), _bits(want)), (t1, t2, plan)
+            assert np.array_equal(_bits(_run(c, luma, nctu, nframes, qp)), _bits(want)), (t1, t2)
             for a in range(0, raw.shape[0], 1100):
                 for s0, s1 in ((a, a + 1024), (a + 1024, a + 1100)):
                     states.add((not want[s0:s1, 1:5].any(), not want[s0:s1, 5:].any()))
         assert len(states) >= 3, states                                # open, half-closed and closed sub-batches all occurred
-        # the fused launch books its time under the FC1 stage and launches no separate heads / gate kernels
+        # one launch per stage and pass
         c.set_profiling(2)
         c.reset_stage_times()
-        _run(c, luma, nctu, nframes, qp, True)
+        _run(c, luma, nctu, nframes, qp)
         st = c.stage_times()
-        assert st["launches"]["fc1"] == 1 and st["launches"]["heads"] == 0 and st["launches"]["gate"] == 0
-        for plan, gate_launches in ((2, 0), (0, 1)):
-            c.reset_stage_times()
-            _run(c, luma, nctu, nframes, qp, plan)
-            st = c.stage_times()
-            assert st["launches"]["fc1"] == 1 and st["launches"]["heads"] == 1 and st["launches"]["gate"] == gate_launches
+        assert st["launches"]["fc1"] == 1 and st["launches"]["heads"] == 1 and st["launches"]["gate"] == 1
         c.set_profiling(0)
     finally:
         c.close()
 
 
-def test_fused_passes_inside_one_huge_frame(pkg, oracle):
-    """one frame of 170,000 CTUs with an 81,920-CTU workspace: passes of 81,920 (fused), 81,920 (fused, starts at sub-batch 80
+def test_passes_inside_one_huge_frame(pkg, oracle):
+    """one frame of 170,000 CTUs with an 81,920-CTU workspace: passes of 81,920, 81,920 (starts at sub-batch 80
     of the frame) and 6,160 CTUs; mixed gates; vs the oracle's whole-frame evaluation"""
     nctu, qp = 170000, 27
     blob = oracle.synth_blob(9, 2.0)
@@ -99,7 +92,7 @@ def test_fused_passes_inside_one_huge_frame(pkg, oracle):
     c.load_blob(blob)
     try:
         c.set_thresholds(-1.0, -1.0)
-        raw = _run(c, luma, nctu, 1, qp, True)
+        raw = _run(c, luma, nctu, 1, qp)
         t1 = float(raw[1024:2048, 0].max())   # exactly the maximum of a low-contrast sub-batch: closed there, open in busy ones
         c.set_thresholds(t1, 0.6)
         want = oracle.predict_frames(blob, luma, 64, 64 * nctu, 1, qp, t1, 0.6, mode=0)
@@ -107,16 +100,15 @@ def test_fused_passes_inside_one_huge_frame(pkg, oracle):
         closed = [not want[a:a + 1024, 1:5].any() for a in range(0, nctu, 1024)]
         assert any(closed) and not all(closed)
         assert any(closed[80:160]) and not all(closed[80:160])         # inside the second (offset) pass too
-        for plan in (1, 0, 2):
-            got = _run(c, luma, nctu, 1, qp, plan)
-            assert np.array_equal(_bits(got), _bits(want)), plan
+        got = _run(c, luma, nctu, 1, qp)
+        assert np.array_equal(_bits(got), _bits(want))
     finally:
         c.close()
 
 
-def test_fused_launch_back_to_back_async_calls(pkg, oracle):
+def test_back_to_back_async_calls(pkg, oracle):
     """what bench.py issues: consecutive asynchronous calls (pass pipeline on: the tile stage of call i+1 zeroes the OTHER
-    sync area while the fused launch of call i still uses its own)"""
+    set of gate predicates while heads + gate of call i still use their own)"""
     nctu, nframes, qp = 2040, 40, 32   # 81,600 CTUs = 3840x2160 geometry count, as a strip
     blob = oracle.synth_blob(3, 8.0)
     luma = _strip(nctu, nframes, 79)
@@ -124,7 +116,6 @@ def test_fused_launch_back_to_back_async_calls(pkg, oracle):
     c.load_blob(blob)
     try:
         c.set_thresholds(0.5, 0.5)
-        c.set_fused_launch(1)
         want = oracle.predict_frames(blob, luma, 64, 64 * nctu, nframes, qp, 0.5, 0.5, mode=0)
         d_in = c.alloc(luma.nbytes)
         outs = [c.alloc(want.nbytes) for _ in range(4)]
