@@ -261,7 +261,7 @@ def main():
                                  "bound": "mfma", "achieved": nprod * f_alg, "peak": PEAK_BF16_MFMA_TFLOPS,
                                  "unit": "TFLOP/s (16-bit products issued)", "frac": nprod * f_alg / PEAK_BF16_MFMA_TFLOPS,
                                  "algorithmic_f32_tflops": f_alg, "avg_launch_ms": f_ms, "launches_timed": f_st["timed"]["fc1"],
-                                 "flop_per_ctu_issued": nprod * FC1_FLOP_PER_CTU, **pmc_traffic_fast(args.workload, fc1_plan),
+                                 "flop_per_ctu_issued": nprod * FC1_FLOP_PER_CTU, **pmc_traffic("%s_plan%d" % (args.workload, fc1_plan)),
                                  "note": "the chip lowers its shader clock under dense 16-bit MFMA streams (profiles/r04_power_probe.txt): "
                                          "the data-sheet peak assumes 2.4 GHz"},
                     "stages_ms_per_step": {k: v / 3.0 for k, v in f_all["ms"].items()},
@@ -314,8 +314,7 @@ def main():
             "ctu_load_stage": {"kernel": "k0_tile", "bound": "hbm", "achieved": tile_gbps, "peak": PEAK_HBM_GBPS,
                                "unit": "GB/s", "frac": tile_gbps / PEAK_HBM_GBPS, "avg_launch_ms": tile_ms,
                                "algorithmic_bytes_per_ctu": 4096,
-                               "counter_bytes_per_ctu": {"fetched": 4066, "written": 6656,
-                                                         "source": "rocprofv3 --pmc FETCH_SIZE (x2) / WRITE_SIZE of k0_tile_slab, profiles/r04_tile_fold.txt"},
+                               "counter_bytes_per_ctu": ctu_load_counters(args.workload, ctus_per_step),
                                "form": "k0_tile_slab on a side stream beside FC1 of the previous step; the form folded into the trunk "
                                        "(no slab records, no side stream) was measured 3.5 % slower per step (profiles/r04_tile_fold.txt)"},
         }
@@ -737,48 +736,41 @@ def cpu_baseline_ldp(luma, W, H, QP, target_seconds):
                       % (n, W, H, nctu, dt)}
 
 
-def pmc_traffic(workload):
-    """HBM bytes per FC1 launch.  PMC counters cannot be read from inside this process: they come
-    from the separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command
-    (scripts/gpu_round.sh), whose per-launch result is committed as profiles/fc1_traffic.json.
+def _step_traffic():
+    """profiles/step_traffic.json (scripts/gpu_step_traffic.sh -> scripts/pmc_traffic.py), or None when it was taken at other kernel
+    sources: the committed PMC passes are only valid for the device code they ran (one hash over every .hip / .h of csrc/)"""
+    d = json.load(open(os.path.join(ROOT, "profiles", "step_traffic.json")))
+    return d if d.get("kernel_source_stamp") == kernel_source_stamp() else None
+
+
+def pmc_traffic(key):
+    """HBM bytes per FC1 launch of the step `key` (c3 / c2 / c3_plan2 ...).  PMC counters cannot be read from inside this process: they
+    come from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this command restricted to ONE workload
+    (--no-other-configs), aggregated per kernel AND grid size (scripts/pmc_traffic.py; VERDICT r05: the round-5 figure averaged the
+    FC1 dispatches of three workloads).  The number is the sum of the FC1 rows of hbm.per_kernel_bytes -- the same file, the same rows.
     FETCH_SIZE is doubled (gfx950 under-counts wide coalesced reads by 2x, MI355X_MICROARCH.md)."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "fc1_traffic.json")))[workload]
-        # the committed PMC pass is only valid for the kernel source it was taken at: stamped with the git blob hashes of
-        # ethcnn_dense.hip + ethcnn_fc1_tile.h; a different kernel -> no number rather than a stale one (scripts/gpu_round.sh refreshes it)
-        now = fc1_source_stamp()
-        if d.get("kernel_source_blob") != now:
-            return {"traffic": None, "traffic_note": "profiles/fc1_traffic.json was taken at FC1 kernel source %s, the kernel "
-                                                     "is now %s: re-run scripts/gpu_round.sh" % (d.get("kernel_source_blob"), now)}
-        return {"traffic": d["bytes_per_launch"], "traffic_unit": "B/launch",
-                "traffic_algorithmic": d["algorithmic_bytes_per_launch"], "traffic_source": d["source"],
-                "traffic_kernel_source_blob": now}
+        d = _step_traffic()
+        if d is None:
+            return {"traffic": None, "traffic_note": "profiles/step_traffic.json was taken at other kernel sources: re-run scripts/gpu_step_traffic.sh"}
+        e = d[key]
+        return {"traffic": e["fc1_bytes_per_launch"], "traffic_unit": "B/launch", "traffic_algorithmic": e["fc1_algorithmic_bytes_per_launch"],
+                "traffic_over_algorithmic": e["fc1_bytes_per_launch"] / e["fc1_algorithmic_bytes_per_launch"],
+                "traffic_rows": {k: v["bytes"] for k, v in e["per_kernel"].items() if k.startswith("k_fc1")},
+                "traffic_source": d["source"], "traffic_kernel_source_stamp": d["kernel_source_stamp"]}
     except Exception:
         return {"traffic": None}
 
 
-def fc1_source_stamp():
-    """identifies the FC1 kernel source: the git blob hashes of the two files that hold its device code"""
-    src = os.path.join(ROOT, "hevc-complexity-reduction_amd", "csrc")
-    return "+".join(git_blob_sha1(os.path.join(src, f))[:12] for f in ("ethcnn_dense.hip", "ethcnn_fc1_tile.h"))
-
-
-def fc1_fast_source_stamp():
-    src = os.path.join(ROOT, "hevc-complexity-reduction_amd", "csrc")
-    return git_blob_sha1(os.path.join(src, "ethcnn_fc1_fast.hip"))[:12]
-
-
-def pmc_traffic_fast(workload, plan):
-    """HBM bytes per k_fc1_fast launch from the committed PMC passes (profiles/fc1_traffic.json, key <workload>_plan<n>), valid only
-    for the kernel source they were taken at"""
+def ctu_load_counters(key, n_ctus):
+    """FETCH / WRITE counter bytes per CTU of the CTU-load stage (k0_tile_slab) from the same stamped file"""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "fc1_traffic.json")))["%s_plan%d" % (workload, plan)]
-        if d.get("kernel_source_blob") != fc1_fast_source_stamp():
-            return {"traffic": None, "traffic_note": "profiles/fc1_traffic.json is from another version of ethcnn_fc1_fast.hip: re-run scripts/gpu_round.sh"}
-        return {"traffic": d["bytes_per_launch"], "traffic_unit": "B/launch", "traffic_algorithmic": d["algorithmic_bytes_per_launch"],
-                "traffic_source": d["source"]}
+        d = _step_traffic()
+        e = next(v for k, v in d[key]["per_kernel"].items() if k.startswith("k0_tile"))
+        return {"fetched": round(e["fetch_bytes"] / n_ctus, 1), "written": round(e["write_bytes"] / n_ctus, 1),
+                "source": "profiles/step_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE of k0_tile_slab, scripts/gpu_step_traffic.sh)"}
     except Exception:
-        return {"traffic": None}
+        return {"fetched": None, "written": None, "source": "profiles/step_traffic.json has no current k0_tile_slab row: re-run scripts/gpu_step_traffic.sh"}
 
 
 def kernel_source_stamp():
@@ -794,13 +786,13 @@ def step_hbm(key, ms_per_step):
     key: c3 / c3_plan2 / c3_plan3) against this run's step time: how close the STEP is to the memory system, beside the FC1
     `roofline` object.  Valid only for the kernel sources the passes were taken at."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "step_traffic.json")))
-        if d.get("kernel_source_stamp") != kernel_source_stamp():
+        d = _step_traffic()
+        if d is None:
             return {"bytes_per_step": None, "note": "profiles/step_traffic.json was taken at other kernel sources: re-run scripts/gpu_step_traffic.sh"}
         e = d[key]
         gbps = e["bytes_per_step"] / (ms_per_step * 1e-3) / 1e9
         return {"bytes_per_step": e["bytes_per_step"], "gbps": gbps, "frac_of_6.3TBps": gbps / 6300.0,
-                "algorithmic_bytes_per_step": e["algorithmic_bytes_per_step"], "per_kernel_bytes": e["per_kernel"],
+                "algorithmic_bytes_per_step": e["algorithmic_bytes_per_step"], "per_kernel_bytes": {k: v["bytes"] for k, v in e["per_kernel"].items()},
                 "source": d["source"], "note": "counter bytes (FETCH_SIZE x 2 + WRITE_SIZE) of a separate PMC run / this run's ms_per_step; "
                                                "6.3 TB/s = what the guide calls achievable of the 8 TB/s peak"}
     except Exception as exc:  # noqa: BLE001

@@ -2,7 +2,7 @@
 # copies the judged summaries of the last scripts/gpu_round.sh call from gpurun_out/ (scratch) to profiles/ (tracked)
 # usage: scripts/collect_round.sh r02
 set -eu
-R=${1:-r05}
+R=${1:-r06}
 cd "$(dirname "$0")/.."
 for wl in c2 c3 c4 c5; do [ -s gpurun_out/bench_$wl.json ] && cp gpurun_out/bench_$wl.json profiles/${R}_bench_$wl.json; done
 for wl in c2 c3; do
@@ -24,6 +24,7 @@ if [ -s gpurun_out/latency_mid_now.txt ]; then { grep "^#" profiles/${R}_latency
 [ -s gpurun_out/power_probe.txt ] && cp gpurun_out/power_probe.txt profiles/${R}_power_probe.txt
 if [ -s gpurun_out/ldp_handshake.txt ]; then { grep "^#" gpurun_out/ldp_handshake.txt; grep "^# native\|^# first form\|^#   \|^#    \|^# Boxes" profiles/${R}_ldp_handshake.txt 2>/dev/null; grep -v "^#" gpurun_out/ldp_handshake.txt; } > /tmp/_hs.txt && cp /tmp/_hs.txt profiles/${R}_ldp_handshake.txt; fi
 [ -s gpurun_out/step_traffic.json ] && cp gpurun_out/step_traffic.json profiles/step_traffic.json
+for f in gpurun_out/traffic_by_kernel_grid_*.csv gpurun_out/kernel_stats_by_grid_*.csv; do [ -s "$f" ] && cp "$f" profiles/${R}_$(basename "$f"); done
 python - "$R" <<'PY'
 import csv, glob, collections, json, sys
 R = sys.argv[1]
@@ -32,24 +33,15 @@ lines = []
 for f in sorted(glob.glob("gpurun_out/pmc_c3_*/**/*counter_collection.csv", recursive=True)):
     agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"][:60]
-        if "ethcnn" not in k: continue
+        if "ethcnn" not in r["Kernel_Name"]: continue
+        k = r["Kernel_Name"].replace("void ", "").replace("ethcnn::", "").split("(")[0] + " @" + r["Grid_Size"]  # kernel AND grid size
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(k, r["Counter_Name"])] += 1
     for k, d in agg.items():
         lines.append("%-62s %s" % (k, {c: "%.5g" % (v / cnt[(k, c)]) for c, v in d.items()}))
 if lines:
     open("profiles/%s_pmc_c3.txt" % R, "w").write(
         "# rocprofv3 --pmc passes (one counter set per pass, --kernel-trace only) of `python bench.py --workload c3 --no-cpu-baseline\n"
-        "# --no-host-scopes --steps 5 --warmup 1` (scripts/gpu_round.sh); per-dispatch averages.  FETCH_SIZE / WRITE_SIZE in KB as\n"
+        "# --no-host-scopes --no-other-configs --no-fast-plan --steps 5 --warmup 1` (scripts/gpu_round.sh); per-dispatch averages per kernel @grid size.  FETCH_SIZE / WRITE_SIZE in KB as\n"
         "# reported (FETCH_SIZE x2 on gfx950 for bytes); SQ_* summed over the chip; GRBM_GUI_ACTIVE summed over the 8 XCDs.\n" + "\n".join(lines) + "\n")
-# FC1 traffic: merge the per-workload results into profiles/fc1_traffic.json
-try:
-    cur = json.load(open("profiles/fc1_traffic.json"))
-except Exception:
-    cur = {}
-for f in glob.glob("gpurun_out/fc1_traffic_*.json"):
-    cur.update(json.load(open(f)))
-json.dump(cur, open("profiles/fc1_traffic.json", "w"), indent=1)
-print("fc1_traffic workloads:", sorted(cur))
 PY
 ls profiles | grep "^$R" | tr '\n' ' '; echo

@@ -97,6 +97,19 @@ def test_one_gpu_line_states_the_north_star_ratio_and_the_fast_plans():
     assert abs(d["vs_baseline"] - hs["s3_file_to_file_ctus_per_s"] / next(
         b["value"] for b in d["cpu_baselines"] if b["name"].startswith("B1 oracle") and "file scope" in b["name"])) < 1e-9
     assert "fast_plan" not in d  # (round 4's bf16 x 3 plan is gone)
+    # roofline.traffic IS the FC1 rows of hbm.per_kernel_bytes (one stamped file, one workload, per kernel AND grid
+    # size) -- or absent when the committed PMC passes were taken at other kernel sources; never an average over other configs' launches
+    for obj in (d, d["fast_plan_fp16x2"], d["fast_plan_fp16x2_trunk"]):
+        rl, hbm = obj["roofline"], obj["hbm"]
+        if rl.get("traffic") is not None:
+            fc1_rows = {k: v for k, v in hbm["per_kernel_bytes"].items() if k.startswith("k_fc1")}
+            assert fc1_rows and rl["traffic"] == sum(fc1_rows.values()) == sum(rl["traffic_rows"].values()), (rl["traffic"], fc1_rows)
+            assert all("@" in k for k in hbm["per_kernel_bytes"])          # every row names its grid size
+            assert 1.0 <= rl["traffic_over_algorithmic"] < 3.0
+        else:
+            assert hbm["bytes_per_step"] is None                            # the same stamp rules both
+    cl = d["ctu_load_stage"]["counter_bytes_per_ctu"]
+    assert cl["fetched"] is None or (3500 < cl["fetched"] < 12000 and 6000 < cl["written"] < 8000), cl
     for key, dtype_word in (("fast_plan_fp16x2", "fp16x2"), ("fast_plan_fp16x2_trunk", "fp16x2")):
         fp = d[key]
         assert dtype_word in fp["dtype"] and fp["value"] > 0 and fp["roofline"]["peak"] == 2500.0
