@@ -83,8 +83,10 @@ int ensure_workspace(ethcnn_ctx* c, int n, int chunks) {
 extern "C" int ethcnn_create(ethcnn_ctx** out, const ethcnn_options* opt) {
     if (!out) return set_err(nullptr, ETHCNN_ERR_ARG, "ethcnn_create: out is NULL");
     *out = nullptr;
+    const auto t_enter = std::chrono::steady_clock::now();
     int ndev = 0;
-    hipError_t e = hipGetDeviceCount(&ndev);
+    hipError_t e = hipGetDeviceCount(&ndev);  // (the first HIP call of a process: loads and initialises the runtime)
+    const auto t_runtime = std::chrono::steady_clock::now();
     if (e != hipSuccess || ndev <= 0)
         return set_err(nullptr, ETHCNN_ERR_DEVICE, "no HIP device available (%s): libethcnn has no CPU fallback",
                        e == hipSuccess ? "device count 0" : hipGetErrorString(e));
@@ -189,6 +191,8 @@ extern "C" int ethcnn_create(ethcnn_ctx** out, const ethcnn_options* opt) {
         }
     }
     if (const char* e = dev_env("ETHCNN_TILE_BLOCKS")) c->tile_blocks = std::max(1, std::atoi(e));
+    c->startup_ms[0] = std::chrono::duration<double, std::milli>(t_runtime - t_enter).count();
+    c->startup_ms[1] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enter).count();
     *out = c;
     return ETHCNN_OK;
 }
@@ -205,6 +209,9 @@ extern "C" void ethcnn_destroy(ethcnn_ctx* c) {
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     free_workspace(c);
     free_staging(c);
+    for (ethcnn_ctx* p : c->peers) ethcnn_destroy(p);  // workers of ethcnn_predict_yuv_file_sharded
+    c->peers.clear();
+    (void)hipSetDevice(c->device);
     for (const auto& r : c->pinned) (void)hipHostFree(const_cast<char*>(r.first));  // ethcnn_host_alloc buffers die with the context
     delete c->pool;
     if (c->dw_arena) (void)hipFree(c->dw_arena);
@@ -225,6 +232,14 @@ extern "C" void ethcnn_destroy(ethcnn_ctx* c) {
     for (hipStream_t st : streams)
         if (st) (void)hipStreamDestroy(st);
     delete c;
+}
+
+// where ethcnn_create's time went (cold start of the drop-in command: VERDICT r05 weak 8)
+extern "C" int ethcnn_get_startup_times(const ethcnn_ctx* c, double* runtime_init_ms, double* create_ms) {
+    if (!c) return ETHCNN_ERR_ARG;
+    if (runtime_init_ms) *runtime_init_ms = c->startup_ms[0];
+    if (create_ms) *create_ms = c->startup_ms[1];
+    return ETHCNN_OK;
 }
 
 extern "C" int ethcnn_device_name(const ethcnn_ctx* c, char* out, size_t cap) {

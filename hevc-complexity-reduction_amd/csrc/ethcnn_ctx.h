@@ -146,6 +146,7 @@ struct ethcnn_ctx {
     hipStream_t copy_out = nullptr; // D2H of the previous pass
     char devname[128] = {0};
     std::string err;
+    double startup_ms[2] = {0, 0};  // ethcnn_create: its first HIP call (runtime initialisation) / the whole call
 
     bool have_weights = false;
     std::vector<float> blob;
@@ -205,6 +206,11 @@ struct ethcnn_ctx {
     uint16_t* dw_fast = nullptr;                // W1 in the form of plan 2 (packed on first use), 4.8 MB
     uint16_t* dw_trunk16 = nullptr;             // plan 3: the trunk's A operands as fp16 x 2 pieces + its per-lane constants (one allocation)
     uint16_t* dw_heads16 = nullptr;             // plan 3: FC2 / FC3 A operands as fp16 x 2 pieces (kHeads16Halves)
+    // load-time accuracy guard of the 16-bit plans (ethcnn_model.cpp::check_fast_plan), per plan, reset by every weight load
+    int guard_state[4] = {0, 0, 0, 0};          // 0 not evaluated, 1 accepted, 2 refused, 3 calibrating
+    double guard_bound[4] = {0, 0, 0, 0};       // a-priori worst case of a probability's error (ethcnn_spec.h::fast_plan_floor_bound)
+    double guard_measured[4] = {-1, -1, -1, -1}; // max |dp| vs the exact plan on the calibration picture; < 0: not measured (the bound sufficed)
+    FastGuard guard_info[4] = {};
     int last_fast = 0;       // the FC1 plan of the last pass (debug_fetch reads the features of plans 1 / 2 from ws.featb)
     // completion word (page-locked host memory): the last block of a latency-path launch stores the launch's sequence number
     // there and the host spins on it instead of calling hipStreamSynchronize (~5 us sooner, scripts/ubench/launch_rtt.hip)
@@ -219,7 +225,8 @@ struct ethcnn_ctx {
     float* host_probs = nullptr;               // set around a host -> host single-launch pass: page-locked destination its last block copies the
                                                // probabilities to (then no copy launch behind the kernel: the caller waits on the completion word)
     bool host_probs_used = false;              // ... and whether the pass took it (single-launch form, completion word armed)
-    struct LdpPending { bool open = false, streamed = false; float* probs = nullptr; float* d_probs = nullptr; size_t pbytes = 0; int out = 0, in = -1, nctu = 0; } ldp;
+    struct LdpPending { bool open = false, streamed = false; float* probs = nullptr; float* d_probs = nullptr; size_t pbytes = 0; int out = 0, in = -1, nctu = 0;
+                        bool in_from_host = false; int prev_cur = -1, prev_nctu = 0; } ldp;  // (prev_*: the state resident before the step, for the give-up path)
     struct LumaPending { bool open = false, direct = false; float* probs = nullptr; size_t out_bytes = 0; } ai;  // ethcnn_predict_luma_begin ... _end
     unsigned done_seq = 0;     // last number handed out
     unsigned done_armed = 0;   // != 0: the LAST operation enqueued on the main stream stores this number when all its outputs are final
@@ -249,6 +256,12 @@ struct ethcnn_ctx {
     hipEvent_t ev_in[kStageBufs] = {}, ev_comp[kStageBufs] = {}, ev_out[kStageBufs] = {};  // created with the ring, destroyed with it
     size_t in_cap = 0, out_cap = 0;
     std::vector<std::pair<const char*, size_t>> pinned;  // ethcnn_host_alloc'ed ranges: device-addressable as they are
+    // ethcnn_predict_yuv_file_sharded: the contexts of workers 1.., created on first use, destroyed with this one; a peer remembers
+    // whose weights (and which load of them) it holds
+    std::vector<ethcnn_ctx*> peers;
+    int shard_workers = 1;             // workers of this process the host-thread budget is divided by
+    const ethcnn_ctx* weights_from = nullptr;
+    unsigned weights_gen = 0;          // counts weight loads of this context
     HostPool* pool = nullptr;  // created on first use by the host / file entry points
     NumaCpus numa;             // the GPU's host NUMA node (staging buffers + fill threads are placed there)
 };
@@ -271,6 +284,8 @@ int ensure_workspace(ethcnn_ctx* c, int n, int chunks);
 hipEvent_t get_event(ethcnn_ctx* c);
 // ethcnn_model.cpp
 int ensure_fast_weights(ethcnn_ctx* c, int plan);
+// ethcnn_pass.cpp: the measured stage of the plans' accuracy guard (max |dp| of the plan vs the exact plan on the calibration picture)
+int calibrate_fast_plan(ethcnn_ctx* c, int plan, double* max_abs);
 // ethcnn_pass.cpp
 int make_geom(ethcnn_ctx* c, int w, int h, ptrdiff_t pitch, ptrdiff_t fstride, FrameGeom* g);
 unsigned done_arm(ethcnn_ctx* c);

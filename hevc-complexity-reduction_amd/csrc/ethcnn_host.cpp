@@ -81,7 +81,9 @@ static int local_workers() {
 
 static HostPool* host_pool(ethcnn_ctx* c) {
     if (!c->pool) {
-        int nt = ethcnn_host_thread_budget(local_workers(), 0);
+        // (shard_workers: this context is one of several workers of ONE process -- ethcnn_predict_yuv_file_sharded -- on top of
+        // whatever other predictor processes share the node)
+        int nt = ethcnn_host_thread_budget(local_workers() * std::max(1, c->shard_workers), 0);
         if (c->host_threads_opt > 0) nt = std::min(32, c->host_threads_opt);
         if (const char* e = std::getenv("ETHCNN_HOST_THREADS")) nt = std::max(1, std::min(32, std::atoi(e)));  // explicit override
         c->pool = new HostPool(nt, c->numa);
@@ -428,7 +430,7 @@ extern "C" int ethcnn_predict_luma_end(ethcnn_ctx* c) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     if (__atomic_load_n(c->h_done + 1, __ATOMIC_ACQUIRE) == seq)
-        return set_err(c, ETHCNN_ERR_DEVICE, "ethcnn_predict_luma_end: the kernels waited 1 s for luma rows that were never reported (ethcnn_rows_ready)");
+        return set_err(c, ETHCNN_ERR_ROWS_TIMEOUT, "ethcnn_predict_luma_end: the kernels waited 1 s for luma rows that were never reported (ethcnn_rows_ready)");
     if (dst != c->ai.probs) std::memcpy(c->ai.probs, dst, c->ai.out_bytes);
     return ETHCNN_OK;
 }
@@ -545,6 +547,127 @@ extern "C" int ethcnn_predict_yuv_file(ethcnn_ctx* c, const char* yuv, int w, in
                                        int64_t* nframes_out) {
     if (!c || !yuv || !out_path) return c ? set_err(c, ETHCNN_ERR_ARG, "null path") : ETHCNN_ERR_ARG;
     return yuv_frames(c, yuv, w, h, qp, out_path, 0, 0, 0, nframes_out);
+}
+
+// ---- the whole file over several GPUs from ONE process: a worker THREAD per listed device ("process-per-GPU or
+// thread-per-GPU"; 8e: contiguous frame ranges, no collective).  The reference's caller blocks in system() (TAppEncCfg.cpp:2317-2321):
+// what the encoder sees is the wall time of the command, and N Python interpreters that each create a context, parse and crc a
+// checkpoint and pin a staging ring to do ~18 ms of GPU work (C4 / 8) cost more than they share out.  Here the calling context is
+// worker 0; a peer context per further device is created once (cached with the context, destroyed with it) and takes a COPY of the
+// caller's weights, thresholds and plan -- no second checkpoint parse.  Each worker preads its frames and pwrites them at
+// frame_begin * nctu * 84 into a pre-sized temp file; one rename at the end.  Byte-identical to ethcnn_predict_yuv_file.
+static int sync_peer(ethcnn_ctx* c, ethcnn_ctx* p) {
+    if (p->weights_from != c || p->weights_gen != c->weights_gen) {
+        const int rc = ethcnn_load_blob(p, c->blob.data(), c->blob.size());
+        if (rc) return set_err(c, rc, "worker on device %d: %s", p->device, p->err.c_str());
+        p->weights_from = c;
+        p->weights_gen = c->weights_gen;
+    }
+    p->thr1 = c->thr1;
+    p->thr2 = c->thr2;
+    p->fc1_plan = c->fc1_plan;
+    p->max_ctus = c->max_ctus;
+    for (int pl : {2, 3}) {  // the accuracy guard is a function of the weights: decided once, by the caller's context
+        p->guard_state[pl] = c->guard_state[pl] == 3 ? 0 : c->guard_state[pl];
+        p->guard_bound[pl] = c->guard_bound[pl];
+        p->guard_measured[pl] = c->guard_measured[pl];
+        p->guard_info[pl] = c->guard_info[pl];
+    }
+    return 0;
+}
+extern "C" int ethcnn_predict_yuv_file_sharded(ethcnn_ctx* c, const int* devices, int ndevices, const char* yuv, int w, int h, int qp,
+                                               const char* out_path, int64_t* nframes_out) {
+    if (!c || !yuv || !out_path || !devices || ndevices < 1 || ndevices > 64)
+        return c ? set_err(c, ETHCNN_ERR_ARG, "ethcnn_predict_yuv_file_sharded: null path / device list, or not 1..64 devices") : ETHCNN_ERR_ARG;
+    if (devices[0] != c->device)
+        return set_err(c, ETHCNN_ERR_ARG, "ethcnn_predict_yuv_file_sharded: devices[0] = %d, but this context (worker 0) lives on device %d", devices[0], c->device);
+    if (!c->have_weights) return set_err(c, ETHCNN_ERR_NOWEIGHTS, "no weights loaded");
+    if (w <= 0 || h <= 0) return set_err(c, ETHCNN_ERR_ARG, "bad frame size %dx%d", w, h);
+    struct stat st;
+    if (stat(yuv, &st) != 0) return set_err(c, ETHCNN_ERR_IO, "cannot stat %s: %s", yuv, std::strerror(errno));
+    const int64_t frame_bytes = (int64_t)w * h * 3 / 2;
+    if (frame_bytes == 0 || st.st_size % frame_bytes != 0)
+        return set_err(c, ETHCNN_ERR_FORMAT, "%s: size %lld is not a multiple of the %dx%d 4:2:0 frame size %lld", yuv, (long long)st.st_size, w, h,
+                       (long long)frame_bytes);
+    const int64_t total = st.st_size / frame_bytes;
+    if (nframes_out) *nframes_out = total;
+    if (ndevices == 1 || total <= 1) return yuv_frames(c, yuv, w, h, qp, out_path, 0, 0, 0, nullptr);
+    if (c->fc1_plan) {  // (guard + weight images once, here; the peers inherit the verdict)
+        HIPCHK(c, hipSetDevice(c->device));
+        const int rc = ensure_fast_weights(c, c->fc1_plan);
+        if (rc) return rc;
+    }
+    // workers: the caller's context + one cached peer per further list entry (a device may be listed more than once)
+    const int nw = (int)std::min<int64_t>(ndevices, total);
+    if (c->shard_workers != nw) {  // the host budget is divided by the worker count: pools of another division are rebuilt
+        delete c->pool;
+        c->pool = nullptr;
+        for (ethcnn_ctx* p : c->peers) { delete p->pool; p->pool = nullptr; p->shard_workers = nw; }
+        c->shard_workers = nw;
+    }
+    while ((int)c->peers.size() < nw - 1) {
+        ethcnn_options o{};
+        o.device = devices[c->peers.size() + 1];
+        o.max_ctus_per_pass = c->max_ctus;
+        ethcnn_ctx* p = nullptr;
+        const int rc = ethcnn_create(&p, &o);
+        if (rc) return set_err(c, rc, "worker on device %d: %s", o.device, ethcnn_last_error(nullptr));
+        p->shard_workers = nw;
+        c->peers.push_back(p);
+    }
+    for (int k = 1; k < nw; ++k)
+        if (c->peers[k - 1]->device != devices[k]) {  // another device list than last time: rebuild that peer
+            ethcnn_destroy(c->peers[k - 1]);
+            ethcnn_options o{};
+            o.device = devices[k];
+            o.max_ctus_per_pass = c->max_ctus;
+            c->peers[k - 1] = nullptr;
+            const int rc = ethcnn_create(&c->peers[k - 1], &o);
+            if (rc) { c->peers.resize(k - 1); return set_err(c, rc, "worker on device %d: %s", o.device, ethcnn_last_error(nullptr)); }
+            c->peers[k - 1]->shard_workers = nw;
+        }
+    for (int k = 1; k < nw; ++k) {
+        const int rc = sync_peer(c, c->peers[k - 1]);
+        if (rc) return rc;
+    }
+    const int nctu = ((w + 63) / 64) * ((h + 63) / 64);
+    const std::string tmp = std::string(out_path) + ".tmp." + std::to_string((long)getpid());
+    {   // pre-size the temp file: every worker pwrites its own range
+        FILE* f = std::fopen(tmp.c_str(), "wb");
+        if (!f || ftruncate(fileno(f), (off_t)(total * nctu * kNOut * 4)) != 0) {
+            if (f) std::fclose(f);
+            std::remove(tmp.c_str());
+            return set_err(c, ETHCNN_ERR_IO, "cannot create %s: %s", tmp.c_str(), std::strerror(errno));
+        }
+        std::fclose(f);
+    }
+    std::vector<int> rcs(nw, 0);
+    std::vector<std::thread> th;
+    auto range = [&](int k, int64_t* f0, int64_t* f1) { *f0 = total * k / nw; *f1 = total * (k + 1) / nw; };  // = sharding.frame_range
+    for (int k = 1; k < nw; ++k)
+        th.emplace_back([&, k] {
+            int64_t f0, f1;
+            range(k, &f0, &f1);
+            rcs[k] = yuv_frames(c->peers[k - 1], yuv, w, h, qp, tmp.c_str(), 1, f0, f1, nullptr);
+        });
+    {
+        int64_t f0, f1;
+        range(0, &f0, &f1);
+        rcs[0] = yuv_frames(c, yuv, w, h, qp, tmp.c_str(), 1, f0, f1, nullptr);
+    }
+    for (auto& t : th) t.join();
+    for (int k = 0; k < nw; ++k)
+        if (rcs[k]) {
+            std::remove(tmp.c_str());
+            if (k > 0) return set_err(c, rcs[k], "worker %d (device %d): %s", k, c->peers[k - 1]->device, c->peers[k - 1]->err.c_str());
+            return rcs[0];
+        }
+    if (std::rename(tmp.c_str(), out_path) != 0) {
+        const int e = errno;
+        std::remove(tmp.c_str());
+        return set_err(c, ETHCNN_ERR_IO, "rename %s -> %s failed: %s", tmp.c_str(), out_path, std::strerror(e));
+    }
+    return ETHCNN_OK;
 }
 
 extern "C" int ethcnn_predict_yuv_range(ethcnn_ctx* c, const char* yuv, int w, int h, int qp, const char* out_path,

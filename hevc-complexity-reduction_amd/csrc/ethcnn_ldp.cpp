@@ -209,6 +209,9 @@ static int ldp_step_begin(ethcnn_ctx* c, const uint8_t* luma, int w, int h, ptrd
     c->ldp.out = out;
     c->ldp.in = in;
     c->ldp.nctu = nctu;
+    c->ldp.in_from_host = state_in != nullptr;
+    c->ldp.prev_cur = c->state_cur;    // (after ensure_lstm_buffers: -1 when the buffers were reallocated)
+    c->ldp.prev_nctu = c->state_nctu;
     return ETHCNN_OK;
 }
 
@@ -227,10 +230,22 @@ static int ldp_step_end(ethcnn_ctx* c) {
     }
     HIPCHK(c, stream_sync(c));
     if (c->ldp.streamed && __atomic_load_n(c->h_done + 1, __ATOMIC_ACQUIRE) == seq) {
-        // computed on rows that never arrived: the output state is garbage, the INPUT state (the other buffer) is untouched and stays the
-        // resident one, so the caller may run the frame again (ethcnn_ldp_step on the by now complete buffer) with the same arguments
-        c->state_cur = c->ldp.in;
-        return set_err(c, ETHCNN_ERR_DEVICE, "ethcnn_ldp_step_end: the kernels waited 1 s for luma rows that were never reported (ethcnn_rows_ready)");
+        // computed on rows that never arrived: the output state is garbage, the INPUT state (the other buffer) is untouched, so the caller
+        // may run the frame again (ethcnn_ldp_step on the by now complete buffer) with the same arguments.  What is resident afterwards
+        // (the size must always belong to the buffer):
+        //   resident input        that state, as before the step;
+        //   caller's state_in     the copy of it in buffer 0, for THIS frame's CTU count;
+        //   zeros (i_frame <= 1)  whatever was resident before, unless the failed step wrote over it (it wrote buffer 0).
+        if (c->ldp.in_from_host) {
+            c->state_cur = 0;
+            c->state_nctu = c->ldp.nctu;
+        } else if (c->ldp.in >= 0) {
+            c->state_cur = c->ldp.in;
+        } else {
+            c->state_cur = (c->ldp.prev_cur == c->ldp.out) ? -1 : c->ldp.prev_cur;
+            c->state_nctu = c->ldp.prev_nctu;
+        }
+        return set_err(c, ETHCNN_ERR_ROWS_TIMEOUT, "ethcnn_ldp_step_end: the kernels waited 1 s for luma rows that were never reported (ethcnn_rows_ready)");
     }
     if (c->ldp.d_probs == c->h_out[0]) std::memcpy(c->ldp.probs, c->ldp.d_probs, c->ldp.pbytes);
     c->state_cur = c->ldp.out;

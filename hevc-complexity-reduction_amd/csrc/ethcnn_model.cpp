@@ -60,14 +60,87 @@ static int upload_weights(ethcnn_ctx* c) {
     d.trunk16_w = nullptr;
     d.heads16_w = nullptr;
     d.trunk16_c = nullptr;
+    c->guard_state[2] = c->guard_state[3] = 0;  // (the guard of the 16-bit plans is a function of the weights)
+    ++c->weights_gen;
     c->have_weights = true;
     return ETHCNN_OK;
 }
 
+// Load-time accuracy guard of the 16-bit plans, two stages, cached per weight load (video_to_cu_depth.py:126-133 restores one of four
+// checkpoints per run: any of them must either be safe under an opted-in plan or be refused -- never silently less accurate):
+//   1. a-priori: ethcnn_spec.h::fast_plan_floor_bound, a RIGOROUS bound on what the plan's fp16 floors can move a probability by, from
+//      the weights alone (every error aligned, every activation at its floor).  <= kFastGuardTol: accepted, nothing is run.
+//   2. otherwise the worst case says nothing either way (it is pessimistic by the looseness of the very bounds it guards: plan 3 on
+//      benign weights has a bound of 0.1 and a measured error of 7e-6), so the plan is MEASURED: a seeded calibration picture (flat,
+//      low-contrast, gradient, noise, edge and texture macro tiles, 640 CTUs) through the exact plan and through the plan with the
+//      loaded weights, gates open; max |dp| <= kFastGuardTol: accepted; else refused with both numbers.
+static int build_fast_weights(ethcnn_ctx* c, int plan);
+static int check_fast_plan(ethcnn_ctx* c, int plan) {
+    if (plan != 2 && plan != 3) return set_err(c, ETHCNN_ERR_ARG, "plan must be 2 or 3, got %d", plan);
+    if (!c->have_weights) return set_err(c, ETHCNN_ERR_NOWEIGHTS, "no weights loaded");
+    if (c->guard_state[plan] == 0) {
+        const FastGuard g = fast_plan_floor_bound(c->blob.data(), plan, /*heads16=*/true);
+        c->guard_bound[plan] = g.prob_err;
+        c->guard_info[plan] = g;
+        c->guard_measured[plan] = -1.0;
+        if (g.prob_err <= kFastGuardTol) {
+            c->guard_state[plan] = 1;
+        } else {
+            int rc = build_fast_weights(c, plan);
+            if (rc) return rc;
+            double worst = 0.0;
+            c->guard_state[plan] = 3;  // calibrating: the passes below are not guarded (they ARE the guard)
+            rc = calibrate_fast_plan(c, plan, &worst);
+            c->guard_state[plan] = 0;
+            if (rc) return rc;
+            c->guard_measured[plan] = worst;
+            c->guard_state[plan] = (worst <= kFastGuardTol) ? 1 : 2;  // (a NaN compares false: refused)
+        }
+    }
+    if (c->guard_state[plan] == 3) return ETHCNN_OK;
+    if (c->guard_state[plan] != 1) {
+        const FastGuard& g = c->guard_info[plan];
+        return set_err(c, ETHCNN_ERR_PLAN_REFUSED,
+                       "FC1 plan %d is refused for these weights: its fp16 x 2 pieces are exact to 2^-24 only while a value stays within ~2^12 of the "
+                       "guaranteed bound its scale comes from, and these weights make the bounds too loose for that: on the calibration picture the plan "
+                       "differs from the exact plan by %.3g on a probability (limit %.3g; a-priori worst case %.3g; guaranteed |feature| bound %.4g, "
+                       "max |W1| %.4g): use plan %s",
+                       plan, c->guard_measured[plan], kFastGuardTol, c->guard_bound[plan], g.feature_bound, g.w1_max, plan == 3 ? "2 or 0" : "0");
+    }
+    return ETHCNN_OK;
+}
+// the a-priori bound without a context or a device (host arithmetic on the blob only): what tests and tools print.  ETHCNN_OK: the
+// bound alone accepts the plan; ETHCNN_ERR_PLAN_REFUSED: it does not (a context would go on to measure)
+extern "C" int ethcnn_fast_plan_bound(const float* blob, size_t nfloats, int plan, double* prob_err_bound, double* feature_bound) {
+    if (!blob || nfloats != kBlobFloats || (plan != 2 && plan != 3) || !prob_err_bound) return ETHCNN_ERR_ARG;
+    const FastGuard g = fast_plan_floor_bound(blob, plan, /*heads16=*/true);
+    *prob_err_bound = g.prob_err;
+    if (feature_bound) *feature_bound = g.feature_bound;
+    return g.prob_err <= kFastGuardTol ? ETHCNN_OK : ETHCNN_ERR_PLAN_REFUSED;
+}
+extern "C" int ethcnn_check_fc1_plan(ethcnn_ctx* c, int plan, double* apriori_bound, double* measured) {
+    if (!c) return ETHCNN_ERR_ARG;
+    if (apriori_bound) *apriori_bound = 0.0;
+    if (measured) *measured = -1.0;
+    if (plan == 0) return ETHCNN_OK;
+    if (plan != 2 && plan != 3) return set_err(c, ETHCNN_ERR_ARG, "plan must be 0, 2 or 3, got %d", plan);
+    HIPCHK(c, hipSetDevice(c->device));
+    const int rc = check_fast_plan(c, plan);
+    if (rc == ETHCNN_OK || rc == ETHCNN_ERR_PLAN_REFUSED) {
+        if (apriori_bound) *apriori_bound = c->guard_bound[plan];
+        if (measured) *measured = c->guard_measured[plan];
+    }
+    return rc;
+}
+
 // plan 2: W1 as fp16 x 2 pieces in the MFMA's B-operand order (ethcnn_weights.cpp::pack_fc1_fast_image), once per weight load
 int ensure_fast_weights(ethcnn_ctx* c, int plan) {
+    const int rc = check_fast_plan(c, plan);  // (cached: one comparison per pass after the first)
+    return rc ? rc : build_fast_weights(c, plan);
+}
+static int build_fast_weights(ethcnn_ctx* c, int plan) {
     if (plan == 3) {  // plan 3 = plan 2's FC1 + the trunk's convolutions as fp16 x 2 (ethcnn_trunk_fast.hip)
-        int rc = ensure_fast_weights(c, 2);
+        int rc = build_fast_weights(c, 2);
         if (rc || c->dw.trunk16_w) return rc;
         const size_t wbytes = (size_t)3 * kTrunk16Halves * 2, cbytes = (size_t)3 * kTrunk16Consts * 4;
         std::vector<uint16_t> wimg((size_t)3 * kTrunk16Halves);

@@ -89,7 +89,11 @@ int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, long ctu0
     const long nchunks = (ctu0 + n - 1) / g.nctu * cpf + ((ctu0 + n - 1) % g.nctu) / kSubBatch + 1 -
                          (ctu0 / g.nctu * cpf + (ctu0 % g.nctu) / kSubBatch);
     c->done_armed = 0;
-    int rc = ensure_workspace(c, n, (int)nchunks);
+    // the 16-bit plans' weight images + their accuracy guard: before anything of THIS pass is enqueued (the guard's measured stage runs
+    // two passes of its own through this workspace)
+    int rc = c->fc1_plan ? ensure_fast_weights(c, c->fc1_plan) : 0;
+    if (rc) return rc;
+    rc = ensure_workspace(c, n, (int)nchunks);
     if (rc) return rc;
     const float qn = (float)qp * (1.0f / 51.0f);  // net_CNN.py:106
     // Small passes (a frame or a few: the in-process encoder hook, the LDP-sized calls) stay on one stream: there is no FC1 of
@@ -161,8 +165,7 @@ int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, long ctu0
         HIPCHK(c, hipEventRecord(c->e_tile[p], s_tile));
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->e_tile[p], 0));
     }
-    const int fast = c->fc1_plan;  // FC1 plans 1 / 2: trunk -> 16-bit feature pieces -> FC1 on the 16-bit matrix pipe
-    if (fast && (rc = ensure_fast_weights(c, fast)) != 0) return rc;
+    const int fast = c->fc1_plan;  // plans 2 / 3: trunk -> 16-bit feature pieces -> FC1 on the 16-bit matrix pipe
     { StageTimer t(c, ETHCNN_STAGE_TRUNK);
       if (fold) launch_trunk_direct(d_luma, g, ctu0, w, c->dw, n, c->stream);
       else if (fold3 && fold3_knob == 1) {
@@ -218,6 +221,72 @@ std::vector<Pass> plan_passes(int nctu, int nframes, int max_ctus) {
             for (int o = 0; o < nctu; o += max_ctus) out.push_back({(long)f * nctu + o, std::min(max_ctus, nctu - o)});
     }
     return out;
+}
+
+// ---- the measured stage of the 16-bit plans' accuracy guard (ethcnn_model.cpp::check_fast_plan).  A seeded picture of 2048 x 1280
+// (32 x 20 CTUs) made of 128 x 128 macro tiles of six kinds, so that large and tiny activations both occur (the floors of the split
+// pieces are ABSOLUTE: they show where values are small); both plans through the multi-launch path, gates open (every output compared).
+static void calibration_picture(std::vector<uint8_t>& luma, int w, int h) {
+    luma.resize((size_t)w * h);
+    uint64_t s = 0x9E3779B97F4A7C15ull;
+    auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (uint32_t)(s >> 32); };
+    for (int ty = 0; ty < h / 128; ++ty)
+        for (int tx = 0; tx < w / 128; ++tx) {
+            const int kind = (tx + 5 * ty) % 6, base = 16 + (int)(rnd() % 208), amp = 1 + (int)(rnd() % 6), per = 4 << (rnd() % 4);
+            for (int y = 0; y < 128; ++y)
+                for (int x = 0; x < 128; ++x) {
+                    int v;
+                    switch (kind) {
+                        case 0: v = base; break;                                                         // flat
+                        case 1: v = base + (int)(rnd() % (2 * amp + 1)) - amp; break;                    // low contrast: a few grey levels of noise
+                        case 2: v = (x * 2 + y) % 256; break;                                            // gradient
+                        case 3: v = (int)(rnd() & 255); break;                                           // full-range noise
+                        case 4: v = ((x / per) & 1) ? 235 : 20; break;                                   // edges
+                        default: { const int a = x % (2 * per), b = y % (2 * per);                       // smooth texture (triangle waves)
+                                   v = 128 + (a < per ? a : 2 * per - a) * 96 / per - 48 + (b < per ? b : 2 * per - b) * 32 / per - 16; }
+                    }
+                    luma[(size_t)(ty * 128 + y) * w + tx * 128 + x] = (uint8_t)std::min(255, std::max(0, v));
+                }
+        }
+}
+int calibrate_fast_plan(ethcnn_ctx* c, int plan, double* max_abs) {
+    constexpr int W = 2048, H = 1280, QP = 32;
+    FrameGeom g;
+    int rc = make_geom(c, W, H, W, (ptrdiff_t)W * H, &g);
+    if (rc) return rc;
+    std::vector<uint8_t> luma;
+    calibration_picture(luma, W, H);
+    const size_t pf = (size_t)g.nctu * kNOut;
+    uint8_t* d_luma = nullptr;
+    float* d_p = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d_luma, luma.size()));
+    if (hipMalloc((void**)&d_p, 2 * pf * 4) != hipSuccess) { (void)hipFree(d_luma); return set_err(c, ETHCNN_ERR_NOMEM, "calibration: out of device memory"); }
+    std::vector<float> p(2 * pf);
+    const float t1 = c->thr1, t2 = c->thr2;
+    const int plan0 = c->fc1_plan, small0 = c->small_launch;
+    const bool cap0 = c->debug_capture;
+    c->thr1 = c->thr2 = -1.0f;  // gates open: all 21 outputs of every CTU are compared
+    c->small_launch = 0;        // the plans are forms of the multi-launch path
+    c->debug_capture = false;
+    hipError_t e = hipMemcpyAsync(d_luma, luma.data(), luma.size(), hipMemcpyHostToDevice, c->stream);
+    for (int k = 0; k < 2 && rc == 0 && e == hipSuccess; ++k) {
+        c->fc1_plan = k == 0 ? 0 : plan;
+        rc = run_pass(c, d_luma, g, 0, g.nctu, QP, d_p + k * pf);
+    }
+    c->thr1 = t1; c->thr2 = t2; c->fc1_plan = plan0; c->small_launch = small0; c->debug_capture = cap0;
+    if (rc == 0 && e == hipSuccess) e = hipMemcpyAsync(p.data(), d_p, 2 * pf * 4, hipMemcpyDeviceToHost, c->stream);
+    const hipError_t e2 = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_luma);
+    (void)hipFree(d_p);
+    if (rc) return rc;
+    if (e != hipSuccess || e2 != hipSuccess) return set_err(c, ETHCNN_ERR_DEVICE, "calibration of plan %d failed: %s", plan, hipGetErrorString(e != hipSuccess ? e : e2));
+    double worst = 0.0;
+    for (size_t i = 0; i < pf; ++i) {
+        const double d = std::fabs((double)p[i] - (double)p[pf + i]);
+        if (!(d <= worst)) worst = d;  // (a NaN sticks)
+    }
+    *max_abs = worst;
+    return ETHCNN_OK;
 }
 
 extern "C" int ethcnn_predict_luma_device(ethcnn_ctx* c, const uint8_t* d_luma, int w, int h, ptrdiff_t pitch,

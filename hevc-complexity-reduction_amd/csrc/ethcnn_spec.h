@@ -179,6 +179,24 @@ struct Heads16Scalars { float S1[3], U2[3], S2[3], U3[3]; };  // h1 scale, 1 / (
 // false: a bound is not finite / zero (degenerate weights) -- the caller keeps the exact heads
 bool pack_heads_f16(const float* blob, float feature_bound, uint16_t* img_out /*[kHeads16Halves]*/, Heads16Scalars* sc);
 
+// ---- load-time accuracy guard of the 16-bit plans (ethcnn_weights.cpp).
+// A value carried as two fp16 pieces of its power-of-two scaled form x is exact to 2^-24 |x| -- the class of fp32's own roundings -- as
+// long as the residual piece is a NORMAL fp16 number; below that it is exact only to an ABSOLUTE floor (2^-25 in scaled units; 2^-36
+// for the heads' 2^11-scaled residuals).  The scales come from guaranteed bounds, so the floor bites exactly when a bound is LOOSE
+// (an outlier weight, heavy tails: DESIGN.md section 5 records the case that first showed it).  fast_plan_floor_bound pushes every
+// floor of the plan -- activations at their worst (always at the floor), weights as they are -- through |W| of the layers behind it,
+// all errors aligned, down to the probabilities (sigmoid' <= 1/4): a rigorous upper bound on what the plan's floors can move a
+// probability by, computed from the weights alone.  Plans whose bound exceeds kFastGuardTol are refused at first use.
+struct FastGuard {
+    double prob_err;       // the bound, worst head
+    double feat_err;       // plan 3: floor error of a feature (value units); plan 2: 0 (exact trunk)
+    double h1_err;         // worst FC1 output
+    double feature_bound;  // fast_feature_bound: the guaranteed |feature| bound the activation scale comes from
+    double w1_max;         // max |W1|: the FC1 weight scale
+};
+constexpr double kFastGuardTol = 2.5e-5;  // a quarter of the north star's 1e-4: the rest is left to summation-order noise (measured ~7e-6)
+FastGuard fast_plan_floor_bound(const float* blob, int plan, bool heads16);
+
 // feature-vector map
 constexpr int kOff3[3] = {0, 512, 640};       // conv3 S, M, L
 constexpr int kOff2[3] = {672, 2208, 2592};   // conv2 S, M, L

@@ -388,6 +388,121 @@ static void f16x2r(float x, uint16_t* hi, uint16_t* lo) {  // scaled residual: x
     *hi = f16_rne(x);
     *lo = f16_rne((x - f16_f32(*hi)) * 2048.0f);
 }
+// see ethcnn_spec.h.  floor of a two-piece value x (scaled units): nothing beyond 2^-24 |x| while the residual (<= 2^-12 |x|) is a normal
+// fp16 number (>= 2^-14), else the subnormal spacing's half
+static double floor_plain(double x) { return std::fabs(x) < 0.25 ? std::ldexp(1.0, -25) : 0.0; }
+static double floor_resid(double x) { return std::fabs(x) < std::ldexp(1.0, -13) ? std::ldexp(1.0, -36) : 0.0; }  // residual x 2^11
+FastGuard fast_plan_floor_bound(const float* blob, int plan, bool heads16) {
+    FastGuard g{};
+    const double FLa = std::ldexp(1.0, -25), FLr = std::ldexp(1.0, -36);
+    const double Fb = fast_feature_bound(blob);
+    g.feature_bound = Fb;
+    const double Sa = std::exp2(14.0 - std::ceil(std::log2(Fb)));  // ethcnn_model.cpp::ensure_fast_weights
+    const double da = FLa / Sa;                                     // floor of a stored feature piece pair, value units
+    if (plan == 3) {  // the trunk of plan 3 (pack_trunk_f16): conv1 on exact pixel sums, conv2 / conv3 with split activations and weights
+        for (int br = 0; br < 3; ++br) {
+            const float* W1 = blob + kOffConvW[br][0];
+            const float* W2 = blob + kOffConvW[br][1];
+            const float* W3 = blob + kOffConvW[br][2];
+            const float* B1 = blob + kOffConvB[br][0];
+            const float* B2 = blob + kOffConvB[br][1];
+            double b1[16], b2[24], e1[16], e2[24], m2 = 0, m3 = 0, bound1 = 0;
+            for (int i = 0; i < 64 * 24; ++i) m2 = std::max(m2, (double)std::fabs(W2[i]));
+            for (int i = 0; i < 96 * 32; ++i) m3 = std::max(m3, (double)std::fabs(W3[i]));
+            for (int co = 0; co < 16; ++co) {
+                b1[co] = std::fabs((double)B1[co]);
+                for (int t = 0; t < 16; ++t) b1[co] += std::fabs((double)W1[t * 16 + co]);
+                bound1 = std::max(bound1, b1[co]);
+            }
+            const double S1 = pow2_scale(bound1 * 1.0001), s2w = pow2_scale(m2), s3w = pow2_scale(m3);
+            const int pool = br == 0 ? 1 : (br == 1 ? 2 : 4);
+            const double k1 = (1.0 / 255.0) / (pool * pool) * S1, psum = 255.0 * pool * pool;  // weight pieces of w k1 times pixel sums <= psum
+            for (int co = 0; co < 16; ++co) {
+                double e = 0;
+                for (int t = 0; t < 16; ++t) e += floor_plain((double)W1[t * 16 + co] * k1) * psum;
+                e1[co] = e / S1;
+            }
+            const double d1 = FLa / S1;  // conv1 outputs as conv2's split B operand
+            for (int co = 0; co < 24; ++co) {
+                double e = 0, b = std::fabs((double)B2[co]);
+                for (int q = 0; q < 4; ++q)
+                    for (int ci = 0; ci < 16; ++ci) {
+                        const double w = W2[(q * 16 + ci) * 24 + co];
+                        e += std::fabs(w) * (e1[ci] + d1) + b1[ci] * floor_plain(w * s2w) / s2w;
+                        b += std::fabs(w) * b1[ci];
+                    }
+                e2[co] = e;
+                b2[co] = b;
+                g.feat_err = std::max(g.feat_err, e);
+            }
+            for (int co = 0; co < 32; ++co) {
+                double e = 0;
+                for (int q = 0; q < 4; ++q)
+                    for (int ci = 0; ci < 24; ++ci) {
+                        const double w = W3[(q * 24 + ci) * 32 + co];
+                        e += std::fabs(w) * (e2[ci] + da) + b2[ci] * floor_plain(w * s3w) / s3w;  // conv2 outputs = the stored feature pieces
+                    }
+                g.feat_err = std::max(g.feat_err, e);
+            }
+        }
+    }
+    // FC1 (plans 2 and 3): features as pieces at Sa, W1 as pieces at Sw (one global scale: max |W1| over the three heads)
+    double wmax = 0;
+    for (int h = 0; h < 3; ++h)
+        for (size_t i = 0; i < (size_t)kNFeat * kN1[h]; ++i) wmax = std::max(wmax, (double)std::fabs(blob[kOffFc1W[h] + i]));
+    g.w1_max = wmax;
+    const double Sw = std::exp2(14.0 - std::ceil(std::log2(wmax)));
+    for (int h = 0; h < 3; ++h) {
+        const int n1 = kN1[h], n2 = kN2[h], n3 = kN3[h];
+        const float* W1 = blob + kOffFc1W[h];
+        const float* B1 = blob + kOffFc1B[h];
+        const float* W2 = blob + kOffFc2W[h];
+        const float* B2 = blob + kOffFc2B[h];
+        const float* W3 = blob + kOffFc3W[h];
+        std::vector<double> eh1(n1), bh1(n1), eh2(n2), bh2(n2);
+        double worst1 = 0, worst2 = 0, m2 = 0, m3 = 0;
+        for (int n = 0; n < n1; ++n) {
+            double sabs = 0, fl = 0;
+            for (int k = 0; k < kNFeat; ++k) {
+                const double w = W1[(size_t)k * n1 + n];
+                sabs += std::fabs(w);
+                fl += floor_plain(w * Sw);
+            }
+            eh1[n] = sabs * (g.feat_err + da) + Fb * fl / Sw;
+            bh1[n] = std::fabs((double)B1[n]) + Fb * sabs;
+            worst1 = std::max(worst1, bh1[n]);
+            g.h1_err = std::max(g.h1_err, eh1[n]);
+        }
+        for (int i = 0; i < n1 * n2; ++i) m2 = std::max(m2, (double)std::fabs(W2[i]));
+        for (int i = 0; i < n2 * n3; ++i) m3 = std::max(m3, (double)std::fabs(W3[i]));
+        for (int m = 0; m < n2; ++m) {
+            bh2[m] = std::fabs((double)B2[m]) + std::fabs((double)W2[(size_t)n1 * n2 + m]);
+            for (int n = 0; n < n1; ++n) bh2[m] += std::fabs((double)W2[(size_t)n * n2 + m]) * bh1[n];
+            worst2 = std::max(worst2, bh2[m]);
+        }
+        const bool h16 = plan == 3 && heads16 && worst1 > 0 && worst2 > 0 && m2 > 0 && m3 > 0;
+        const double S1 = h16 ? pow2_scale(worst1 * 1.0001) : 1, S2 = h16 ? pow2_scale(worst2 * 1.0001) : 1, sw2 = h16 ? pow2_scale(m2) : 1, sw3 = h16 ? pow2_scale(m3) : 1;
+        for (int m = 0; m < n2; ++m) {
+            double e = 0;
+            for (int n = 0; n < n1; ++n) {
+                const double w = W2[(size_t)n * n2 + m];
+                e += std::fabs(w) * (eh1[n] + (h16 ? FLr / S1 : 0.0)) + (h16 ? bh1[n] * floor_resid(w * sw2) / sw2 : 0.0);
+            }
+            eh2[m] = e;
+        }
+        for (int o = 0; o < n3; ++o) {
+            double e = 0;
+            for (int m = 0; m < n2; ++m) {
+                const double w = W3[(size_t)m * n3 + o];
+                e += std::fabs(w) * (eh2[m] + (h16 ? FLr / S2 : 0.0)) + (h16 ? bh2[m] * floor_resid(w * sw3) / sw3 : 0.0);
+            }
+            g.prob_err = std::max(g.prob_err, 0.25 * e);
+        }
+    }
+    if (!std::isfinite(g.prob_err)) g.prob_err = INFINITY;
+    return g;
+}
+
 bool pack_heads_f16(const float* blob, float feature_bound, uint16_t* img, Heads16Scalars* sc) {
     for (int h = 0; h < 3; ++h) {
         const int n1 = kN1[h], n2 = kN2[h], n3 = kN3[h], nt = n2 / 16;
@@ -413,12 +528,18 @@ bool pack_heads_f16(const float* blob, float feature_bound, uint16_t* img, Heads
         }
         for (int i = 0; i < n1 * n2; ++i) m2 = std::max(m2, (double)std::fabs(W2[i]));
         for (int i = 0; i < n2 * n3; ++i) m3 = std::max(m3, (double)std::fabs(W3[i]));
-        if (!(worst1 > 0) || !(worst2 > 0) || !(m2 > 0) || !(m3 > 0) || !std::isfinite(worst1) || !std::isfinite(worst2)) return false;
+        if (!(worst1 > 0) || !(worst2 > 0) || !(m2 > 0) || !(m3 > 0) || !std::isfinite(worst1) || !std::isfinite(worst2) || !std::isfinite(m2) ||
+            !std::isfinite(m3))
+            return false;
         const float S1 = pow2_scale(worst1 * 1.0001), S2 = pow2_scale(worst2 * 1.0001), sw2 = pow2_scale(m2), sw3 = pow2_scale(m3);
         sc->S1[h] = S1;
         sc->U2[h] = 1.0f / (S1 * sw2);
         sc->S2[h] = S2;
         sc->U3[h] = 1.0f / (S2 * sw3);
+        //  a bound that is finite as a double but beyond FLT_MAX makes pow2_scale return 0 and its reciprocal inf: every scale
+        // and every product of scales the kernel multiplies by must be a normal float, else the exact heads are kept
+        for (float v : {S1, S2, sw2, sw3, sc->U2[h], sc->U3[h]})
+            if (!std::isnormal(v)) return false;
         uint16_t* f2 = img + heads16_fc2_at(h);
         for (int c = 0; c < n1 / 32; ++c)
             for (int j = 0; j < nt; ++j)

@@ -22,6 +22,20 @@ DBG_FEATURES, DBG_FC1, DBG_FC2, DBG_LOGITS, DBG_RAW_PROBS = range(5)
 _DBG_WIDTH = {DBG_FEATURES: NFEAT, DBG_FC1: NVEC, DBG_FC2: NFC2, DBG_LOGITS: NOUT, DBG_RAW_PROBS: NOUT}
 
 
+ERR_ROWS_TIMEOUT, ERR_PLAN_REFUSED = -7, -8  # include/ethcnn.h
+
+
+def fast_plan_bound(blob, plan, lib=None):
+    """a-priori floor bound of plan 2 / 3 on a probability for a blob in host memory (no device) -> (accepted_by_bound_alone, bound, feature_bound)"""
+    lib = lib or load_library()
+    blob = np.ascontiguousarray(blob, dtype=np.float32)
+    b, f = ctypes.c_double(), ctypes.c_double()
+    rc = lib.ethcnn_fast_plan_bound(blob.ctypes.data, blob.size, int(plan), ctypes.byref(b), ctypes.byref(f))
+    if rc not in (0, ERR_PLAN_REFUSED):
+        raise EthCnnError(rc, "ethcnn_fast_plan_bound: bad arguments")
+    return rc == 0, b.value, f.value
+
+
 class EthCnnError(RuntimeError):
     def __init__(self, code, msg):
         RuntimeError.__init__(self, "libethcnn error %d: %s" % (code, msg))
@@ -66,6 +80,8 @@ SIGNATURES = {
     "ethcnn_set_small_pass_launch": (_i, [_vp, _i]),
     "ethcnn_set_fc1_plan": (_i, [_vp, _i]),
     "ethcnn_get_fc1_plan": (_i, [_vp]),
+    "ethcnn_check_fc1_plan": (_i, [_vp, _i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    "ethcnn_fast_plan_bound": (_i, [_vp, _sz, _i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "ethcnn_measure_mfma_rate": (_i, [_vp, ctypes.c_double, ctypes.POINTER(ctypes.c_double)]),
     "ethcnn_ldp_step": (_i, [_vp, _vp, _i, _i, _pd, _i, _i, _vp, _fp]),
     "ethcnn_ldp_get_state": (_i, [_vp, _fp, _sz]),
@@ -78,6 +94,8 @@ SIGNATURES = {
     "ethcnn_host_free": (_i, [_vp, _vp]),
     "ethcnn_predict_luma": (_i, [_vp, _vp, _i, _i, _pd, _pd, _i, _i, _fp]),
     "ethcnn_predict_yuv_file": (_i, [_vp, _cp, _i, _i, _i, _cp, ctypes.POINTER(ctypes.c_int64)]),
+    "ethcnn_predict_yuv_file_sharded": (_i, [_vp, ctypes.POINTER(ctypes.c_int), _i, _cp, _i, _i, _i, _cp, ctypes.POINTER(ctypes.c_int64)]),
+    "ethcnn_get_startup_times": (_i, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "ethcnn_predict_yuv_shard": (_i, [_vp, _cp, _i, _i, _i, _cp, ctypes.c_int64, ctypes.c_int64]),
     "ethcnn_predict_yuv_range": (_i, [_vp, _cp, _i, _i, _i, _cp, ctypes.c_int64, ctypes.c_int64]),
     "ethcnn_ckpt_read_blob": (_i, [_cp, _fp, _sz, ctypes.c_char_p, _sz]),
@@ -359,6 +377,21 @@ class EthCnn(object):
                                                    os.fsencode(out_path), ctypes.byref(nf)))
         return nf.value
 
+    def predict_yuv_file_sharded(self, devices, yuv_path, width, height, qp, out_path):
+        """the whole file over `devices` (HIP ordinals; devices[0] = this context's) from this process: a worker thread per entry
+        (ethcnn_predict_yuv_file_sharded; ctypes releases the GIL for the call)"""
+        nf = ctypes.c_int64(0)
+        arr = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+        self._chk(self.lib.ethcnn_predict_yuv_file_sharded(self.h, arr, len(devices), os.fsencode(yuv_path), width, height, int(qp),
+                                                           os.fsencode(out_path), ctypes.byref(nf)))
+        return nf.value
+
+    def startup_times(self):
+        """(ms of ethcnn_create's first HIP call = runtime initialisation, ms of the whole ethcnn_create)"""
+        a, b = ctypes.c_double(), ctypes.c_double()
+        self._chk(self.lib.ethcnn_get_startup_times(self.h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
     def predict_yuv_range(self, yuv_path, width, height, qp, out_path, frame_begin, frame_end):
         """frames [frame_begin, frame_end) -> an out_path holding exactly those (get_prob's n_frames_start / n_frames_end)"""
         self._chk(self.lib.ethcnn_predict_yuv_range(self.h, os.fsencode(yuv_path), width, height, int(qp),
@@ -520,6 +553,16 @@ class EthCnn(object):
 
     def fc1_plan(self):
         return int(self.lib.ethcnn_get_fc1_plan(self.h))
+
+    def check_fc1_plan(self, plan):
+        """the load-time accuracy guard of plans 2 / 3 for the loaded weights (ethcnn_check_fc1_plan) ->
+        {"accepted", "apriori_bound", "measured" (None: the a-priori bound sufficed), "message"}; never raises for a refusal"""
+        b, m = ctypes.c_double(0.0), ctypes.c_double(-1.0)
+        rc = self.lib.ethcnn_check_fc1_plan(self.h, int(plan), ctypes.byref(b), ctypes.byref(m))
+        if rc not in (0, ERR_PLAN_REFUSED):
+            self._chk(rc)
+        return {"accepted": rc == 0, "apriori_bound": b.value, "measured": None if m.value < 0 else m.value,
+                "message": "" if rc == 0 else self.lib.ethcnn_last_error(self.h).decode()}
 
     def set_small_pass_launch(self, on=True):
         """one picture (<= 2304 CTUs, 16-byte aligned rows) as ONE launch (default on); off = five launches.  Same results."""

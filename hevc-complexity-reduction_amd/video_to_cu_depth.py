@@ -62,6 +62,18 @@ def restore_model(ctx, qp_seq, model_dir='.'):
     return 'synthetic(seed=%s)' % seed
 
 
+def guard_fast_plan(ctx):
+    """ETHCNN_FC1_PLAN=2|3 is an opt-in; the encoder asserts a zero exit status (TAppEncCfg.cpp:2321).  The library REFUSES a plan
+    whose load-time accuracy guard fails for the restored checkpoint (include/ethcnn.h, ethcnn_check_fc1_plan); the launcher then says
+    so on stderr and runs the exact plan -- always correct, only slower -- instead of failing the encode."""
+    plan = ctx.fc1_plan()
+    if plan:
+        g = ctx.check_fc1_plan(plan)
+        if not g['accepted']:
+            sys.stderr.write('video_to_cu_depth: %s\nvideo_to_cu_depth: continuing with the exact plan (0)\n' % g['message'])
+            ctx.set_fc1_plan(0)
+
+
 def _shard_worker(device, yuv_file, width, height, qp_seq, out_path, f0, f1, thr, nworkers=1):
     """One process per GPU: own context, own frame range, pwrite into out_path.
     The node's host-CPU budget is shared: every worker starts budget / nworkers staging-fill threads
@@ -70,13 +82,24 @@ def _shard_worker(device, yuv_file, width, height, qp_seq, out_path, f0, f1, thr
     ctx = _e.EthCnn(device=device)
     ctx.set_thresholds(*thr)
     restore_model(ctx, qp_seq)
+    guard_fast_plan(ctx)
     ctx.predict_yuv_shard(yuv_file, width, height, qp_seq, out_path, f0, f1)
     ctx.close()
 
 
 def predict_sharded(yuv_file, width, height, qp_seq, save_file, devices):
-    """Frame-range sharding over `devices` (list of HIP ordinals, one worker process each).
-    No collective: ranges are disjoint and the output offsets deterministic."""
+    """Frame-range sharding over `devices` (list of HIP ordinals).  No collective: ranges are disjoint and the output offsets
+    deterministic.  Default: ONE process, a worker thread per device inside the library (ethcnn_predict_yuv_file_sharded: one
+    interpreter, one checkpoint parse, peers cloned from the first context -- the encoder blocks on this command, TAppEncCfg.cpp:2317-2321).
+    ETHCNN_SHARD_PROCESSES=1: a worker PROCESS per device (the form the torchrun bench uses), each with its own context."""
+    if os.environ.get('ETHCNN_SHARD_PROCESSES', '0') in ('', '0'):
+        ctx = _e.EthCnn(device=devices[0])
+        ctx.load_thresholds(THR_FILE)
+        restore_model(ctx, qp_seq)
+        guard_fast_plan(ctx)
+        n = ctx.predict_yuv_file_sharded(devices, yuv_file, width, height, qp_seq, save_file)
+        ctx.close()
+        return n
     import multiprocessing as mp
     from . import sharding
     n_frames = get_file_size(yuv_file) // (width * height * 3 // 2)
@@ -118,6 +141,7 @@ def main(argv=None):
         ctx = _e.EthCnn(device=devices[0])
         ctx.load_thresholds(THR_FILE)          # net_CNN.py:47 (cwd-relative; at import time there)
         restore_model(ctx, qp_seq)
+        guard_fast_plan(ctx)
         t1 = time.time()                       # the reference times get_prob only (:142-145)
         n_frames = get_prob(ctx, yuv_file, IMAGE_SIZE, SAVE_FILE, qp_seq, 0,
                             get_file_size(yuv_file) // frame_bytes, width, height)

@@ -38,7 +38,12 @@ enum {
     ETHCNN_ERR_FORMAT = -3,    /* malformed checkpoint / Thr_info.txt / YUV size */
     ETHCNN_ERR_DEVICE = -4,    /* no usable gfx950 device or a HIP call failed */
     ETHCNN_ERR_NOWEIGHTS = -5, /* predict called before any ethcnn_load_* */
-    ETHCNN_ERR_NOMEM = -6
+    ETHCNN_ERR_NOMEM = -6,
+    ETHCNN_ERR_PLAN_REFUSED = -8, /* an opted-in 16-bit plan (ethcnn_set_fc1_plan 2 / 3) failed its load-time accuracy guard for the loaded
+                                     weights; nothing was computed.  Plan 0 (and usually plan 2 when 3 was refused) still works. */
+    ETHCNN_ERR_ROWS_TIMEOUT = -7 /* streamed input only (ethcnn_predict_luma_end / ethcnn_ldp_step_end): the kernels waited ~1 s for a CTU row
+                                    that ethcnn_rows_ready never reported and gave up.  Nothing is wrong with the device: the same picture can
+                                    be run again the plain way once its buffer is complete.  Every OTHER error of those calls is final. */
 };
 
 /* Geometry constants of the path (net_CNN.py:8-36). */
@@ -107,7 +112,7 @@ int ethcnn_predict_luma(ethcnn_ctx* ctx, const uint8_t* luma, int width, int hei
  *                               the previous streamed call on this context has ended (a begin that FAILS consumes the picture: rows
  *                               reported for it are forgotten, and no further row of it may be reported).  Every CTU row
  *                               [0, ceil(height / 64)) must be reported: kernels that wait ~1 s for a row give up and the end call
- *                               fails with ETHCNN_ERR_DEVICE (the GPU is not left hanging).  Shared with ethcnn_ldp_step_begin below.
+ *                               fails with ETHCNN_ERR_ROWS_TIMEOUT (the GPU is not left hanging).  Shared with ethcnn_ldp_step_begin below.
  *   ethcnn_predict_luma_end     waits; probs (the pointer given to begin) are final when it returns ETHCNN_OK.
  * Results are bit-identical to ethcnn_predict_luma's. */
 int ethcnn_predict_luma_begin(ethcnn_ctx* ctx, const uint8_t* luma, int width, int height, int qp, float* probs);
@@ -123,6 +128,16 @@ int ethcnn_predict_yuv_file(ethcnn_ctx* ctx, const char* yuv_path, int width, in
  * which must already exist with its final size (frames * nctu * 84 bytes). */
 int ethcnn_predict_yuv_shard(ethcnn_ctx* ctx, const char* yuv_path, int width, int height, int qp,
                              const char* out_path, int64_t frame_begin, int64_t frame_end);
+
+/* The whole file over several GPUs from ONE process, a worker thread per listed device (thread-per-GPU form of the same split: the
+ * reference's caller blocks in system(), TAppEncCfg.cpp:2317-2321, so what counts is the command's wall time -- N interpreters, N
+ * checkpoint parses and N cold contexts cost more than 1/N of a short job saves).  `ctx` is worker 0 and must live on devices[0]; a
+ * device may be listed more than once (several workers sharing one GPU: tests, and profiles/r06_cold_start.txt).  Workers 1.. are
+ * contexts the library creates once and keeps with `ctx` (a copy of its weights, thresholds, plan; host threads: the node budget divided
+ * by the worker count).  Frames [total k / n, total (k + 1) / n) to worker k, each pwriting at its offset into a temp file; one
+ * rename.  Output byte-identical to ethcnn_predict_yuv_file.  ndevices == 1 is that call. */
+int ethcnn_predict_yuv_file_sharded(ethcnn_ctx* ctx, const int* devices, int ndevices, const char* yuv_path, int width, int height, int qp,
+                                    const char* out_path, int64_t* nframes_out);
 
 /* get_prob(yuv_name, ..., n_frames_start, n_frames_end, ...) (video_to_cu_depth.py:75-118): frames [frame_begin, frame_end) of the
  * file (the reference reads and discards the first n_frames_start frames, :86-87) -> an `out_path` that holds exactly those
@@ -180,8 +195,9 @@ int ethcnn_ldp_get_state(ethcnn_ctx* ctx, float* state_out, size_t nfloats /* nc
  *                           thread, any order, each CTU row once; may be called BEFORE ethcnn_ldp_step_begin of the same frame, but
  *                           not before the previous streamed step has ended.  Every CTU row [0, ceil(height / 64)) must be
  *                           reported: kernels that wait ~1 s for a row give up, and ethcnn_ldp_step_end then fails with
- *                           ETHCNN_ERR_DEVICE (the GPU is not left hanging; the state that was resident BEFORE the step stays resident,
- *                           so the frame can be run again with ethcnn_ldp_step once its buffer is complete).
+ *                           ETHCNN_ERR_ROWS_TIMEOUT (the GPU is not left hanging; the step's INPUT state stays resident -- the state the
+ *                           previous step left, or the copy of state_in --, so the frame can be run again with ethcnn_ldp_step and the
+ *                           same arguments once its buffer is complete).
  *   ethcnn_ldp_step_end     waits; probs (the pointer given to begin) and the resident state are final when it returns ETHCNN_OK.
  * Results are bit-identical to ethcnn_ldp_step's. */
 int ethcnn_ldp_step_begin(ethcnn_ctx* ctx, const uint8_t* luma, int width, int height, ptrdiff_t pitch, int qp, int i_frame,
@@ -214,6 +230,9 @@ int ethcnn_memcpy_d2h(ethcnn_ctx* ctx, void* dst, const void* src, size_t bytes)
  * is hipStreamSynchronize.  Env ETHCNN_DONE_WORD=0: always the latter. */
 int ethcnn_synchronize(ethcnn_ctx* ctx);
 int ethcnn_device_name(const ethcnn_ctx* ctx, char* out, size_t cap);
+/* Cold start (no reference counterpart; the reference quotes "1~10 s" of TensorFlow initialisation, README.md:124): how long
+ * ethcnn_create took, and how much of it was its first HIP call (loading and initialising the runtime).  Milliseconds. */
+int ethcnn_get_startup_times(const ethcnn_ctx* ctx, double* runtime_init_ms, double* create_ms);
 
 /* ---- measurement: per-stage kernel time from HIP events recorded on the ctx stream
  *      (replaces the reference's only instrument, the 'Predicting Time' wall clock,
@@ -265,6 +284,24 @@ int ethcnn_reset_stage_times(ethcnn_ctx* ctx);
  * multi-frame host entries and the streamed entries of pictures above 2304 CTUs (tests/test_gpu_fast_plan.py).  Env ETHCNN_FC1_PLAN=2|3 starts contexts in that plan.  Takes effect with the next pass enqueued. */
 int ethcnn_set_fc1_plan(ethcnn_ctx* ctx, int plan);
 int ethcnn_get_fc1_plan(const ethcnn_ctx* ctx);
+/* Load-time accuracy guard of plans 2 / 3.  The pieces of a split value are exact to 2^-24 relative only while the value stays within
+ * about 2^12 of the GUARANTEED bound its scale was derived from; below that an absolute floor takes over.  Seeded and well-conditioned
+ * trained weights are far inside; a checkpoint with a few outlier weights (a bound 10^3..10^9 above typical values) is not.  At the
+ * first pass under a plan (and here, on request) the library pushes every such floor of the plan through the |weights| of the layers
+ * behind it -- all errors aligned, activations always at their floor -- down to the probabilities: a rigorous upper bound, computed from
+ * the weights alone (video_to_cu_depth.py:126-133: any of the four checkpoints a run may restore must be safe).  At or below 2.5e-5 (a
+ * quarter of the 1e-4 contract) the plan is accepted on the bound alone.  Above it the worst case decides nothing (it is pessimistic by
+ * the looseness of the very bounds it guards), so the plan is MEASURED once: a seeded calibration picture (640 CTUs: flat, low-contrast,
+ * gradient, noise, edge and texture tiles) through the exact plan and through the plan, gates open; max |dp| <= 2.5e-5 accepts, anything
+ * else REFUSES: the pass returns ETHCNN_ERR_PLAN_REFUSED with the numbers in ethcnn_last_error, nothing is computed, the context stays
+ * usable (ethcnn_set_fc1_plan(ctx, 0 or 2)).  Never a silent loss of accuracy, never a silent fallback.  ~3 ms, once per weight load.
+ *   ethcnn_check_fc1_plan   ETHCNN_OK / ETHCNN_ERR_PLAN_REFUSED for the loaded weights; *apriori_bound, *measured (may be NULL; measured
+ *                           < 0: the bound sufficed and nothing was run).
+ * The launchers (video_to_cu_depth.py, tools/video_to_cu_depth.c) call it when ETHCNN_FC1_PLAN is set and continue with plan 0 after
+ * printing the refusal. */
+int ethcnn_check_fc1_plan(ethcnn_ctx* ctx, int plan, double* apriori_bound /* may be NULL */, double* measured /* may be NULL */);
+/* the a-priori bound for a blob in host memory: no context, no device (pure host arithmetic).  ETHCNN_OK: the bound alone accepts */
+int ethcnn_fast_plan_bound(const float* blob, size_t nfloats, int plan, double* prob_err_bound, double* feature_bound /* may be NULL */);
 /* Single-launch small pass (default on): a pass of <= 2304 CTUs (up to one 3840x2160 picture) whose rows are 16-byte aligned (width, pitch, frame stride and
  * base pointer multiples of 16) -- one picture from the in-process encoder hook, every Low-Delay-P frame, the reference's own
  * 768x512 case -- runs CTU load + trunk -> FC1 -> heads -> gates as ONE kernel launch (a dataflow inside one grid, per-group /

@@ -300,3 +300,90 @@ def test_streamed_input_under_the_fast_plans(pkg, oracle, plan):
             assert np.abs(plain - want.reshape(-1, 21)).max() <= TOL
     finally:
         c.close()
+
+
+def _guard_cases(oracle):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import adversarial_blobs as ab
+    return [("seeded gain 1", oracle.synth_blob(21, 1.0), True),
+            ("seeded gain 8", oracle.synth_blob(21, 8.0), True),
+            ("one 1e3 outlier per tensor", ab.outlier_per_tensor(oracle, 21, 2.0, 1e3), None),
+            ("one 1e3 outlier per conv tensor", ab.outlier_in(oracle, 21, 8.0, 1e3, ("Variable",)), None),
+            ("one 1e3 outlier per FC tensor", ab.outlier_in(oracle, 21, 2.0, 1e3, ("h_fc", "y_conv")), None),
+            ("Student-t (df 2) weights", ab.heavy_tailed(oracle, 21, 4.0), None),
+            ("one 1e7 outlier per conv tensor", ab.outlier_in(oracle, 21, 8.0, 1e7, ("Variable",)), False)]
+
+
+@pytest.mark.parametrize("plan", [2, 3])
+def test_load_time_accuracy_guard_with_adversarial_weights(pkg, oracle, plan):
+    """VERDICT r05 item 3.  Every other test of the plans uses the seeded weight generator; a trained checkpoint with a few outlier
+    weights or heavy tails makes the guaranteed activation bounds -- and with them the fp16 scales -- loose, and the plans' pieces
+    then sit on their absolute floors.  For each weight set, under each plan: either the load-time guard ACCEPTS the plan (a-priori
+    bound <= 2.5e-5, or measured on the calibration picture <= 2.5e-5) and a test picture the guard never saw is within the north
+    star's 1e-4 of the oracle with identical zero patterns -- or the guard REFUSES it: the pass returns ETHCNN_ERR_PLAN_REFUSED (-8) with
+    the numbers in the message, nothing is written, and the context still computes the exact plan bit for bit.  Seeded weights must be
+    accepted, the 1e7 conv outliers (a feature bound 2^70 above typical values) refused: the guard is neither vacuous nor trigger-happy."""
+    e = pkg.ethcnn
+    rng = np.random.default_rng(4242)
+    w, h, frames, qp = 1280, 768, 2, 27           # 240 CTUs per frame
+    luma = np.stack([_mixed_ctus(rng, 240).reshape(12, 20, 64, 64).transpose(0, 2, 1, 3).reshape(h, w) for _ in range(frames)])
+    seen = {}
+    for name, blob, expect in _guard_cases(oracle):
+        c = pkg.EthCnn(device=0)
+        try:
+            c.load_blob(blob)
+            c.set_small_pass_launch(False)
+            c.set_thresholds(0.5, 0.5)
+            g = c.check_fc1_plan(plan)
+            seen[name] = g
+            if expect is not None:
+                assert g["accepted"] == expect, (name, g)
+            by_bound, bound, _ = e.fast_plan_bound(blob, plan)
+            assert abs(bound - g["apriori_bound"]) <= 1e-12 * max(1.0, bound) and (g["measured"] is None) == by_bound, (name, g, bound)
+            want = oracle.predict_frames(blob, luma, w, h, frames, qp, 0.5, 0.5, mode=0)
+            c.set_fc1_plan(plan)
+            if g["accepted"]:
+                assert g["measured"] is None or g["measured"] <= 2.5e-5, (name, g)
+                got = c.predict_luma(luma, w, h, frames, qp)
+                assert np.array_equal(got == 0.0, want == 0.0), name
+                assert np.abs(got - want).max() <= TOL, (name, float(np.abs(got - want).max()), g)
+            else:
+                assert g["measured"] is not None and not (g["measured"] <= 2.5e-5) and "refused" in g["message"], (name, g)
+                with pytest.raises(e.EthCnnError, match="refused") as ei:
+                    c.predict_luma(luma, w, h, frames, qp)
+                assert ei.value.code == e.ERR_PLAN_REFUSED
+                c.set_fc1_plan(0)
+                assert np.array_equal(_bits(c.predict_luma(luma, w, h, frames, qp)), _bits(want)), name   # the context still works, exactly
+                c.load_blob(oracle.synth_blob(21, 1.0))                                                    # ... and a new weight load is judged anew
+                assert c.check_fc1_plan(plan)["accepted"]
+        finally:
+            c.close()
+    print("plan", plan, {k: (v["accepted"], "%.3g" % v["apriori_bound"], v["measured"]) for k, v in seen.items()})
+
+
+def test_launchers_fall_back_to_the_exact_plan_when_the_guard_refuses(pkg, oracle, tmp_path):
+    """ETHCNN_FC1_PLAN=3 with a checkpoint the guard refuses: both launchers (Python host mirror, C tool) print the refusal and write the
+    EXACT plan's cu_depth.dat (the encoder asserts a zero exit status, TAppEncCfg.cpp:2321) -- bit-identical to the oracle."""
+    import subprocess
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import adversarial_blobs as ab
+    from tfckpt_writer import write_bundle
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    blob = ab.outlier_in(oracle, 21, 8.0, 1e7, ("Variable",))
+    w, h, frames, qp = 832, 480, 30, 32            # 3120 CTUs: the file entry's multi-launch path
+    rng = np.random.default_rng(5)
+    yuv = rng.integers(0, 256, size=(frames, w * h * 3 // 2), dtype=np.uint8)
+    yuv.tofile(str(tmp_path / "seq.yuv"))
+    (tmp_path / "Thr_info.txt").write_text("0.5 0.5 0.5 0.5 0.5 0.5\n")
+    write_bundle(str(tmp_path / "model_2000000_qp30~35.dat"), [(n, np.array(v)) for n, v in oracle.tensor_views(blob).items()],
+                 data_crc=pkg.ethcnn.crc32c_masked)
+    want = oracle.predict_frames(blob, yuv, w, h, frames, qp, 0.5, 0.5, frame_stride=w * h * 3 // 2)
+    env = dict(os.environ, ETHCNN_FC1_PLAN="3")
+    for cmd in ([sys.executable, os.path.join(root, "video_to_cu_depth.py")], [os.path.join(root, "hevc-complexity-reduction_amd", "bin", "video_to_cu_depth")]):
+        out = tmp_path / "cu_depth.dat"
+        if out.exists():
+            out.unlink()
+        r = subprocess.run(cmd + ["seq.yuv", str(w), str(h), str(qp)], cwd=str(tmp_path), capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0 and "refused" in r.stderr and "exact plan" in r.stderr, (cmd, r.stderr[-800:])
+        got = np.fromfile(str(out), dtype="<f4").reshape(-1, 21)
+        assert np.array_equal(_bits(got), _bits(want)), cmd

@@ -247,6 +247,14 @@ def test_ldp_step_keeps_the_state_resident(pkg, oracle, lstm):
         b.close()
 
 
+def a_has_state(c, w, h):
+    try:
+        c.ldp_get_state(w, h)
+        return True
+    except Exception:
+        return False
+
+
 def test_ldp_step_streamed_input(pkg, oracle, lstm):
     """ethcnn_ldp_step_begin / ethcnn_rows_ready / ethcnn_ldp_step_end: the frame's kernels are queued on a page-locked buffer that
     a filling thread is still writing, CTU row by CTU row in a scrambled order, some rows reported before begin was even called --
@@ -356,6 +364,43 @@ def test_ldp_step_streamed_input(pkg, oracle, lstm):
         want3 = b.ldp_step(luma3, w, h, 27, 3)
         assert np.array_equal(_bits(a.ldp_step(luma3, w, h, 27, 3)), _bits(want3))
         assert np.array_equal(_bits(a.ldp_get_state(w, h)), _bits(b.ldp_get_state(w, h)))
+        # a streamed step that was given an explicit state_in at ANOTHER geometry gives up.  The error is the distinct
+        # "rows never came" code (-7; everything else is final), what stays resident is the copy of state_in FOR ITS OWN CTU COUNT: a
+        # resident step at the old geometry is refused (it used to pass the size check and read a state of the wrong size), the
+        # frame itself can be run again with the same arguments
+        w2, h2 = 832, 480
+        n2 = e.ctus_per_frame(w2, h2)
+        pin2 = a.host_buffer(w2 * h2)
+        pp2 = a.host_buffer(n2 * 21 * 4).view(np.float32)
+        st_in = (rng.standard_normal((n2, 2, 448)) * 0.1).astype(np.float32)
+        luma4 = rng.integers(0, 256, size=(h2, w2), dtype=np.uint8)
+        pin2[:] = luma4.reshape(-1)
+        a.ldp_step_begin(pin2, w2, h2, 27, 2, pp2, state_in=st_in)
+        a.rows_ready(0, (h2 + 63) // 64 - 1)
+        with pytest.raises(e.EthCnnError, match="never reported") as ei:
+            a.ldp_step_end()
+        assert ei.value.code == -7
+        with pytest.raises(e.EthCnnError, match="none is resident"):
+            a.ldp_step(luma3, w, h, 27, 4)                                     # geometry A: its state is gone, and the library says so
+        assert np.array_equal(_bits(a.ldp_get_state(w2, h2)), _bits(st_in))    # resident: the caller's state, for geometry B
+        want4 = b.ldp_step(luma4, w2, h2, 27, 2, state_in=st_in)
+        assert np.array_equal(_bits(a.ldp_step(luma4, w2, h2, 27, 2)), _bits(want4))   # resident step at geometry B = the same frame again
+        assert np.array_equal(_bits(a.ldp_get_state(w2, h2)), _bits(b.ldp_get_state(w2, h2)))
+        # zeros as the input (i_frame <= 1) while a state of another geometry is resident: the failed step wrote ONE of the two state
+        # buffers -- both parities: the resident state is either still there bit for bit, or declared gone; never a state of the wrong size
+        kept = 0
+        for i_frame in (3, 4):
+            a.ldp_step(luma4, w2, h2, 27, i_frame, state_in=None if a_has_state(a, w2, h2) else st_in)
+            keep = a.ldp_get_state(w2, h2)
+            a.ldp_step_begin(pin, w, h, 27, 1, pprobs)
+            with pytest.raises(e.EthCnnError, match="never reported"):
+                a.ldp_step_end()
+            try:
+                assert np.array_equal(_bits(a.ldp_get_state(w2, h2)), _bits(keep))
+                kept += 1
+            except e.EthCnnError:
+                pass
+        assert kept == 1                                                       # (one parity keeps it, the other had to drop it)
     finally:
         a.close()
         b.close()

@@ -480,7 +480,7 @@ int main(int argc, char** argv) {
         if (sidecar(tagbuf) != 0 || prepare_cu_depth(nctu * 21 * sizeof(float)) != 0) { fprintf(stderr, "resi_to_cu_depth_ldp: cannot write state.dat.idx / cu_depth.dat: %s\n", strerror(errno)); if (step_rc == ETHCNN_OK && !no_stream) (void)ethcnn_ldp_step_end(ctx); goto out; }
         if (step_rc == ETHCNN_OK) step_rc = no_stream ? ethcnn_ldp_step(ctx, luma, w, h, w, qp_seq, i_frame, state_in, probs) : ethcnn_ldp_step_end(ctx);
         if (read_rc != 0) { fprintf(stderr, "resi_to_cu_depth_ldp: resi.yuv: short read (%zu luma bytes wanted)\n", npx); goto out; }
-        if (step_rc != ETHCNN_OK && !no_stream) {
+        if (step_rc == ETHCNN_ERR_ROWS_TIMEOUT && !no_stream) { /* (only this one: any other error of begin / end is final -- ADVICE r05) */
             /* streamed frame: a row came more than ~1 s late (a cold or remote resi.yuv) and the kernels gave up.  The buffer is complete by
              * now and the library kept the previous frame's state resident: answer the frame the plain way instead of leaving HM spinning
              * on pred_end.sig */
