@@ -134,19 +134,36 @@ def main(argv=None):
     assert frame_bytes > 0 and get_file_size(yuv_file) % frame_bytes == 0   # :137
     # ETHCNN_DEVICES="0,1,2,3" shards frames over several GPUs; default: one GPU (ETHCNN_DEVICE)
     devices = [int(d) for d in os.environ.get('ETHCNN_DEVICES', os.environ.get('ETHCNN_DEVICE', '0')).split(',')]
+    timing = os.environ.get('ETHCNN_TIMING', '0') not in ('', '0')
+    stamps = [('imports done', time.perf_counter())]
     t1 = time.time()
     if len(devices) > 1:
         n_frames = predict_sharded(yuv_file, width, height, qp_seq, SAVE_FILE, devices)
+        stamps.append(('create + weights + predict (%d workers)' % len(devices), time.perf_counter()))
     else:
         ctx = _e.EthCnn(device=devices[0])
+        stamps.append(('create (HIP runtime init %.1f, whole call %.1f)' % ctx.startup_times(), time.perf_counter()))
         ctx.load_thresholds(THR_FILE)          # net_CNN.py:47 (cwd-relative; at import time there)
         restore_model(ctx, qp_seq)
         guard_fast_plan(ctx)
+        stamps.append(('thresholds + weights + plan guard', time.perf_counter()))
         t1 = time.time()                       # the reference times get_prob only (:142-145)
         n_frames = get_prob(ctx, yuv_file, IMAGE_SIZE, SAVE_FILE, qp_seq, 0,
                             get_file_size(yuv_file) // frame_bytes, width, height)
+        stamps.append(('predict', time.perf_counter()))
         ctx.close()
+        stamps.append(('destroy', time.perf_counter()))
     t2 = time.time()
+    if timing:  # (perf_counter is CLOCK_MONOTONIC: comparable with the spawning process's stamp, ETHCNN_T0_MS)
+        t0 = float(os.environ.get('ETHCNN_T0_MS', '0')) * 1e-3
+        up = float(os.environ.get('ETHCNN_T_UP_MS', '0')) * 1e-3
+        prev, parts = (up or stamps[0][1]), []
+        if t0 and up:
+            parts.append('spawn -> interpreter up %.1f' % ((up - t0) * 1e3))
+        for name, t in stamps:
+            parts.append('%s %.1f' % (name, (t - prev) * 1e3))
+            prev = t
+        sys.stderr.write('video_to_cu_depth.py timing (ms): ' + ' | '.join(parts) + '\n')
     print('%s  frame %d/%d  %dx%d' % (yuv_file, n_frames, n_frames, width, height))
     print('--------\n\nPredicting Time: %.3f sec.\n\n--------' % float(t2 - t1))  # :145
     return 0

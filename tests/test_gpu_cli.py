@@ -61,9 +61,12 @@ def test_cli_failures_exit_nonzero(tmp_path):
 
 
 @pytest.mark.parametrize("devices", ["0,0", "0,0,0,0,0,0,0,0"])
-def test_sharded_cli_is_byte_identical(oracle, tmp_path, devices):
-    """Frame-range sharding (no collective).  One MI355X is visible here, so the G workers all
-    use device 0: what is checked is that ranges + offsets reproduce the 1-worker file."""
+@pytest.mark.parametrize("form", ["threads", "processes", "native"])
+def test_sharded_cli_is_byte_identical(oracle, tmp_path, devices, form):
+    """Frame-range sharding (no collective).  One MI355X is visible here, so the G workers all use device 0: what is checked is that
+    ranges + offsets reproduce the 1-worker file -- through the Python launcher's default (ONE process, a worker thread per device
+    inside the library: ethcnn_predict_yuv_file_sharded), through its process-per-GPU form (ETHCNN_SHARD_PROCESSES=1) and through the
+    native C tool (the same library entry, no interpreter at all)."""
     w, h, frames, qp = 832, 480, 11, 37   # 13 x 8 = 104 CTUs per frame, ragged bottom edge
     yuv = _yuv(str(tmp_path / "seq.yuv"), w, h, frames, 3)
     (tmp_path / "Thr_info.txt").write_text("0.5 0.5 0.5 0.5 0.5 0.5\n")
@@ -71,11 +74,51 @@ def test_sharded_cli_is_byte_identical(oracle, tmp_path, devices):
     assert r.returncode == 0, r.stderr
     single = (tmp_path / "cu_depth.dat").read_bytes()
     os.remove(str(tmp_path / "cu_depth.dat"))
-    r = _run(tmp_path, ["seq.yuv", w, h, qp], ETHCNN_SYNTHETIC_SEED=9, ETHCNN_HEAD_GAIN=8, ETHCNN_DEVICES=devices)
-    assert r.returncode == 0, r.stderr
+    if form == "native":
+        tool = os.path.join(ROOT, "hevc-complexity-reduction_amd", "bin", "video_to_cu_depth")
+        r = subprocess.run([tool, "seq.yuv", str(w), str(h), str(qp)], cwd=str(tmp_path), capture_output=True, text=True,
+                           env=dict(os.environ, ETHCNN_SYNTHETIC_SEED="9", ETHCNN_HEAD_GAIN="8", ETHCNN_DEVICES=devices, ETHCNN_TIMING="1"))
+        assert r.returncode == 0 and "predict (%d workers)" % len(devices.split(",")) in r.stderr, r.stderr
+    else:
+        r = _run(tmp_path, ["seq.yuv", w, h, qp], ETHCNN_SYNTHETIC_SEED=9, ETHCNN_HEAD_GAIN=8, ETHCNN_DEVICES=devices,
+                 ETHCNN_SHARD_PROCESSES="1" if form == "processes" else "0")
+        assert r.returncode == 0, r.stderr
     assert (tmp_path / "cu_depth.dat").read_bytes() == single
+    assert not [f for f in os.listdir(str(tmp_path)) if ".tmp." in f]      # no temp file left behind
     want = oracle.predict_frames(oracle.synth_blob(9, 8.0), yuv, w, h, frames, qp, 0.5, 0.5, frame_stride=w * h * 3 // 2)
     assert np.array_equal(np.frombuffer(single, dtype="<f4").view(np.uint32), want.reshape(-1).view(np.uint32))
+
+
+def test_sharded_entry_reuses_its_workers_and_follows_the_context(pkg, oracle, tmp_path):
+    """ethcnn_predict_yuv_file_sharded through the binding: the peers are created once and FOLLOW the calling context -- new weights,
+    new thresholds, another plan, another worker count, fewer frames than workers -- byte-identical to the unsharded entry each time;
+    a device list that does not start with the context's device is an argument error, and so is a device that does not exist."""
+    e = pkg.ethcnn
+    w, h, frames, qp = 416, 240, 9, 32
+    yuv = _yuv(str(tmp_path / "seq.yuv"), w, h, frames, 7)
+    c = pkg.EthCnn(device=0)
+    try:
+        for k, (seed, gain, thr, plan, devs) in enumerate(((3, 8.0, (0.5, 0.5), 0, [0, 0, 0]), (4, 2.0, (0.45, 0.6), 0, [0, 0, 0]),
+                                                           (4, 2.0, (0.45, 0.6), 0, [0] * 5), (4, 2.0, (0.5, 0.5), 0, [0] * 16), (5, 1.0, (0.5, 0.5), 3, [0, 0]))):
+            c.load_blob(oracle.synth_blob(seed, gain))
+            c.set_thresholds(*thr)
+            c.set_fc1_plan(plan)
+            c.predict_yuv_file(str(tmp_path / "seq.yuv"), w, h, qp, str(tmp_path / "one.dat"))
+            n = c.predict_yuv_file_sharded(devs, str(tmp_path / "seq.yuv"), w, h, qp, str(tmp_path / "many.dat"))
+            assert n == frames and (tmp_path / "many.dat").read_bytes() == (tmp_path / "one.dat").read_bytes(), k
+            if plan == 0:
+                want = oracle.predict_frames(oracle.synth_blob(seed, gain), yuv, w, h, frames, qp, thr[0], thr[1], frame_stride=w * h * 3 // 2)
+                assert np.array_equal(np.fromfile(str(tmp_path / "many.dat"), dtype="<f4").view(np.uint32), want.reshape(-1).view(np.uint32)), k
+        c.set_fc1_plan(0)
+        with pytest.raises(e.EthCnnError):
+            c.predict_yuv_file_sharded([1, 0], str(tmp_path / "seq.yuv"), w, h, qp, str(tmp_path / "x.dat"))
+        with pytest.raises(e.EthCnnError):
+            c.predict_yuv_file_sharded([0, 99], str(tmp_path / "seq.yuv"), w, h, qp, str(tmp_path / "x.dat"))
+        assert not (tmp_path / "x.dat").exists() and not [f for f in os.listdir(str(tmp_path)) if ".tmp." in f]
+        a, b = c.startup_times()
+        assert 0.0 <= a <= b < 60000.0
+    finally:
+        c.close()
 
 
 def test_native_c_cli_matches(pkg, oracle, tmp_path):

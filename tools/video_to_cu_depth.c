@@ -110,6 +110,7 @@ int main(int argc, char** argv) {
     printf("%lld frames predicted -> cu_depth.dat\n", (long long)nframes);
     if (timing && atoi(timing) != 0) {
         (void)ethcnn_get_startup_times(ctx, &runtime_ms, &create_ms);
+        if (getenv("ETHCNN_T0_MS")) fprintf(stderr, "video_to_cu_depth timing: spawn -> main %.1f ms\n", t0 - atof(getenv("ETHCNN_T0_MS")));
         fprintf(stderr, "video_to_cu_depth timing (ms since main): create %.1f (HIP runtime init %.1f, context %.1f) | thresholds + weights %.1f | plan guard %.1f | "
                         "predict (%d worker%s) %.1f | total in main %.1f\n",
                 t_create - t0, runtime_ms, create_ms - runtime_ms, t_weights - t_create, t_guard - t_weights, ndev, ndev == 1 ? "" : "s",

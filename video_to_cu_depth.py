@@ -6,9 +6,13 @@ Set ETHCNN_HOME to the repository root if this file is copied rather than symlin
 import importlib
 import os
 import sys
+import time
+
+_T_UP = time.perf_counter()  # interpreter up (ETHCNN_TIMING=1: where the command's wall time goes, scripts/cold_start.py)
 
 
 def _main():
+    os.environ.setdefault("ETHCNN_T_UP_MS", "%.3f" % (_T_UP * 1e3))
     home = os.environ.get("ETHCNN_HOME") or os.path.dirname(os.path.realpath(__file__))
     sys.path.insert(0, home)
     try:
