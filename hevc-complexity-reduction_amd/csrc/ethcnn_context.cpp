@@ -92,6 +92,9 @@ extern "C" int ethcnn_create(ethcnn_ctx** out, const ethcnn_options* opt) {
                        e == hipSuccess ? "device count 0" : hipGetErrorString(e));
     const int dev = opt ? opt->device : 0;
     if (dev < 0 || dev >= ndev) return set_err(nullptr, ETHCNN_ERR_ARG, "device %d out of range (0..%d)", dev, ndev - 1);
+    // (where the rest of the call goes: printed under ETHCNN_TIMING=1, scripts/cold_start.py)
+    std::vector<std::pair<const char*, std::chrono::steady_clock::time_point>> marks;
+    auto mark = [&](const char* what) { marks.emplace_back(what, std::chrono::steady_clock::now()); };
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess)
         return set_err(nullptr, ETHCNN_ERR_DEVICE, "hipGetDeviceProperties: %s", hipGetErrorString(e));
@@ -105,6 +108,7 @@ extern "C" int ethcnn_create(ethcnn_ctx** out, const ethcnn_options* opt) {
     if (opt && opt->max_ctus_per_pass > 0)
         c->max_ctus = std::min(kMaxCtusPerPass, std::max(1024, (int)(((long long)opt->max_ctus_per_pass + 1023) / 1024 * 1024)));
     if (opt && opt->host_threads > 0) c->host_threads_opt = opt->host_threads;
+    mark("device properties");
     if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->copy_in, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->copy_out, hipStreamNonBlocking) != hipSuccess ||
@@ -112,6 +116,7 @@ extern "C" int ethcnn_create(ethcnn_ctx** out, const ethcnn_options* opt) {
         ethcnn_destroy(c);  // releases whichever streams were created
         return set_err(nullptr, ETHCNN_ERR_DEVICE, "cannot create HIP streams on device %d", dev);
     }
+    mark("4 streams");
     {
         hipEvent_t* evs[] = {&c->e_tile[0], &c->e_tile[1], &c->e_trunk[0], &c->e_trunk[1], &c->e_main, &c->e_fc1[0], &c->e_fc1[1],
                              &c->e_band[0], &c->e_band[1], &c->e_band[2], &c->e_band[3]};
@@ -131,6 +136,7 @@ extern "C" int ethcnn_create(ethcnn_ctx** out, const ethcnn_options* opt) {
     if (const char* e = dev_env("ETHCNN_PULL")) c->pull = std::atoi(e) != 0;            // development knob (A/B runs)
     if (const char* e = dev_env("ETHCNN_TILE_AFTER_FC1")) c->tile_after_fc1 = std::atoi(e) != 0;  // development knob (A/B runs)
     if (const char* e = dev_env("ETHCNN_LSTM_ONE_LAUNCH")) c->lstm_one_launch = std::atoi(e) != 0;  // development knob (A/B runs)
+    mark("11 events");
     if (hipHostMalloc((void**)&c->h_done, 64, hipHostMallocDefault) != hipSuccess) {
         ethcnn_destroy(c);
         return set_err(nullptr, ETHCNN_ERR_DEVICE, "cannot allocate the completion word on device %d", dev);
@@ -141,6 +147,7 @@ extern "C" int ethcnn_create(ethcnn_ctx** out, const ethcnn_options* opt) {
     // steps then report ETHCNN_ERR_DEVICE; everything else works)
     if (c->h_rows) std::memset(c->h_rows, 0, kStreamCtuRows * sizeof(unsigned));
     c->tile_blocks = c->cus = prop.multiProcessorCount;
+    mark("page-locked words");
     {   // the GPU's NUMA node -> its CPU list (/sys/devices/system/node/nodeN/cpulist: "64-127,192-255"); ETHCNN_NUMA_BIND=0 opts out
         int node = -1;
         const char* off = std::getenv("ETHCNN_NUMA_BIND");
@@ -191,6 +198,19 @@ extern "C" int ethcnn_create(ethcnn_ctx** out, const ethcnn_options* opt) {
         }
     }
     if (const char* e = dev_env("ETHCNN_TILE_BLOCKS")) c->tile_blocks = std::max(1, std::atoi(e));
+    mark("NUMA lookup");
+    if (const char* tm = std::getenv("ETHCNN_TIMING"))
+        if (std::atoi(tm) != 0) {
+            std::string line = "ethcnn_create timing (ms): first HIP call (runtime init) " + std::to_string(std::chrono::duration<double, std::milli>(t_runtime - t_enter).count());
+            auto prev = t_runtime;
+            for (const auto& m : marks) {
+                char buf[96];
+                std::snprintf(buf, sizeof buf, " | %s %.2f", m.first, std::chrono::duration<double, std::milli>(m.second - prev).count());
+                line += buf;
+                prev = m.second;
+            }
+            std::fprintf(stderr, "%s\n", line.c_str());
+        }
     c->startup_ms[0] = std::chrono::duration<double, std::milli>(t_runtime - t_enter).count();
     c->startup_ms[1] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enter).count();
     *out = c;
@@ -209,8 +229,13 @@ extern "C" void ethcnn_destroy(ethcnn_ctx* c) {
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     free_workspace(c);
     free_staging(c);
-    for (ethcnn_ctx* p : c->peers) ethcnn_destroy(p);  // workers of ethcnn_predict_yuv_file_sharded
-    c->peers.clear();
+    {   // workers of ethcnn_predict_yuv_file_sharded: torn down side by side (a context's teardown is ~15-30 ms of runtime calls)
+        std::vector<std::thread> th;
+        for (ethcnn_ctx* p : c->peers)
+            if (p) th.emplace_back([p] { ethcnn_destroy(p); });
+        for (auto& t : th) t.join();
+        c->peers.clear();
+    }
     (void)hipSetDevice(c->device);
     for (const auto& r : c->pinned) (void)hipHostFree(const_cast<char*>(r.first));  // ethcnn_host_alloc buffers die with the context
     delete c->pool;

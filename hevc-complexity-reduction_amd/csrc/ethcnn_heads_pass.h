@@ -537,7 +537,7 @@ __device__ __forceinline__ void gate_chunk_range(const GateIndex& gi, int ch, in
 template <bool SELF_CLEAN = false, int TILE = 64>
 __device__ __forceinline__ void heads_gates_arrive(int* sync, int* arrived, const GateIndex& gi, int N, int first_ctu, float thr2,
                                                    float* probs, GateArrive* ga) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this block's probabilities and predicates have completed
+    ETHCNN_HANDOFF_RELEASE();  // this block's probabilities and predicates have completed
     __syncthreads();
     if (threadIdx.x == 0) {
         const int last_ctu = min(first_ctu + TILE - 1, N - 1);
@@ -552,6 +552,7 @@ __device__ __forceinline__ void heads_gates_arrive(int* sync, int* arrived, cons
         ga->n = n;
     }
     __syncthreads();
+    if (ga->n > 0) ETHCNN_HANDOFF_ACQUIRE();  // the completer reads the other blocks' predicates and may overwrite their probabilities
     for (int i = 0; i < ga->n; ++i) {
         const int ch = ga->ch[i];
         const bool open32 = __hip_atomic_load(sync + 2 * ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;

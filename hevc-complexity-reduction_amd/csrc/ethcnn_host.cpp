@@ -556,10 +556,10 @@ extern "C" int ethcnn_predict_yuv_file(ethcnn_ctx* c, const char* yuv, int w, in
 // worker 0; a peer context per further device is created once (cached with the context, destroyed with it) and takes a COPY of the
 // caller's weights, thresholds and plan -- no second checkpoint parse.  Each worker preads its frames and pwrites them at
 // frame_begin * nctu * 84 into a pre-sized temp file; one rename at the end.  Byte-identical to ethcnn_predict_yuv_file.
-static int sync_peer(ethcnn_ctx* c, ethcnn_ctx* p) {
+static int sync_peer(const ethcnn_ctx* c, ethcnn_ctx* p) {  // (on the peer's worker thread: errors stay in p->err)
     if (p->weights_from != c || p->weights_gen != c->weights_gen) {
         const int rc = ethcnn_load_blob(p, c->blob.data(), c->blob.size());
-        if (rc) return set_err(c, rc, "worker on device %d: %s", p->device, p->err.c_str());
+        if (rc) return rc;
         p->weights_from = c;
         p->weights_gen = c->weights_gen;
     }
@@ -597,39 +597,34 @@ extern "C" int ethcnn_predict_yuv_file_sharded(ethcnn_ctx* c, const int* devices
         const int rc = ensure_fast_weights(c, c->fc1_plan);
         if (rc) return rc;
     }
-    // workers: the caller's context + one cached peer per further list entry (a device may be listed more than once)
+    // workers: the caller's context + one cached peer per further list entry (a device may be listed more than once).  A peer is created
+    // (first call) and brought up to date BY ITS OWN WORKER THREAD, side by side with the others: a context costs ~60 ms of runtime calls,
+    // eight of them one after the other cost more than the whole job (profiles/r06_cold_start_first_form.txt)
     const int nw = (int)std::min<int64_t>(ndevices, total);
     if (c->shard_workers != nw) {  // the host budget is divided by the worker count: pools of another division are rebuilt
         delete c->pool;
         c->pool = nullptr;
-        for (ethcnn_ctx* p : c->peers) { delete p->pool; p->pool = nullptr; p->shard_workers = nw; }
+        for (ethcnn_ctx* p : c->peers)
+            if (p) { delete p->pool; p->pool = nullptr; p->shard_workers = nw; }
         c->shard_workers = nw;
     }
-    while ((int)c->peers.size() < nw - 1) {
-        ethcnn_options o{};
-        o.device = devices[c->peers.size() + 1];
-        o.max_ctus_per_pass = c->max_ctus;
-        ethcnn_ctx* p = nullptr;
-        const int rc = ethcnn_create(&p, &o);
-        if (rc) return set_err(c, rc, "worker on device %d: %s", o.device, ethcnn_last_error(nullptr));
-        p->shard_workers = nw;
-        c->peers.push_back(p);
-    }
-    for (int k = 1; k < nw; ++k)
-        if (c->peers[k - 1]->device != devices[k]) {  // another device list than last time: rebuild that peer
-            ethcnn_destroy(c->peers[k - 1]);
+    if ((int)c->peers.size() < nw - 1) c->peers.resize(nw - 1, nullptr);
+    std::vector<std::string> werr(nw);
+    auto prepare_peer = [&](int k) -> int {  // runs on worker k's thread; touches only c->peers[k - 1] and reads the caller's context
+        ethcnn_ctx*& p = c->peers[k - 1];
+        if (p && p->device != devices[k]) { ethcnn_destroy(p); p = nullptr; }  // another device list than last time
+        if (!p) {
             ethcnn_options o{};
             o.device = devices[k];
             o.max_ctus_per_pass = c->max_ctus;
-            c->peers[k - 1] = nullptr;
-            const int rc = ethcnn_create(&c->peers[k - 1], &o);
-            if (rc) { c->peers.resize(k - 1); return set_err(c, rc, "worker on device %d: %s", o.device, ethcnn_last_error(nullptr)); }
-            c->peers[k - 1]->shard_workers = nw;
+            const int rc = ethcnn_create(&p, &o);
+            if (rc) { werr[k] = ethcnn_last_error(nullptr); p = nullptr; return rc; }
+            p->shard_workers = nw;
         }
-    for (int k = 1; k < nw; ++k) {
-        const int rc = sync_peer(c, c->peers[k - 1]);
-        if (rc) return rc;
-    }
+        const int rc = sync_peer(c, p);
+        if (rc) werr[k] = p->err;
+        return rc;
+    };
     const int nctu = ((w + 63) / 64) * ((h + 63) / 64);
     const std::string tmp = std::string(out_path) + ".tmp." + std::to_string((long)getpid());
     {   // pre-size the temp file: every worker pwrites its own range
@@ -648,7 +643,11 @@ extern "C" int ethcnn_predict_yuv_file_sharded(ethcnn_ctx* c, const int* devices
         th.emplace_back([&, k] {
             int64_t f0, f1;
             range(k, &f0, &f1);
-            rcs[k] = yuv_frames(c->peers[k - 1], yuv, w, h, qp, tmp.c_str(), 1, f0, f1, nullptr);
+            rcs[k] = prepare_peer(k);
+            if (rcs[k] == 0) {
+                rcs[k] = yuv_frames(c->peers[k - 1], yuv, w, h, qp, tmp.c_str(), 1, f0, f1, nullptr);
+                if (rcs[k]) werr[k] = c->peers[k - 1]->err;
+            }
         });
     {
         int64_t f0, f1;
@@ -659,7 +658,7 @@ extern "C" int ethcnn_predict_yuv_file_sharded(ethcnn_ctx* c, const int* devices
     for (int k = 0; k < nw; ++k)
         if (rcs[k]) {
             std::remove(tmp.c_str());
-            if (k > 0) return set_err(c, rcs[k], "worker %d (device %d): %s", k, c->peers[k - 1]->device, c->peers[k - 1]->err.c_str());
+            if (k > 0) return set_err(c, rcs[k], "worker %d (device %d): %s", k, devices[k], werr[k].c_str());
             return rcs[0];
         }
     if (std::rename(tmp.c_str(), out_path) != 0) {

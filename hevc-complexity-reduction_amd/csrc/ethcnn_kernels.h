@@ -60,6 +60,24 @@ void launch_heads(const Workspace& ws, const DeviceWeights& w, int n, float qn, 
 void launch_heads_f16(const Workspace& ws, const DeviceWeights& w, int n, float qn, int nctu_per_frame, long ctu0, float thr1, float thr2,
                       float* d_probs, hipStream_t s);
 // ints of ws.flags a pass of `nchunks` gate sub-batches uses; ZERO on entry (the tile stage / the folded plan-3 trunk clears them)
+// ---- hand-offs INSIDE one launch (the single-launch small pass, k_lstm_frame, the gate arrival counters): a producer block's results are
+// read by a consumer block that may run on another XCD, i.e. behind another L2.  Shipped form ("lean"): results are stored, and read,
+// with AGENT-SCOPE accesses (sc1: written through to / fetched from memory, never resident in an L2 as ordinary lines), the producer
+// completes them (s_waitcnt vmcnt(0)) before the relaxed agent-scope atomic that announces them.  -DETHCNN_FULL_FENCE (A/B build,
+// scripts/gpu_fence_ab.sh -> profiles/r06_handoff_fence_ab.txt) adds the two cache-maintenance instructions of LLVM's gfx942
+// agent-scope release / acquire sequences -- buffer_wbl2 sc1 before the wait, buffer_inv sc1 behind the consumer's flag read --, which
+// are vacuous for data that is only ever touched with sc1 accesses (the argument of DESIGN_history.md section 3b) and are measured
+// there instead of argued.
+#ifdef ETHCNN_FULL_FENCE
+#define ETHCNN_HANDOFF_RELEASE() asm volatile("buffer_wbl2 sc1\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#define ETHCNN_HANDOFF_ACQUIRE() asm volatile("buffer_inv sc1" ::: "memory")
+#else
+#define ETHCNN_HANDOFF_RELEASE() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define ETHCNN_HANDOFF_ACQUIRE() \
+    do {                         \
+    } while (0)
+#endif
+
 inline int sync_words(int nchunks) { return 2 * nchunks + 8; }
 // A small pass (<= kSmallPassMaxCtus CTUs: up to one 3840x2160 picture; 16-byte aligned rows) as ONE launch (ethcnn_small.hip): CTU load + trunk -> FC1 ->
 // heads -> gates as a dataflow inside one grid (per-group / per-tile completion counters).  resi: the LDP front-end (stops

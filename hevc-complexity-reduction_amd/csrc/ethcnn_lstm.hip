@@ -328,7 +328,7 @@ __device__ __forceinline__ void lstm_heads(const LstmParams& lp, const float* __
 __device__ __forceinline__ void lstm_finish_frame(int* gate, int chunks, int N, float thr2, float* __restrict__ probs, unsigned bid,
                                                   unsigned nblk, unsigned* done, unsigned done_seq, int* s_last) {
     int* const pred = gate;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ETHCNN_HANDOFF_RELEASE();
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned l1 = bid >> 3, n_l1 = (nblk + 7) >> 3, in_l1 = min(8u, nblk - 8u * l1);
@@ -347,6 +347,7 @@ __device__ __forceinline__ void lstm_finish_frame(int* gate, int chunks, int N, 
     __syncthreads();
     LSTM_STAMP(1, 3);
     if (!*s_last) return;
+    ETHCNN_HANDOFF_ACQUIRE();  // the last block reads every block's predicates and may overwrite their probabilities
     for (int ch = 0; ch < chunks; ++ch) {
         const bool open32 = __hip_atomic_load(pred + 2 * ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
         // y16 is gated on the GATED y32: a closed L1 gate leaves zeros, and any(0 > thr2) decides (the 0 > thr2 corner)
@@ -495,7 +496,7 @@ __device__ __forceinline__ void lstm_frame_cell_item(const LstmFrameParams& P, c
     if (!mine) return;
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     lstm_cell<LV, CG, true>(P.lp, P.vec, P.state_in, P.state_out, P.N, gpx * CG, lane, q, t, xch, xh);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tile's new state (agent-scope stores) has completed ...
+    ETHCNN_HANDOFF_RELEASE();  // the tile's new state (agent-scope stores) has completed ...
     __syncthreads();
     if (threadIdx.x == 0 && lf_add(Y.cell_done + (gpx * 3 + LV) * kLPad, 1) + 1 == NT) {  // ... before the counter moves
         lf_put(Y.cell_done + (gpx * 3 + LV) * kLPad, 0);
@@ -564,6 +565,7 @@ __device__ __forceinline__ void lstm_frame_heads(const LstmFrameParams& P, const
         __syncthreads();                                                                                                \
         result = *s_flag != 0;                                                                                          \
         __syncthreads();                                                                                                \
+        if (result) ETHCNN_HANDOFF_ACQUIRE();                                                                           \
     }
     // The block is resident ~10 us before the cells of its group are done and fetches during that wait (holding the fetch back
     // for the first 6 / 10 us, while the cell blocks' own operand loads are in flight, measured slower).

@@ -150,8 +150,11 @@ int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, long ctu0
         const hipError_t le_ = hipGetLastError();                                                                  \
         if (le_ != hipSuccess) return set_err(c, ETHCNN_ERR_DEVICE, "launch of the %s stage failed: %s", name, hipGetErrorString(le_)); \
     } while (0)
+    // experiments build only (scripts/plan3_power.py): ONE stage of the pass, launched alone over and over (outputs meaningless) -- socket
+    // power and shader clock of each stage at steady state.  1 trunk (+ CTU-load stage), 2 FC1, 3 heads + gate
+    static const int only = [] { const char* e = dev_env("ETHCNN_STAGE_ONLY"); return e ? std::atoi(e) : 0; }();
     // the tile stage also zeroes the pass's gate predicates
-    if (fold3) {
+    if (fold3 || (only != 0 && only != 1)) {
         // (no tile launch; the folded trunk below clears the sync area itself)
     } else if (fold) {  // no tile launch: only the pass's sync area is cleared (what the tile stage does on the way)
         HIPCHK(c, hipMemsetAsync(w.flags, 0, (size_t)sync_words((int)nchunks) * sizeof(int), s_tile));
@@ -166,6 +169,7 @@ int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, long ctu0
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->e_tile[p], 0));
     }
     const int fast = c->fc1_plan;  // plans 2 / 3: trunk -> 16-bit feature pieces -> FC1 on the 16-bit matrix pipe
+    if (only == 0 || only == 1)
     { StageTimer t(c, ETHCNN_STAGE_TRUNK);
       if (fold) launch_trunk_direct(d_luma, g, ctu0, w, c->dw, n, c->stream);
       else if (fold3 && fold3_knob == 1) {
@@ -181,21 +185,21 @@ int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, long ctu0
     Workspace wv = w;
     if (!c->debug_capture) wv.h2 = wv.logits = wv.raw = nullptr;
     if (fast) {
-        { StageTimer t(c, ETHCNN_STAGE_FC1, n); launch_fc1_fast(w, c->dw, n, w.h1, fast == 3 ? 2 : fast, c->stream, c->cus); }
+        if (only == 0 || only == 2) { StageTimer t(c, ETHCNN_STAGE_FC1, n); launch_fc1_fast(w, c->dw, n, w.h1, fast == 3 ? 2 : fast, c->stream, c->cus); }
         LAUNCH_OK("FC1 (16-bit pipe)");
         if (side_tile && c->tile_after_fc1) HIPCHK(c, hipEventRecord(c->e_fc1[p], c->stream));
         // plan 3: the heads on the 16-bit pipe as well (experiments build: ETHCNN_PLAN3_HEADS=0 keeps the exact heads for the A/B)
         static const bool heads16_knob = [] { const char* e = dev_env("ETHCNN_PLAN3_HEADS"); return !e || std::atoi(e) != 0; }();
-        { StageTimer t(c, ETHCNN_STAGE_HEADS);
+        if (only == 0 || only == 3) { StageTimer t(c, ETHCNN_STAGE_HEADS);
           if (fast == 3 && heads16_knob && c->dw.heads16_w)
               launch_heads_f16(wv, c->dw, n, qn, g.nctu, ctu0, c->thr1, c->thr2, d_probs_pass, c->stream);
           else launch_heads(wv, c->dw, n, qn, g.nctu, ctu0, c->thr1, c->thr2, d_probs_pass, c->stream); }
     } else {
-        { StageTimer t(c, ETHCNN_STAGE_FC1, n); launch_fc1(w, c->dw, n, w.h1, c->stream); }
+        if (only == 0 || only == 2) { StageTimer t(c, ETHCNN_STAGE_FC1, n); launch_fc1(w, c->dw, n, w.h1, c->stream); }
         LAUNCH_OK("FC1");
-        { StageTimer t(c, ETHCNN_STAGE_HEADS); launch_heads(wv, c->dw, n, qn, g.nctu, ctu0, c->thr1, c->thr2, d_probs_pass, c->stream); }
+        if (only == 0 || only == 3) { StageTimer t(c, ETHCNN_STAGE_HEADS); launch_heads(wv, c->dw, n, qn, g.nctu, ctu0, c->thr1, c->thr2, d_probs_pass, c->stream); }
     }
-    { StageTimer t(c, ETHCNN_STAGE_GATE); launch_gate(w, n, g.nctu, ctu0, c->thr2, d_probs_pass, c->stream); }
+    if (only == 0 || only == 3) { StageTimer t(c, ETHCNN_STAGE_GATE); launch_gate(w, n, g.nctu, ctu0, c->thr2, d_probs_pass, c->stream); }
     LAUNCH_OK("heads / gate");
 #undef LAUNCH_OK
     if (!side_tile) c->main_dirty = true;  // a later pipelined tile stage must wait for this pass

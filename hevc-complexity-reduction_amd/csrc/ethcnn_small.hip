@@ -184,6 +184,7 @@ __device__ __forceinline__ bool block_wait(int* flag, const SmallParams& P, Smal
     __syncthreads();
     const bool w = sh->woken != 0;
     __syncthreads();
+    if (w) ETHCNN_HANDOFF_ACQUIRE();  // (every wave: what the flag announces is read behind this point)
     return w;
 }
 
@@ -198,7 +199,7 @@ __device__ __forceinline__ void do_pull_item(const SmallParams& P, const SmallSy
     if (P.tw.rows != nullptr) tile_wait_rows(P.tw, P.src.ctu0, grp, P.src.n_total, P.src.nctu, P.src.cw);
     tile_group<true, true, true>(reinterpret_cast<uint32_t*>(smem), P.src.luma, P.src.width, P.src.height, P.src.pitch, P.src.frame_stride, P.src.cw,
                                  P.src.nctu, P.src.ctu0, P.src.n_total, grp, P.xs, P.xm, P.xl);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the records (agent-scope stores) have completed before the flags move
+    ETHCNN_HANDOFF_RELEASE();  // the records (agent-scope stores) have completed before the flags move
     __syncthreads();
     if (threadIdx.x < 6) {  // the group's trunk items: 4 S blocks, the M block, the L block
         const int k = threadIdx.x, item = k < 4 ? 4 * grp + k : (k == 4 ? P.bS + grp : P.bS + P.bM + grp);
@@ -262,7 +263,7 @@ __device__ __forceinline__ void do_trunk_item(const SmallParams& P, const SmallS
         Trunk<2, RESI, true, true>::run(nullptr, P.ngroups, grp, P.bL, P.trunk_w, P.trunk_b, P.feat, P.n, smem, &P.src, claim, P.epoch, &sh->owned);
     }
     // the block's features (agent-scope stores) have completed before its group's counter moves
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ETHCNN_HANDOFF_RELEASE();
     __syncthreads();
     if (threadIdx.x == 0 && sh->owned && add_ret(Y.feat_done + grp * kPad, ntask) + ntask == 21) {  // 16 S + 4 M + 1 L: group complete
         put(Y.feat_done + grp * kPad, 0);
@@ -325,7 +326,7 @@ __device__ __forceinline__ void do_fc1_item(const SmallParams& P, const SmallSyn
     else fc1_tile_at<1, NS, 4, NSUB, 3, true, true>(smem, P.feat, P.wimg, P.fc1_b, P.h1, P.n, mt, nb);
     SMALL_STAMP(2);
     if (!RESI) {  // (LDP front-end: the vectors are the launch's output, nothing waits for them inside it)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ETHCNN_HANDOFF_RELEASE();
         __syncthreads();
         if (threadIdx.x == 0 && add_ret(Y.fc1_done + mt * kPad, 1) + 1 == NSPLIT) {  // all column blocks of the tile: wake its heads
             put(Y.fc1_done + mt * kPad, 0);
@@ -410,7 +411,7 @@ __global__ __launch_bounds__(256, 2) void k_small_pass(SmallParams P) {  // <= 2
     // block that completes the last one has seen, through the arrival counters, every probability of the launch stored
     // (s_waitcnt vmcnt(0) before each arrival) -- its own zero-fills included once it has waited for them here.
     if (P.done && sh.ga.n > 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ETHCNN_HANDOFF_RELEASE();
         __syncthreads();
         if (threadIdx.x == 0) {
             const bool last = add_ret(Y.done_cnt, sh.ga.n) + sh.ga.n == P.nchunks;
@@ -418,6 +419,7 @@ __global__ __launch_bounds__(256, 2) void k_small_pass(SmallParams P) {  // <= 2
             sh.woken = last ? 1 : 0;
         }
         __syncthreads();
+        if (sh.woken) ETHCNN_HANDOFF_ACQUIRE();
         if (sh.woken) {  // (block-uniform) this block completes the launch
             if (P.host_probs != nullptr) {
                 // every probability of the launch is in memory (agent-scope stores, completed before their blocks' arrivals): hand them

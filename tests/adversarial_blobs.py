@@ -41,3 +41,16 @@ def heavy_tailed(oracle, seed, gain, df=2.0):
         t *= med / max(float(np.median(np.abs(t))), 1e-20)
         v[...] = t
     return blob
+
+
+def cancelling_pairs(oracle, seed, gain, mag):
+    """two taps of output channel 0 of every conv kernel set to +mag and -mag: the response to FLAT input is unchanged (the pair cancels
+    exactly), the guaranteed bounds -- sums of |w| -- grow by mag per layer, i.e. by mag^3 for the features.  On flat / smooth content
+    the activations stay small while the fp16 scales are sized for 'mag^3': the loose-bound case at its purest, without saturating
+    every output (an outlier weight alone drives the sigmoids to 0 / 1, where no plan can differ from another)."""
+    blob = oracle.synth_blob(seed, gain).copy()
+    for name, v in _tensors(oracle, blob).items():
+        if v.ndim == 4:  # conv kernels [ky][kx][ci][co]
+            v[0, 0, 0, 0] = mag
+            v[0, 1, 0, 0] = -mag
+    return blob

@@ -311,7 +311,8 @@ def _guard_cases(oracle):
             ("one 1e3 outlier per conv tensor", ab.outlier_in(oracle, 21, 8.0, 1e3, ("Variable",)), None),
             ("one 1e3 outlier per FC tensor", ab.outlier_in(oracle, 21, 2.0, 1e3, ("h_fc", "y_conv")), None),
             ("Student-t (df 2) weights", ab.heavy_tailed(oracle, 21, 4.0), None),
-            ("one 1e7 outlier per conv tensor", ab.outlier_in(oracle, 21, 8.0, 1e7, ("Variable",)), False)]
+            ("one 1e7 outlier per conv tensor (saturates every output)", ab.outlier_in(oracle, 21, 8.0, 1e7, ("Variable",)), None),
+            ("cancelling +-1e6 tap pairs in every conv kernel", ab.cancelling_pairs(oracle, 21, 8.0, 1e6), False)]
 
 
 @pytest.mark.parametrize("plan", [2, 3])
@@ -322,7 +323,9 @@ def test_load_time_accuracy_guard_with_adversarial_weights(pkg, oracle, plan):
     bound <= 2.5e-5, or measured on the calibration picture <= 2.5e-5) and a test picture the guard never saw is within the north
     star's 1e-4 of the oracle with identical zero patterns -- or the guard REFUSES it: the pass returns ETHCNN_ERR_PLAN_REFUSED (-8) with
     the numbers in the message, nothing is written, and the context still computes the exact plan bit for bit.  Seeded weights must be
-    accepted, the 1e7 conv outliers (a feature bound 2^70 above typical values) refused: the guard is neither vacuous nor trigger-happy."""
+    accepted; conv kernels with a cancelling +-1e6 tap pair (bounds 1e18 above what flat content produces, outputs NOT saturated)
+    refused: the guard is neither vacuous nor trigger-happy.  (A plain 1e7 outlier saturates every sigmoid -- no plan can differ
+    from another there, measured 0 -- and is rightly accepted.)"""
     e = pkg.ethcnn
     rng = np.random.default_rng(4242)
     w, h, frames, qp = 1280, 768, 2, 27           # 240 CTUs per frame
@@ -369,7 +372,7 @@ def test_launchers_fall_back_to_the_exact_plan_when_the_guard_refuses(pkg, oracl
     import adversarial_blobs as ab
     from tfckpt_writer import write_bundle
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    blob = ab.outlier_in(oracle, 21, 8.0, 1e7, ("Variable",))
+    blob = ab.cancelling_pairs(oracle, 21, 8.0, 1e6)
     w, h, frames, qp = 832, 480, 30, 32            # 3120 CTUs: the file entry's multi-launch path
     rng = np.random.default_rng(5)
     yuv = rng.integers(0, 256, size=(frames, w * h * 3 // 2), dtype=np.uint8)
