@@ -20,6 +20,13 @@ extern "C" const char* ethcnn_last_error(const ethcnn_ctx* ctx) {
 }
 
 // ------------------------------------------------------------------ workspace -------
+int ensure_side_streams(ethcnn_ctx* c) {
+    hipStream_t* ss[] = {&c->copy_in, &c->copy_out, &c->s_tile};
+    for (hipStream_t* s : ss)
+        if (!*s) HIPCHK(c, hipStreamCreateWithFlags(s, hipStreamNonBlocking));
+    return 0;
+}
+
 static void free_workspace(ethcnn_ctx* c) {
     Workspace& w = c->ws;
     void* ptrs[] = {w.featb, w.xs, w.xm, w.xl, w.feat, w.h1, w.h2, w.logits, w.raw, w.flags, c->xs1, c->xm1, c->xl1, c->h1_1, c->flags1};
@@ -109,14 +116,14 @@ extern "C" int ethcnn_create(ethcnn_ctx** out, const ethcnn_options* opt) {
         c->max_ctus = std::min(kMaxCtusPerPass, std::max(1024, (int)(((long long)opt->max_ctus_per_pass + 1023) / 1024 * 1024)));
     if (opt && opt->host_threads > 0) c->host_threads_opt = opt->host_threads;
     mark("device properties");
-    if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->copy_in, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->copy_out, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->s_tile, hipStreamNonBlocking) != hipSuccess) {
-        ethcnn_destroy(c);  // releases whichever streams were created
-        return set_err(nullptr, ETHCNN_ERR_DEVICE, "cannot create HIP streams on device %d", dev);
+    // the main stream only: a HIP stream costs 10-15 ms to create (profiles/r06_cold_start.txt: "4 streams 68 ms" of a 260 ms command whose GPU
+    // work is 41 us), and one picture -- the reference's own C1 run, the encoder hook, every LDP frame -- never leaves the main stream.
+    // The H2D / D2H / CTU-load streams are created by the first call that pipelines (ensure_side_streams)
+    if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        ethcnn_destroy(c);
+        return set_err(nullptr, ETHCNN_ERR_DEVICE, "cannot create a HIP stream on device %d", dev);
     }
-    mark("4 streams");
+    mark("device init + main stream");
     {
         hipEvent_t* evs[] = {&c->e_tile[0], &c->e_tile[1], &c->e_trunk[0], &c->e_trunk[1], &c->e_main, &c->e_fc1[0], &c->e_fc1[1],
                              &c->e_band[0], &c->e_band[1], &c->e_band[2], &c->e_band[3]};

@@ -281,6 +281,7 @@ int set_err(ethcnn_ctx* c, int code, const char* fmt, ...);  // ethcnn_context.c
 // ethcnn_context.cpp
 Workspace ws_view(const ethcnn_ctx* c, int p);         // the buffer set of pass parity p
 int ensure_workspace(ethcnn_ctx* c, int n, int chunks);
+int ensure_side_streams(ethcnn_ctx* c);  // copy_in / copy_out / s_tile: created on first pipelined use, not by ethcnn_create
 hipEvent_t get_event(ethcnn_ctx* c);
 // ethcnn_model.cpp
 int ensure_fast_weights(ethcnn_ctx* c, int plan);

@@ -152,6 +152,7 @@ static int host_pipeline(ethcnn_ctx* c, int w, int h, int nframes, int qp, Fill 
                                          std::max((4096 + g.nctu - 1) / g.nctu, (nframes + 15) / 16)));
     const size_t plane = (size_t)w * h;
     rc = ensure_staging(c, plane * fpg, (size_t)fpg * g.nctu * kNOut * 4, kStageBufs);
+    if (rc == 0) rc = ensure_side_streams(c);
     if (rc) return rc;
     struct Group { int f0, nf; };
     std::vector<Group> groups;
@@ -208,7 +209,7 @@ static int host_pipeline(ethcnn_ctx* c, int w, int h, int nframes, int qp, Fill 
     };
     const int result = body();
     (void)hipStreamSynchronize(c->copy_in);  // on an error path nothing may still be reading / writing the ring
-    (void)hipStreamSynchronize(c->s_tile);
+    if (c->s_tile) (void)hipStreamSynchronize(c->s_tile);
     (void)hipStreamSynchronize(c->stream);
     (void)hipStreamSynchronize(c->copy_out);
     return result;
@@ -293,6 +294,8 @@ static int predict_luma_latency(ethcnn_ctx* c, const uint8_t* luma, int w, int h
         c->luma_over_pcie = false;
         c->host_probs = nullptr;
         direct = rc == 0 && c->host_probs_used;
+    } else if (banded && (rc = ensure_side_streams(c)) != 0) {
+        return rc;
     } else if (banded) {
         // (the round's first form, kept for ETHCNN_PULL=0 A/B runs)  One big picture (3840x2160: 8.3 MB = 151 us of PCIe against ~100 us of kernels, serial until round 4): the picture is
         // cut on its gate sub-batch boundaries (1024 CTUs in raster order: video_to_cu_depth.py:61-73, so gate scope is intact) and

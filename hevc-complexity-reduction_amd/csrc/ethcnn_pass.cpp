@@ -106,6 +106,7 @@ int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, long ctu0
     const bool side_tile = c->overlap != 0 && n >= kPipelineMinCtus && !fold3;
     const int p = side_tile ? (int)(c->pass_idx++ & 1) : 0;
     const Workspace w = ws_view(c, p);
+    if (side_tile && !c->s_tile && (rc = ensure_side_streams(c)) != 0) return rc;
     hipStream_t s_tile = side_tile ? c->s_tile : c->stream;
     if (input_ready) HIPCHK(c, hipStreamWaitEvent(s_tile, input_ready, 0));
     if (!side_tile && c->small_launch && small_pass_ok(d_luma, g, n)) {
@@ -152,7 +153,10 @@ int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, long ctu0
     } while (0)
     // experiments build only (scripts/plan3_power.py): ONE stage of the pass, launched alone over and over (outputs meaningless) -- socket
     // power and shader clock of each stage at steady state.  1 trunk (+ CTU-load stage), 2 FC1, 3 heads + gate
-    static const int only = [] { const char* e = dev_env("ETHCNN_STAGE_ONLY"); return e ? std::atoi(e) : 0; }();
+    // (the first three passes of the process run whole: the stage then loops on the REAL features / h1 they left -- FC1's power depends on its data)
+    static const int only_knob = [] { const char* e = dev_env("ETHCNN_STAGE_ONLY"); return e ? std::atoi(e) : 0; }();
+    static int passes_seen = 0;
+    const int only = (only_knob != 0 && ++passes_seen > 3) ? only_knob : 0;
     // the tile stage also zeroes the pass's gate predicates
     if (fold3 || (only != 0 && only != 1)) {
         // (no tile launch; the folded trunk below clears the sync area itself)

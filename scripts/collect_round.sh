@@ -24,6 +24,8 @@ if [ -s gpurun_out/latency_mid_now.txt ]; then { grep "^#" profiles/${R}_latency
 [ -s gpurun_out/power_probe.txt ] && cp gpurun_out/power_probe.txt profiles/${R}_power_probe.txt
 if [ -s gpurun_out/ldp_handshake.txt ]; then { grep "^#" gpurun_out/ldp_handshake.txt; grep "^# native\|^# first form\|^#   \|^#    \|^# Boxes" profiles/${R}_ldp_handshake.txt 2>/dev/null; grep -v "^#" gpurun_out/ldp_handshake.txt; } > /tmp/_hs.txt && cp /tmp/_hs.txt profiles/${R}_ldp_handshake.txt; fi
 [ -s gpurun_out/step_traffic.json ] && cp gpurun_out/step_traffic.json profiles/step_traffic.json
+[ -s gpurun_out/step_gaps.txt ] && cp gpurun_out/step_gaps.txt profiles/${R}_step_gaps.txt
+[ -s gpurun_out/cold_start.txt ] && cp gpurun_out/cold_start.txt profiles/${R}_cold_start.txt
 for f in gpurun_out/traffic_by_kernel_grid_*.csv gpurun_out/kernel_stats_by_grid_*.csv; do [ -s "$f" ] && cp "$f" profiles/${R}_$(basename "$f"); done
 python - "$R" <<'PY'
 import csv, glob, collections, json, sys

@@ -56,6 +56,16 @@ cd $REPO
 python scripts/kernel_stats_by_grid.py $(find gpurun_out/prof_$WL -name "*kernel_trace.csv" | head -1) gpurun_out/kernel_stats_by_grid_$WL.csv "rocprofv3 --kernel-trace --stats -- python bench.py --workload $WL --no-cpu-baseline --no-host-scopes --no-other-configs --no-fast-plan (scripts/gpu_round.sh): the exact plan of $WL alone"
 python scripts/kernel_stats_by_grid.py $(find gpurun_out/prof_${WL}_plan3 -name "*kernel_trace.csv" | head -1) gpurun_out/kernel_stats_by_grid_${WL}_plan3.csv "rocprofv3 --kernel-trace -- python bench.py --workload $WL --no-cpu-baseline --no-host-scopes --no-other-configs --fast-plans 3 (scripts/gpu_round.sh): exact region, then the plan-3 region"
 head -12 gpurun_out/kernel_stats_by_grid_$WL.csv
+# where a step's time goes between its kernels, c3 against c2: the c2 trace the same way, then scripts/trace_gaps.py
+if [ "$WL" = c3 ]; then
+  cd /tmp
+  rocprofv3 --kernel-trace --output-format csv -d $REPO/gpurun_out/prof_c2 -o c2 -- python $REPO/bench.py --workload c2 --no-cpu-baseline --no-host-scopes --no-other-configs --no-fast-plan > $REPO/gpurun_out/prof_c2.log 2>&1
+  cd $REPO
+  python scripts/kernel_stats_by_grid.py $(find gpurun_out/prof_c2 -name "*kernel_trace.csv" | head -1) gpurun_out/kernel_stats_by_grid_c2.csv "rocprofv3 --kernel-trace -- python bench.py --workload c2 --no-cpu-baseline --no-host-scopes --no-other-configs --no-fast-plan (scripts/gpu_round.sh): the exact plan of c2 alone"
+  { python scripts/trace_gaps.py $(find gpurun_out/prof_c3 -name "*kernel_trace.csv" | head -1) "c3 (3840x2160 x 50 = 102,000 CTUs per step), exact plan"
+    python scripts/trace_gaps.py $(find gpurun_out/prof_c2 -name "*kernel_trace.csv" | head -1) "c2 (1920x1080 x 50 = 25,500 CTUs per step), exact plan"; } > gpurun_out/step_gaps.txt 2>&1
+  cat gpurun_out/step_gaps.txt
+fi
 python - <<'PY'
 import csv, glob, collections
 for f in sorted(glob.glob("gpurun_out/pmc_c*/**/*counter_collection.csv", recursive=True)):

@@ -18,7 +18,7 @@ BIN = os.path.join(ROOT, "hevc-complexity-reduction_amd", "bin")
 GOLD = os.path.join(ROOT, "tests", "golden", "model_LDP_200000_qp32.dat")
 
 
-def run(base, w, h, frames, gap_us, extra=()):
+def run(base, w, h, frames, gap_us, extra=(), client_extra=()):
     work = tempfile.mkdtemp(prefix="ldp_tail_", dir=base)
     try:
         open(os.path.join(work, "Thr_info.txt"), "w").write("0.4 0.6 0.3 0.7 0.2 0.8")
@@ -28,14 +28,14 @@ def run(base, w, h, frames, gap_us, extra=()):
         d = subprocess.Popen([os.path.join(BIN, "resi_to_cu_depth_ldp"), "--max-frames", str(frames), "--idle-timeout", "120", "--quiet", "--trace",
                               "--trace-slow", "600"] + list(extra), cwd=work, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
         time.sleep(2.5)
-        c = subprocess.run([os.path.join(BIN, "ldp_client"), work, str(w), str(h), "32", str(frames), "--gap-us", str(gap_us), "--slow-us", "1000"],
+        c = subprocess.run([os.path.join(BIN, "ldp_client"), work, str(w), str(h), "32", str(frames), "--gap-us", str(gap_us), "--slow-us", "1000"] + list(client_extra),
                            capture_output=True, text=True, timeout=900)
         try:
             d.wait(timeout=60)
         except subprocess.TimeoutExpired:
             d.kill()
         derr = d.stderr.read()
-        print("%-8s %dx%d gap %d %s: %s" % (base, w, h, gap_us, " ".join(extra), c.stdout.strip()))
+        print("%-8s %dx%d gap %d %s%s: %s" % (base, w, h, gap_us, " ".join(extra), (" client " + " ".join(client_extra)) if client_extra else "", c.stdout.strip()))
         slow_c = {int(m.group(1)): m for m in re.finditer(r"slow POC (\d+): handshake (\d+) us = remove \+ command.dat (\d+) \| create pred_start.sig (\d+) \| wait for pred_end.sig (\d+) \| "
                                                            r"remove it \+ read cu_depth.dat (\d+) ; monotonic us: pred_start.sig created (\d+), pred_end.sig seen (\d+)", c.stderr)}
         slow_d = {int(m.group(1)): m for m in re.finditer(r"slow frame (\d+): (\d+) us from detection.*?monotonic us: detected (\d+), ending signal (\d+)", derr)}
@@ -70,6 +70,15 @@ def main():
                 run(base, w, h, frames if gap == 0 else frames // 5, gap)
     run("/dev/shm", 1920, 1080, frames, 0, ("--spin",))
     run("/dev/shm", 1920, 1080, frames, 0, ("--no-stream",))
+    # round 6: is it the ENCODER's wait -- a tight loop of failing fopen("pred_end.sig") calls, TEncGOP.cpp:1483 -- that
+    # stalls every file operation in a tmpfs directory?  tmpfs keeps no negative dentries: each failing lookup takes the directory's rwsem
+    # shared and allocates a dentry, and whoever has to MODIFY the directory meanwhile (the daemon's link() for the ending signal, its
+    # unlink of pred_start.sig, the encoder's own remove / create) queues behind a stream of readers.  A DIAGNOSTIC client that sleeps
+    # between two attempts (not what the unchanged encoder does) takes that stream away:
+    if os.path.isdir("/dev/shm"):
+        for poll in ("0", "20", "100"):
+            run("/dev/shm", 1920, 1080, frames, 0, (), ("--poll-us", poll))
+        run("/dev/shm", 416, 240, frames, 0, (), ("--poll-us", "20"))
 
 
 if __name__ == "__main__":

@@ -89,3 +89,13 @@ def test_c4_full_job_streamed_in_shards(pkg, oracle):
             assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), k
     finally:
         c.close()
+
+
+def test_handoff_stress_slice():
+    """a 6000-launch slice of scripts/handoff_stress.py (the round's full run: 100,000 launches, profiles/r06_handoff_stress.txt): the
+    single-launch pass and the LDP frame launches on ONE workspace with different data every launch, bit-compared, beside a context
+    streaming C3-sized passes and a thread of copies on the same GPU -- the test of the lean hand-off form (include csrc/ethcnn_kernels.h:
+    agent-scope accesses + s_waitcnt, without the two cache-maintenance instructions the full release / acquire sequence would add
+    at 20 us per 1080p call)"""
+    out = _script("handoff_stress.py", LAUNCHES=6000)
+    assert "handoff stress:" in out and out.strip().endswith(": 0 mismatches"), out[-800:]

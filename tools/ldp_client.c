@@ -24,6 +24,7 @@
 #define _POSIX_C_SOURCE 200809L
 #include <errno.h>
 #include <stdint.h>
+#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -59,7 +60,7 @@ static int cmp_double(const void* a, const void* b) {
 
 int main(int argc, char** argv) {
     if (argc < 6) {
-        fprintf(stderr, "usage: ldp_client <workdir> <width> <height> <qp> <frames> [--seed N] [--gap-us N] [--digest FILE] [--keep-resi]\n");
+        fprintf(stderr, "usage: ldp_client <workdir> <width> <height> <qp> <frames> [--seed N] [--gap-us N] [--digest FILE] [--keep-resi] [--slow-us US] [--poll-us US]\n");
         return 2;
     }
     const char* dir = argv[1];
@@ -68,6 +69,9 @@ int main(int argc, char** argv) {
     double slow_us = 0.0;
     const char* digest = NULL;
     int keep_resi = 0;
+    long poll_us = -1; /* < 0: HM's own wait, a tight loop of failing fopen("pred_end.sig") calls (TEncGOP.cpp:1483); >= 0 (DIAGNOSTIC, not
+                          what the unchanged encoder does): sleep that long between two attempts -- profiles/r06_ldp_tail.txt uses it to show
+                          what the busy loop itself does to file operations in a tmpfs directory */
     rng_state = 12345;
     for (int i = 6; i < argc; ++i) {
         if (!strcmp(argv[i], "--seed") && i + 1 < argc) rng_state = strtoull(argv[++i], NULL, 10);
@@ -75,6 +79,7 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--digest") && i + 1 < argc) digest = argv[++i];
         else if (!strcmp(argv[i], "--keep-resi")) keep_resi = 1;
         else if (!strcmp(argv[i], "--slow-us") && i + 1 < argc) slow_us = atof(argv[++i]);
+        else if (!strcmp(argv[i], "--poll-us") && i + 1 < argc) poll_us = atol(argv[++i]);
         else { fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
     }
     if (w <= 0 || h <= 0 || frames <= 0) { fprintf(stderr, "bad geometry / frame count\n"); return 2; }
@@ -115,6 +120,10 @@ int main(int argc, char** argv) {
         unsigned spins = 0;
         while ((fe = fopen("pred_end.sig", "r")) == NULL) {
             if ((++spins & 0xfff) == 0 && now_us() - t_wait0 > 30e6) { fprintf(stderr, "no answer from the daemon for 30 s (POC %d)\n", poc); return 3; }
+            if (poll_us >= 0) {
+                struct timespec ts = {0, poll_us * 1000};
+                if (poll_us > 0) nanosleep(&ts, NULL); else sched_yield();
+            }
         }
         const double t_seen = now_us();
         int rr = -1;
