@@ -47,10 +47,17 @@ __global__ __launch_bounds__(256) void k_heads(const float* __restrict__ H1, Hea
     // the short heads 32 / 64 fill in behind it.  A third of the per-block latency, three times the blocks.
     if (head_ == 0)
         head_pass<2>(smem, H1, hp, qn, lane, wvu, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
+#ifdef HEADS_OLD_SHORT  // A/B builds: round 5's fetch plan for the short heads (scripts/build_variant.sh oldheads -DHEADS_OLD_SHORT)
     else if (head_ == 1)
         head_pass<1>(smem, H1, hp, qn, lane, wvu, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
     else
         head_pass<0>(smem, H1, hp, qn, lane, wvu, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
+#else
+    else if (head_ == 1)
+        head_pass_short<1>(smem, H1, hp, qn, lane, wvu, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
+    else
+        head_pass_short<0>(smem, H1, hp, qn, lane, wvu, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
+#endif
     HEADS_STAMP(4);
 }
 
