@@ -878,6 +878,7 @@ def cold_start_ms():
     import shutil
     import subprocess
     import tempfile
+    import numpy as np
     out = {}
     d = tempfile.mkdtemp(prefix="cold_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     try:
