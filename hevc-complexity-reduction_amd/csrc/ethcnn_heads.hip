@@ -14,7 +14,9 @@
 //   FC3^T needs for step (t, r) -- so FC2 -> FC3 chains in registers (same k order), no LDS,
 //   no HBM round trip.  FC3^T's A operand (W3, 3525 floats in all) comes straight from L1/L2.
 // Where the stage's time goes (phase stamps, device timeline, the rebuilt "wide" variant that was measured and dropped):
-// profiles/r02_heads_timeline.txt, scripts/ubench/heads_probe.hip.
+// profiles/r02_heads_timeline.txt, scripts/ubench/heads_probe.hip.  Round 6 built the leaner fetch plan for the short heads that the round-5
+// timeline suggested (h1 of all chunks at block start, four W2 stages in the same 24 KB, W3 + scalars in one round trip; bit-identical):
+// stage 0.150 -> 0.143 ms, 0.3 % of a C3 step, the tail of the launch unchanged -- below the 1 % bar, removed (profiles/r06_heads_short_ab.txt).
 #include <hip/hip_runtime.h>
 
 #include "ethcnn_kernels.h"
@@ -47,17 +49,10 @@ __global__ __launch_bounds__(256) void k_heads(const float* __restrict__ H1, Hea
     // the short heads 32 / 64 fill in behind it.  A third of the per-block latency, three times the blocks.
     if (head_ == 0)
         head_pass<2>(smem, H1, hp, qn, lane, wvu, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
-#ifdef HEADS_OLD_SHORT  // A/B builds: round 5's fetch plan for the short heads (scripts/build_variant.sh oldheads -DHEADS_OLD_SHORT)
     else if (head_ == 1)
         head_pass<1>(smem, H1, hp, qn, lane, wvu, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
     else
         head_pass<0>(smem, H1, hp, qn, lane, wvu, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
-#else
-    else if (head_ == 1)
-        head_pass_short<1>(smem, H1, hp, qn, lane, wvu, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
-    else
-        head_pass_short<0>(smem, H1, hp, qn, lane, wvu, valid, ctu, h2row, logits, raw, probs, fl, fl + 1, thr1, thr2);
-#endif
     HEADS_STAMP(4);
 }
 

@@ -242,165 +242,6 @@ __device__ __forceinline__ void head_pass(float* smem, const float* __restrict__
 }
 
 
-// ---- the SHORT heads (32 and 64) of the multi-launch path, round 6.  profiles/r05_heads_timeline.txt: head 16 -- 75 % of the stage's matrix
-// work -- runs at the matrix pipe's rate and is gone after 65 us; the 60 us behind it belong to the short heads, whose blocks spend 57 k
-// clocks on 6.9 k clocks of MFMAs (head 32): a chain of dependent round trips (h1 piece + W2 chunk one chunk ahead, W3 one tile ahead,
-// the qp weight and bias at the very end) with nothing left on the CU to cover them.  Same arithmetic, same k order, same results bit
-// for bit -- other fetch plan:
-//   * the wave's h1 quads of ALL chunks are requested at block start (NK x 4 VGPRs); all of W3 (4 NT VGPRs) and the qp weight / bias of the
-//     output row in one go behind the K loop, in flight under the FC2 epilogue;
-//   * W2 chunks are 6 / 3 KB here, so the block's 24 KB of LDS hold FOUR stages of them: head 64's whole W2 is in flight at once, head 32
-//     runs three chunks ahead instead of one (h1 no longer travels through the stage).
-// Head 16 keeps head_pass: its 12 KB chunks fill a stage each, and in its phase the other blocks of the CU do cover the round trips.
-template <int H>
-__device__ __forceinline__ void head_pass_short(float* smem, const float* __restrict__ H1, const HeadsParams& hp, float qn,
-                                                int lane, unsigned wvu, bool valid, int ctu, float* __restrict__ h2row,
-                                                float* __restrict__ logits, float* __restrict__ raw, float* __restrict__ probs,
-                                                int* flag32, int* flag16, float thr1, float thr2) {
-    using D = Hd<H>;
-    static_assert(H == 0 || H == 1, "heads 64 / 32");
-    constexpr int STG = D::B_FLOATS;                                    // floats per stage: one W2 chunk, nothing else
-    constexpr int NSTG = (kHeadsStages * kHeadsStage / STG) < D::NK ? (kHeadsStages * kHeadsStage / STG) : D::NK;  // 4 / 4
-    static_assert(NSTG >= 2 && NSTG * STG <= kHeadsStages * kHeadsStage, "stages must fit the block's LDS");
-    const int col = lane & 15, g = lane >> 4;
-    const float* W2 = hp.w2[H];
-    const float* W3 = hp.w3[H];
-    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void*)smem);
-    unsigned b_off[D::B_PER];
-#pragma unroll
-    for (int i = 0; i < D::B_PER; ++i) {
-        const int q = min((int)wvu + i * 4, D::B_INST - 1);
-        const int e = q * 64 + lane;
-        int row = (e / (D::N2 / 4)) % 16;
-        int c4 = e % (D::N2 / 4);
-        if (D::COLSWZ) c4 ^= ((row >> 2) & 1) << 2;
-        else row ^= (row >> 2) & 1;
-        b_off[i] = 4u * (unsigned)(row * D::N2 + c4 * 4);
-    }
-    int a_base[2];
-    if (D::COLSWZ) { a_base[0] = 4 * g * D::N2 + col + 16 * (g & 1); a_base[1] = 4 * g * D::N2 + col - 16 * (g & 1); }
-    else { a_base[0] = 4 * g * D::N2 + col + D::N2 * (g & 1); a_base[1] = 4 * g * D::N2 + col - D::N2 * (g & 1); }
-
-    // ---- block start: every operand that does not wait for the K loop (buffer loads: in vmcnt order BEFORE the DMA groups below, so the
-    // counted waits of the loop cover them too)
-    const __amdgpu_buffer_rsrc_t rH1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(H1), 0, -1, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rW2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W2), 0, (D::N1 + 1) * D::N2 * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rB2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hp.b2[H]), 0, D::N2 * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rW3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W3), 0, (D::N2 + 1) * D::N3 * 4, 0x00020000);
-    const unsigned a_off = 4u * (unsigned)(ctu * kNVec + D::O1 + 4 * g);
-    f32x4 hq[D::NK];
-#pragma unroll
-    for (int kc = 0; kc < D::NK; ++kc) hq[kc] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rH1, a_off, kc * 64, 0));
-    __builtin_amdgcn_sched_barrier(0);
-
-#define HS2_DMA(voff, sbase, lds_byte_off)                                                               \
-    {                                                                                                    \
-        unsigned keep_;                                                                                  \
-        const unsigned dst_ = __builtin_amdgcn_readfirstlane(lds_base + (lds_byte_off));                 \
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" \
-                     : "=&s"(keep_) : "v"(voff), "s"(sbase), "s"(dst_) : "memory");                      \
-    }
-#define HS2_ISSUE(kc)                                                                                    \
-    {                                                                                                    \
-        _Pragma("unroll") for (int i = 0; i < D::B_PER; ++i)                                             \
-            HS2_DMA(b_off[i], W2 + (size_t)(kc) * 16 * D::N2,                                            \
-                    4u * (((kc) % NSTG) * STG + min(wvu + i * 4, (unsigned)(D::B_INST - 1)) * 256));     \
-    }
-    f32x4 acc[D::NT];
-#pragma unroll
-    for (int j = 0; j < D::NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    __builtin_amdgcn_s_barrier();  // the previous user of the block's LDS has consumed it
-    HEADS_STAMP(1);
-#pragma unroll
-    for (int kc = 0; kc < NSTG - 1; ++kc) { HS2_ISSUE(kc); }
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D::B_PER * (NSTG - 2)) : "memory");  // chunk 0 (and every load above) has landed
-    __builtin_amdgcn_s_barrier();
-    HEADS_STAMP(2);
-#pragma unroll
-    for (int kc = 0; kc < D::NK; ++kc) {
-        // chunk kc + NSTG - 1 goes into the stage chunk kc - 1 used: every wave left it at the barrier that ended iteration kc - 1
-        if (kc + NSTG - 1 < D::NK) { HS2_ISSUE(kc + NSTG - 1); }
-        const f32x4 av = hq[kc];
-        const float* bsE = smem + (kc % NSTG) * STG + a_base[0];
-        const float* bsO = smem + (kc % NSTG) * STG + a_base[1];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float hv = av[e];
-#pragma unroll
-            for (int j = 0; j < D::NT; ++j)
-                acc[j] = MFMA16((((D::COLSWZ ? j : e) & 1) ? bsO : bsE)[e * D::N2 + 16 * j], hv, acc[j]);  // rows = W2 columns
-        }
-        if (kc + 1 < D::NK) {
-            // chunk kc + 1 has landed when at most the groups issued behind it are outstanding: chunks kc + 2 .. min(kc + NSTG - 1, NK - 1)
-            constexpr int kLast = D::NK - 1;
-            const int later = ((kc + NSTG - 1 < kLast) ? kc + NSTG - 1 : kLast) - (kc + 1);
-            switch (later) {  // (kc is a compile-time constant in the unrolled loop: one immediate survives)
-                case 0: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(0) : "memory"); break;
-                case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D::B_PER) : "memory"); break;
-                default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * D::B_PER) : "memory"); break;
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    }
-#undef HS2_DMA
-#undef HS2_ISSUE
-    HEADS_STAMP(3);
-    // all of W3, the qp weight and the bias of this lane's outputs: requested together here (h1's registers are free now; keeping them live
-    // through the K loop cost the kernel its six blocks per CU: 109 VGPRs), in flight under the FC2 epilogue's own operand loads -- ONE round
-    // trip where head_pass makes one per tile and one more for the two scalars
-    float w3r[D::NT][4];
-    {
-        const int w3off = (4 * g * D::N3 + col) * 4;  // lane part of W3[(16 j + 4 g + r) * N3 + col]; columns >= N3 read as 0
-#pragma unroll
-        for (int j = 0; j < D::NT; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                w3r[j][r] = (col < D::N3) ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rW3, w3off, (16 * j + r) * D::N3 * 4, 0)) : 0.0f;
-    }
-    float w3q[4], b3v[4];  // the qp weight and the bias of outputs 4 g + r (the sigmoid's last two operands)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int o = min(4 * g + r, D::N3 - 1);
-        w3q[r] = W3[D::N2 * D::N3 + o];
-        b3v[r] = hp.b3[H][o];
-    }
-    // FC2 epilogue in place, then FC3^T and the sigmoid: exactly head_pass's arithmetic (same operand order)
-#pragma unroll
-    for (int j = 0; j < D::NT; ++j) {
-        const int n = 16 * j + 4 * g;
-        const f32x4 wq = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW2, 16 * g, (D::N1 * D::N2 + 16 * j) * 4, 0));
-        const f32x4 bv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rB2, 16 * g, 64 * j, 0));
-        acc[j][0] = lrelu_h(fmaf(qn, wq.x, acc[j][0]) + bv.x);
-        acc[j][1] = lrelu_h(fmaf(qn, wq.y, acc[j][1]) + bv.y);
-        acc[j][2] = lrelu_h(fmaf(qn, wq.z, acc[j][2]) + bv.z);
-        acc[j][3] = lrelu_h(fmaf(qn, wq.w, acc[j][3]) + bv.w);
-        if (valid && h2row) *reinterpret_cast<f32x4*>(h2row + D::O2 + n) = acc[j];
-    }
-    f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < D::NT; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) z = MFMA16(w3r[j][r], acc[j][r], z);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int o = 4 * g + r;
-        if (o < D::N3 && valid) {
-            const float zz = fmaf(qn, w3q[r], z[r]) + b3v[r];
-            const float p = 1.0f / (1.0f + expf_canonical_h(-zz));
-            const size_t idx = (size_t)ctu * kNOut + D::O3 + o;
-            if (logits) logits[idx] = zz;
-            if (raw) raw[idx] = p;
-            probs[idx] = p;
-            if (H == 0 && p > thr1 && __hip_atomic_load(flag32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
-                __hip_atomic_store(flag32, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // any(y64 > THR_L1_LOWER)
-            if (H == 1 && p > thr2 && __hip_atomic_load(flag16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
-                __hip_atomic_store(flag16, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // any(y32_tmp > THR_L2_LOWER)
-        }
-    }
-}
-
-
 // ---- latency form for ONE group of 16 CTUs (the single-launch small pass, ethcnn_small.hip): the block's waves SPLIT the FC2
 // output tiles of the head (head 16: 12 tiles -> 3 per wave; 32: 2, 2, 2, -; 64: 1, 1, 1, -) instead of each taking 16
 // CTUs with all tiles: a wave's K loop is a quarter as long (head 16: 192 MFMAs instead of 768 -- the 64-CTU form keeps one
