@@ -559,6 +559,14 @@ extern "C" int ethcnn_predict_yuv_file(ethcnn_ctx* c, const char* yuv, int w, in
 // worker 0; a peer context per further device is created once (cached with the context, destroyed with it) and takes a COPY of the
 // caller's weights, thresholds and plan -- no second checkpoint parse.  Each worker preads its frames and pwrites them at
 // frame_begin * nctu * 84 into a pre-sized temp file; one rename at the end.  Byte-identical to ethcnn_predict_yuv_file.
+// worker k of n gets frames [floor(k F / n), floor((k + 1) F / n)): the split of sharding.frame_range (the process-per-GPU form), in one place
+extern "C" int ethcnn_shard_range(int64_t nframes, int workers, int k, int64_t* frame_begin, int64_t* frame_end) {
+    if (nframes < 0 || workers <= 0 || k < 0 || k >= workers || !frame_begin || !frame_end) return ETHCNN_ERR_ARG;
+    *frame_begin = nframes * k / workers;
+    *frame_end = nframes * (k + 1) / workers;
+    return ETHCNN_OK;
+}
+
 static int sync_peer(const ethcnn_ctx* c, ethcnn_ctx* p) {  // (on the peer's worker thread: errors stay in p->err)
     if (p->weights_from != c || p->weights_gen != c->weights_gen) {
         const int rc = ethcnn_load_blob(p, c->blob.data(), c->blob.size());
@@ -641,7 +649,7 @@ extern "C" int ethcnn_predict_yuv_file_sharded(ethcnn_ctx* c, const int* devices
     }
     std::vector<int> rcs(nw, 0);
     std::vector<std::thread> th;
-    auto range = [&](int k, int64_t* f0, int64_t* f1) { *f0 = total * k / nw; *f1 = total * (k + 1) / nw; };  // = sharding.frame_range
+    auto range = [&](int k, int64_t* f0, int64_t* f1) { (void)ethcnn_shard_range(total, nw, k, f0, f1); };
     for (int k = 1; k < nw; ++k)
         th.emplace_back([&, k] {
             int64_t f0, f1;

@@ -95,6 +95,7 @@ SIGNATURES = {
     "ethcnn_predict_luma": (_i, [_vp, _vp, _i, _i, _pd, _pd, _i, _i, _fp]),
     "ethcnn_predict_yuv_file": (_i, [_vp, _cp, _i, _i, _i, _cp, ctypes.POINTER(ctypes.c_int64)]),
     "ethcnn_predict_yuv_file_sharded": (_i, [_vp, ctypes.POINTER(ctypes.c_int), _i, _cp, _i, _i, _i, _cp, ctypes.POINTER(ctypes.c_int64)]),
+    "ethcnn_shard_range": (_i, [ctypes.c_int64, _i, _i, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
     "ethcnn_get_startup_times": (_i, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "ethcnn_predict_yuv_shard": (_i, [_vp, _cp, _i, _i, _i, _cp, ctypes.c_int64, ctypes.c_int64]),
     "ethcnn_predict_yuv_range": (_i, [_vp, _cp, _i, _i, _i, _cp, ctypes.c_int64, ctypes.c_int64]),

@@ -138,6 +138,8 @@ int ethcnn_predict_yuv_shard(ethcnn_ctx* ctx, const char* yuv_path, int width, i
  * rename.  Output byte-identical to ethcnn_predict_yuv_file.  ndevices == 1 is that call. */
 int ethcnn_predict_yuv_file_sharded(ethcnn_ctx* ctx, const int* devices, int ndevices, const char* yuv_path, int width, int height, int qp,
                                     const char* out_path, int64_t* nframes_out);
+/* the split both sharded forms use: worker k of n gets frames [floor(k F / n), floor((k + 1) F / n)).  Pure (no context, no device). */
+int ethcnn_shard_range(int64_t nframes, int workers, int k, int64_t* frame_begin, int64_t* frame_end);
 
 /* get_prob(yuv_name, ..., n_frames_start, n_frames_end, ...) (video_to_cu_depth.py:75-118): frames [frame_begin, frame_end) of the
  * file (the reference reads and discards the first n_frames_start frames, :86-87) -> an `out_path` that holds exactly those

@@ -1,6 +1,6 @@
 #!/bin/bash
 # The host side of the library (worker pool, staging ring, cross-stream events, completion word, checkpoint parser) under
-# AddressSanitizer + UndefinedBehaviorSanitizer: `make asan` builds the four .cpp files instrumented with g++ (the kernels are the
+# AddressSanitizer + UndefinedBehaviorSanitizer: `make asan` builds the host .cpp files instrumented with g++ (the kernels are the
 # same hipcc objects) into lib_asan/libethcnn.so; the CPU suite and the GPU suite then run on it through ETHCNN_LIB with the sanitizer runtime
 # preloaded into python.  Any report aborts the process (halt_on_error, -fno-sanitize-recover): a green run = no finding.
 # Usage (GPU box): bash scripts/gpu_asan.sh [pytest args]  -> gpurun_out/asan_gpu.log

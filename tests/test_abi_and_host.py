@@ -89,6 +89,23 @@ def test_constants_mirror(pkg):
     assert pkg.ethcnn.ctus_per_frame(1920, 1080) == 510 and pkg.ethcnn.ctus_per_frame(4928, 3264) == 3927
 
 
+def test_thread_sharded_entry_splits_frames_like_the_process_form(pkg):
+    """ethcnn_shard_range (the split ethcnn_predict_yuv_file_sharded hands its worker threads) == sharding.frame_range (the split of the
+    process-per-GPU form, world-size-2 gloo test): the two sharded forms cut a file at the same frames, so their outputs can only be
+    byte-identical (GPU: tests/test_gpu_cli.py).  Pure host arithmetic."""
+    import ctypes
+    lib = pkg.load_library()
+    for nframes in (0, 1, 7, 8, 9, 50, 425, 10 ** 9 + 7):
+        for world in (1, 2, 3, 8, 64):
+            for k in range(world):
+                a, b = ctypes.c_int64(), ctypes.c_int64()
+                assert lib.ethcnn_shard_range(nframes, world, k, ctypes.byref(a), ctypes.byref(b)) == 0
+                assert (a.value, b.value) == pkg.sharding.frame_range(nframes, world, k)
+    a, b = ctypes.c_int64(), ctypes.c_int64()
+    assert lib.ethcnn_shard_range(10, 0, 0, ctypes.byref(a), ctypes.byref(b)) != 0
+    assert lib.ethcnn_shard_range(10, 2, 2, ctypes.byref(a), ctypes.byref(b)) != 0
+
+
 def test_frame_ranges_partition(pkg):
     fr = pkg.sharding.frame_range
     for F in (0, 1, 7, 50, 425):
