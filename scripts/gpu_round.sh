@@ -10,8 +10,8 @@ export TMPDIR=/tmp
 REPO=$PWD
 WL=${WL:-c3}
 if [ -z "${SKIP_TESTS:-}" ]; then
-  python -m pytest tests -m gpu -x -q --timeout 400 2>&1 | tail -4
-  python __graft_entry__.py smoke 2>&1 | tail -3
+  python -m pytest tests -m gpu -x -q --timeout 900 2>&1 | tail -6 | tee gpurun_out/gpu_tests.txt
+  python __graft_entry__.py smoke 2>&1 | tail -3 | tee -a gpurun_out/gpu_tests.txt
 fi
 bash scripts/gpu_dist_smoke.sh 2>&1 | tail -6
 # the counter passes FIRST: the bench lines below carry roofline.traffic and hbm only when the committed numbers were taken at these kernel sources
