@@ -26,4 +26,11 @@ def _main():
 
 
 if __name__ == "__main__":  # guard: multi-GPU mode spawns worker processes that re-import this file
-    sys.exit(_main())
+    _rc = _main()
+    if _rc == 0 and os.environ.get("ETHCNN_FAST_EXIT", "1") not in ("", "0"):
+        # cu_depth.dat is complete and renamed into place; the interpreter's and the HIP runtime's teardown (~60 ms) would only keep the
+        # encoder waiting (it blocks on this command, TAppEncCfg.cpp:2317-2321).  ETHCNN_FAST_EXIT=0 keeps the orderly exit.
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
+    sys.exit(_rc)
