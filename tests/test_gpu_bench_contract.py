@@ -108,6 +108,8 @@ def test_one_gpu_line_states_the_north_star_ratio_and_the_fast_plans():
             assert 1.0 <= rl["traffic_over_algorithmic"] < 3.0
         else:
             assert hbm["bytes_per_step"] is None                            # the same stamp rules both
+    cs = hs["cold_start_ms"]   # the command's wall time on the reference's own C1 case, both launchers
+    assert "error" not in cs and 30.0 < cs["native_tool"] < 5000.0 and 60.0 < cs["python_launcher"] < 10000.0, cs
     cl = d["ctu_load_stage"]["counter_bytes_per_ctu"]
     assert cl["fetched"] is None or (3500 < cl["fetched"] < 12000 and 6000 < cl["written"] < 8000), cl
     for key, dtype_word in (("fast_plan_fp16x2", "fp16x2"), ("fast_plan_fp16x2_trunk", "fp16x2")):
