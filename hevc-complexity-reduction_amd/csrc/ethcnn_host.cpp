@@ -650,21 +650,29 @@ extern "C" int ethcnn_predict_yuv_file_sharded(ethcnn_ctx* c, const int* devices
     std::vector<int> rcs(nw, 0);
     std::vector<std::thread> th;
     auto range = [&](int k, int64_t* f0, int64_t* f1) { (void)ethcnn_shard_range(total, nw, k, f0, f1); };
-    for (int k = 1; k < nw; ++k)
-        th.emplace_back([&, k] {
-            int64_t f0, f1;
-            range(k, &f0, &f1);
-            rcs[k] = prepare_peer(k);
-            if (rcs[k] == 0) {
-                rcs[k] = yuv_frames(c->peers[k - 1], yuv, w, h, qp, tmp.c_str(), 1, f0, f1, nullptr);
-                if (rcs[k]) werr[k] = c->peers[k - 1]->err;
-            }
-        });
+    auto work = [&](int k) {
+        int64_t f0, f1;
+        range(k, &f0, &f1);
+        rcs[k] = prepare_peer(k);
+        if (rcs[k] == 0) {
+            rcs[k] = yuv_frames(c->peers[k - 1], yuv, w, h, qp, tmp.c_str(), 1, f0, f1, nullptr);
+            if (rcs[k]) werr[k] = c->peers[k - 1]->err;
+        }
+    };
+    std::vector<int> inline_k;  // workers whose thread could not be started (no exception may cross the C ABI): their share runs here, afterwards
+    for (int k = 1; k < nw; ++k) {
+        try {
+            th.emplace_back(work, k);
+        } catch (...) {
+            inline_k.push_back(k);
+        }
+    }
     {
         int64_t f0, f1;
         range(0, &f0, &f1);
         rcs[0] = yuv_frames(c, yuv, w, h, qp, tmp.c_str(), 1, f0, f1, nullptr);
     }
+    for (int k : inline_k) work(k);
     for (auto& t : th) t.join();
     for (int k = 0; k < nw; ++k)
         if (rcs[k]) {

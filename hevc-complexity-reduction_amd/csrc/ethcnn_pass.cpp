@@ -90,8 +90,10 @@ int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, long ctu0
                          (ctu0 / g.nctu * cpf + (ctu0 % g.nctu) / kSubBatch);
     c->done_armed = 0;
     // the 16-bit plans' weight images + their accuracy guard: before anything of THIS pass is enqueued (the guard's measured stage runs
-    // two passes of its own through this workspace)
-    int rc = c->fc1_plan ? ensure_fast_weights(c, c->fc1_plan) : 0;
+    // two passes of its own through this workspace).  Not for a pass that will run as the single-launch small pass: that one always
+    // computes exactly, whatever the plan (and may be a STREAMED picture whose rows are not in memory yet)
+    const bool takes_small = c->small_launch && n < kPipelineMinCtus && small_pass_ok(d_luma, g, n);
+    int rc = (c->fc1_plan && !takes_small) ? ensure_fast_weights(c, c->fc1_plan) : 0;
     if (rc) return rc;
     rc = ensure_workspace(c, n, (int)nchunks);
     if (rc) return rc;
@@ -272,16 +274,22 @@ int calibrate_fast_plan(ethcnn_ctx* c, int plan, double* max_abs) {
     std::vector<float> p(2 * pf);
     const float t1 = c->thr1, t2 = c->thr2;
     const int plan0 = c->fc1_plan, small0 = c->small_launch;
-    const bool cap0 = c->debug_capture;
+    const bool cap0 = c->debug_capture, pcie0 = c->luma_over_pcie;
+    const unsigned* const wait0 = c->tile_wait_rows;  // (the caller may be a streamed picture's pass: the calibration picture is complete)
+    float* const hp0 = c->host_probs;
     c->thr1 = c->thr2 = -1.0f;  // gates open: all 21 outputs of every CTU are compared
     c->small_launch = 0;        // the plans are forms of the multi-launch path
     c->debug_capture = false;
+    c->tile_wait_rows = nullptr;
+    c->luma_over_pcie = false;
+    c->host_probs = nullptr;
     hipError_t e = hipMemcpyAsync(d_luma, luma.data(), luma.size(), hipMemcpyHostToDevice, c->stream);
     for (int k = 0; k < 2 && rc == 0 && e == hipSuccess; ++k) {
         c->fc1_plan = k == 0 ? 0 : plan;
         rc = run_pass(c, d_luma, g, 0, g.nctu, QP, d_p + k * pf);
     }
     c->thr1 = t1; c->thr2 = t2; c->fc1_plan = plan0; c->small_launch = small0; c->debug_capture = cap0;
+    c->tile_wait_rows = wait0; c->luma_over_pcie = pcie0; c->host_probs = hp0;
     if (rc == 0 && e == hipSuccess) e = hipMemcpyAsync(p.data(), d_p, 2 * pf * 4, hipMemcpyDeviceToHost, c->stream);
     const hipError_t e2 = hipStreamSynchronize(c->stream);
     (void)hipFree(d_luma);

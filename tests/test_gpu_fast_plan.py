@@ -390,3 +390,34 @@ def test_launchers_fall_back_to_the_exact_plan_when_the_guard_refuses(pkg, oracl
         assert r.returncode == 0 and "refused" in r.stderr and "exact plan" in r.stderr, (cmd, r.stderr[-800:])
         got = np.fromfile(str(out), dtype="<f4").reshape(-1, 21)
         assert np.array_equal(_bits(got), _bits(want)), cmd
+
+
+@pytest.mark.parametrize("plan", [2, 3])
+def test_first_call_under_a_plan_may_be_a_streamed_small_picture(pkg, oracle, plan):
+    """The accuracy guard's measured stage runs two passes of its own; it must not run inside a pass whose picture is still being copied
+    (the host entry streams a pageable picture's staging copy into the queued single-launch pass) -- and has no reason to: the
+    single-launch pass always computes exactly.  First call of a fresh context under a plan = one pageable 1080p picture: bit-exact vs
+    the oracle, and quick (a calibration waiting for rows that are not there yet would sit out its 1 s patience).  The guard is then
+    evaluated by the first BIG pass, as always."""
+    import time
+    w, h, qp = 1920, 1080, 27
+    rng = np.random.default_rng(77)
+    luma = rng.integers(0, 256, size=(h, w), dtype=np.uint8)
+    blob = oracle.synth_blob(13, 8.0)
+    c = pkg.EthCnn(device=0)
+    try:
+        c.load_blob(blob)
+        c.set_thresholds(0.5, 0.5)
+        c.set_fc1_plan(plan)
+        c.predict_luma(luma, w, h, 1, qp)          # (first call of the context: allocations)
+        t0 = time.time()
+        got = c.predict_luma(luma, w, h, 1, qp)
+        assert time.time() - t0 < 0.5
+        assert np.array_equal(_bits(got), _bits(oracle.predict_frames(blob, luma, w, h, 1, qp, 0.5, 0.5, mode=0)))
+        big = np.stack([luma] * 6)                  # 3060 CTUs: multi-launch path -> the plan (and its guard) apply
+        got = c.predict_luma(big, w, h, 6, qp)
+        want = oracle.predict_frames(blob, big, w, h, 6, qp, 0.5, 0.5, mode=0)
+        assert np.array_equal(got == 0.0, want == 0.0) and np.abs(got - want).max() <= TOL
+        assert c.check_fc1_plan(plan)["accepted"]
+    finally:
+        c.close()
