@@ -235,7 +235,8 @@ std::vector<Pass> plan_passes(int nctu, int nframes, int max_ctus) {
 
 // ---- the measured stage of the 16-bit plans' accuracy guard (ethcnn_model.cpp::check_fast_plan).  A seeded picture of 2048 x 1280
 // (32 x 20 CTUs) made of 128 x 128 macro tiles of six kinds, so that large and tiny activations both occur (the floors of the split
-// pieces are ABSOLUTE: they show where values are small); both plans through the multi-launch path, gates open (every output compared).
+// pieces are ABSOLUTE: they show where values are small); both plans through the multi-launch path at QP 22 and at QP 37, gates open
+// (every output compared).
 static void calibration_picture(std::vector<uint8_t>& luma, int w, int h) {
     luma.resize((size_t)w * h);
     uint64_t s = 0x9E3779B97F4A7C15ull;
@@ -260,7 +261,8 @@ static void calibration_picture(std::vector<uint8_t>& luma, int w, int h) {
         }
 }
 int calibrate_fast_plan(ethcnn_ctx* c, int plan, double* max_abs) {
-    constexpr int W = 2048, H = 1280, QP = 32;
+    constexpr int W = 2048, H = 1280;
+    constexpr int kQps[2] = {22, 37};  // both ends of the QP range the four checkpoints cover (the QP column of FC2 / FC3 is part of the plan-3 heads)
     FrameGeom g;
     int rc = make_geom(c, W, H, W, (ptrdiff_t)W * H, &g);
     if (rc) return rc;
@@ -270,8 +272,8 @@ int calibrate_fast_plan(ethcnn_ctx* c, int plan, double* max_abs) {
     uint8_t* d_luma = nullptr;
     float* d_p = nullptr;
     HIPCHK(c, hipMalloc((void**)&d_luma, luma.size()));
-    if (hipMalloc((void**)&d_p, 2 * pf * 4) != hipSuccess) { (void)hipFree(d_luma); return set_err(c, ETHCNN_ERR_NOMEM, "calibration: out of device memory"); }
-    std::vector<float> p(2 * pf);
+    if (hipMalloc((void**)&d_p, 4 * pf * 4) != hipSuccess) { (void)hipFree(d_luma); return set_err(c, ETHCNN_ERR_NOMEM, "calibration: out of device memory"); }
+    std::vector<float> p(4 * pf);  // [qp][exact | plan]
     const float t1 = c->thr1, t2 = c->thr2;
     const int plan0 = c->fc1_plan, small0 = c->small_launch;
     const bool cap0 = c->debug_capture, pcie0 = c->luma_over_pcie;
@@ -284,23 +286,24 @@ int calibrate_fast_plan(ethcnn_ctx* c, int plan, double* max_abs) {
     c->luma_over_pcie = false;
     c->host_probs = nullptr;
     hipError_t e = hipMemcpyAsync(d_luma, luma.data(), luma.size(), hipMemcpyHostToDevice, c->stream);
-    for (int k = 0; k < 2 && rc == 0 && e == hipSuccess; ++k) {
-        c->fc1_plan = k == 0 ? 0 : plan;
-        rc = run_pass(c, d_luma, g, 0, g.nctu, QP, d_p + k * pf);
+    for (int k = 0; k < 4 && rc == 0 && e == hipSuccess; ++k) {
+        c->fc1_plan = (k & 1) == 0 ? 0 : plan;
+        rc = run_pass(c, d_luma, g, 0, g.nctu, kQps[k >> 1], d_p + k * pf);
     }
     c->thr1 = t1; c->thr2 = t2; c->fc1_plan = plan0; c->small_launch = small0; c->debug_capture = cap0;
     c->tile_wait_rows = wait0; c->luma_over_pcie = pcie0; c->host_probs = hp0;
-    if (rc == 0 && e == hipSuccess) e = hipMemcpyAsync(p.data(), d_p, 2 * pf * 4, hipMemcpyDeviceToHost, c->stream);
+    if (rc == 0 && e == hipSuccess) e = hipMemcpyAsync(p.data(), d_p, 4 * pf * 4, hipMemcpyDeviceToHost, c->stream);
     const hipError_t e2 = hipStreamSynchronize(c->stream);
     (void)hipFree(d_luma);
     (void)hipFree(d_p);
     if (rc) return rc;
     if (e != hipSuccess || e2 != hipSuccess) return set_err(c, ETHCNN_ERR_DEVICE, "calibration of plan %d failed: %s", plan, hipGetErrorString(e != hipSuccess ? e : e2));
     double worst = 0.0;
-    for (size_t i = 0; i < pf; ++i) {
-        const double d = std::fabs((double)p[i] - (double)p[pf + i]);
-        if (!(d <= worst)) worst = d;  // (a NaN sticks)
-    }
+    for (int q = 0; q < 2; ++q)
+        for (size_t i = 0; i < pf; ++i) {
+            const double d = std::fabs((double)p[(2 * q) * pf + i] - (double)p[(2 * q + 1) * pf + i]);
+            if (!(d <= worst)) worst = d;  // (a NaN sticks)
+        }
     *max_abs = worst;
     return ETHCNN_OK;
 }

@@ -294,7 +294,7 @@ int ethcnn_get_fc1_plan(const ethcnn_ctx* ctx);
  * the weights alone (video_to_cu_depth.py:126-133: any of the four checkpoints a run may restore must be safe).  At or below 2.5e-5 (a
  * quarter of the 1e-4 contract) the plan is accepted on the bound alone.  Above it the worst case decides nothing (it is pessimistic by
  * the looseness of the very bounds it guards), so the plan is MEASURED once: a seeded calibration picture (640 CTUs: flat, low-contrast,
- * gradient, noise, edge and texture tiles) through the exact plan and through the plan, gates open; max |dp| <= 2.5e-5 accepts, anything
+ * gradient, noise, edge and texture tiles) through the exact plan and through the plan at QP 22 and QP 37, gates open; max |dp| <= 2.5e-5 accepts, anything
  * else REFUSES: the pass returns ETHCNN_ERR_PLAN_REFUSED with the numbers in ethcnn_last_error, nothing is computed, the context stays
  * usable (ethcnn_set_fc1_plan(ctx, 0 or 2)).  Never a silent loss of accuracy, never a silent fallback.  ~3 ms, once per weight load.
  *   ethcnn_check_fc1_plan   ETHCNN_OK / ETHCNN_ERR_PLAN_REFUSED for the loaded weights; *apriori_bound, *measured (may be NULL; measured
