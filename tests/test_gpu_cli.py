@@ -117,6 +117,17 @@ def test_sharded_entry_reuses_its_workers_and_follows_the_context(pkg, oracle, t
         assert not (tmp_path / "x.dat").exists() and not [f for f in os.listdir(str(tmp_path)) if ".tmp." in f]
         a, b = c.startup_times()
         assert 0.0 <= a <= b < 60000.0
+        # a plan the accuracy guard refuses for the loaded weights: the sharded entry says so BEFORE any worker starts, nothing is written
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import adversarial_blobs as ab
+        c.load_blob(ab.cancelling_pairs(oracle, 21, 8.0, 1e6))
+        c.set_fc1_plan(3)
+        big = _yuv(str(tmp_path / "big.yuv"), 832, 480, 40, 9)     # 4160 CTUs: the multi-launch path, where the plans apply
+        with pytest.raises(e.EthCnnError, match="refused") as ei:
+            c.predict_yuv_file_sharded([0, 0], str(tmp_path / "big.yuv"), 832, 480, qp, str(tmp_path / "y.dat"))
+        assert ei.value.code == e.ERR_PLAN_REFUSED and not (tmp_path / "y.dat").exists() and not [f for f in os.listdir(str(tmp_path)) if ".tmp." in f]
+        c.set_fc1_plan(0)
+        assert c.predict_yuv_file_sharded([0, 0], str(tmp_path / "big.yuv"), 832, 480, qp, str(tmp_path / "y.dat")) == 40
     finally:
         c.close()
 
