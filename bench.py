@@ -502,12 +502,47 @@ def host_scopes_sharded(ctx, luma, W, H, NF, QP, rank, world, dist, backend, bar
         out["s3_luma_gbps_total"] = world * NF * W * H / best / 1e9
         out["s3_file"] = "%d frames of %dx%d 4:2:0 (%.2f GB) in %s, one frame range per rank" % (world * NF, W, H, world * NF * frame_bytes / 1e9, os.path.dirname(box[0]))
         barrier()
+        # ... and what the encoder would see: the drop-in COMMAND over all the job's GPUs -- one process, a worker thread
+        # per GPU (tools/video_to_cu_depth.c -> ethcnn_predict_yuv_file_sharded) -- on the same file, wall time incl. process start, N
+        # contexts and the exit; rank 0 runs it while the other ranks wait at the barrier (their contexts stay allocated, idle)
+        if rank == 0:
+            out["sharded_command"] = sharded_command(box[0], yuv, W, H, QP, world, nctu * NF * world)
+        barrier()
     finally:
         barrier()
         if rank == 0:
             shutil.rmtree(box[0], ignore_errors=True)
     out["note"] = "best of 3, whole job: sum over ranks / slowest rank; every rank runs at the same time"
     return out
+
+
+def sharded_command(workdir, yuv, W, H, QP, world, total_ctus):
+    """wall time of `ETHCNN_DEVICES=<the ranks' GPUs> video_to_cu_depth <yuv> <w> <h> <qp>` (native tool), median of 3 behind a warm-up run;
+    a side measurement: any failure is reported, never raised"""
+    import subprocess
+    tool = os.path.join(ROOT, "hevc-complexity-reduction_amd", "bin", "video_to_cu_depth")
+    try:
+        forced = os.environ.get("BENCH_FORCE_DEVICE")
+        devices = [int(forced)] * world if forced is not None else list(range(world))
+        cwd = os.path.join(workdir, "cmd")
+        os.makedirs(cwd, exist_ok=True)
+        open(os.path.join(cwd, "Thr_info.txt"), "w").write("0.5 0.5 0.5 0.5 0.5 0.5\n")
+        env = dict(os.environ, ETHCNN_SYNTHETIC_SEED="1", ETHCNN_DEVICES=",".join(str(d) for d in devices))
+        for k in ("ETHCNN_LOCAL_WORKERS", "LOCAL_WORLD_SIZE", "WORLD_SIZE", "RANK", "LOCAL_RANK"):
+            env.pop(k, None)  # (the command is ONE process with its own worker threads: the node budget is divided inside it)
+        walls = []
+        for rep in range(4):
+            t0 = time.perf_counter()
+            r = subprocess.run([tool, yuv, str(W), str(H), str(QP)], cwd=cwd, env=env, capture_output=True, text=True, timeout=600)
+            if r.returncode != 0:
+                return {"error": r.stderr[-300:]}
+            if rep:
+                walls.append(time.perf_counter() - t0)
+        w = sorted(walls)[len(walls) // 2]
+        return {"wall_ms": w * 1e3, "ctus_per_s": total_ctus / w, "workers": world, "devices": devices,
+                "what": "native tool, one process, a worker thread per GPU, whole command incl. process start / N contexts / exit; median of 3"}
+    except Exception as exc:  # noqa: BLE001
+        return {"error": str(exc)}
 
 
 def pin_to_gpu_numa_node(device_name):

@@ -13,4 +13,4 @@ import json
 lines=[l for l in open('gpurun_out/dist_smoke.json') if l.startswith('{')]
 assert len(lines)==1, lines
 d=json.loads(lines[0]); print('n_gpus', d['n_gpus'], 'value %.2fM' % (d['value']/1e6), 'ms_per_step %.3f' % d['ms_per_step'], 'keys ok', all(k in d for k in ('metric','unit','steps','warmup','scaling','roofline','config','cpu_baseline','host_scopes')))
-print('host_scopes', d['host_scopes'])"
+print('host_scopes', d['host_scopes']); assert 'wall_ms' in d['host_scopes']['sharded_command'], d['host_scopes']['sharded_command']"
