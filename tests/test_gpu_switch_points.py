@@ -3,7 +3,7 @@ its plan (ADVICE r03 #1 / VERDICT r04 item 5), bit-exact against the oracle, pas
 
   total CTUs <= 2304 (kSmallPassMaxCtus, ethcnn_kernels.h)     one launch for the whole picture (ethcnn_small.hip)
   2305 .. 8191                                                  the latency path with five launches on the main stream
-  >= 8192 (kPipelineMinCtus, ethcnn_api.cpp)                    the staging ring + pass pipeline (tile stage on the side stream beside FC1)
+  >= 8192 (kPipelineMinCtus, ethcnn_ctx.h)                      the staging ring + pass pipeline (tile stage on the side stream beside FC1)
 
 A pass of EXACTLY 8192 CTUs once took the latency path while its tile stage ran on the side stream, unordered with the latency path's
 H2D copy (fixed in round 3 by the strict `<` in ethcnn_predict_luma); these are the sizes that would show such a slip again.
