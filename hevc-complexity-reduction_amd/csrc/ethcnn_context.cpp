@@ -24,10 +24,6 @@ int ensure_side_streams(ethcnn_ctx* c) {
     hipStream_t* ss[] = {&c->copy_in, &c->copy_out, &c->s_tile};
     for (hipStream_t* s : ss)
         if (!*s) HIPCHK(c, hipStreamCreateWithFlags(s, hipStreamNonBlocking));
-    if (!c->d_tile_ticket) {
-        HIPCHK(c, hipMalloc((void**)&c->d_tile_ticket, 128));
-        HIPCHK(c, hipMemset(c->d_tile_ticket, 0, 128));
-    }
     return 0;
 }
 
@@ -255,7 +251,7 @@ extern "C" void ethcnn_destroy(ethcnn_ctx* c) {
     if (c->dw_trunk16) (void)hipFree(c->dw_trunk16);
     if (c->dw_heads16) (void)hipFree(c->dw_heads16);
     {
-        void* lp[] = {c->d_lstm, c->d_vec, c->d_state[0], c->d_state[1], c->d_lprobs, c->d_lgate, c->d_ssync, c->d_tile_ticket};
+        void* lp[] = {c->d_lstm, c->d_vec, c->d_state[0], c->d_state[1], c->d_lprobs, c->d_lgate, c->d_ssync};
         for (void* p : lp)
             if (p) (void)hipFree(p);
     }

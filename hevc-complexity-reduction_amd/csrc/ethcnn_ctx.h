@@ -175,7 +175,6 @@ struct ethcnn_ctx {
     float* h1_1 = nullptr;
     int* flags1 = nullptr;
     hipStream_t s_tile = nullptr;
-    int* d_tile_ticket = nullptr;  // ticket word of the side-stream CTU-load launches (launch_tile_side): zero between launches
     hipEvent_t e_tile[2] = {}, e_trunk[2] = {}, e_main = nullptr;
     hipEvent_t e_fc1[2] = {};     // fast plans: "FC1 of the pass on buffer set p has finished" (the next pass's tile stage starts behind it)
     int tile_after_fc1 = 0;       // fast plans: the CTU-load stage of pass i+1 beside heads + gates of pass i instead of beside its FC1

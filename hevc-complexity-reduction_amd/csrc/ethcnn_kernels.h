@@ -35,10 +35,6 @@ struct FrameGeom {
 // CTU rows hold wait_seq (ethcnn_tile.hip, TileWait); *gave_up = wait_seq if a block waited ~1 s in vain
 void launch_tile(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, const Workspace& ws, int n_flags,
                  hipStream_t s, int max_blocks = 0, const unsigned* wait_rows = nullptr, unsigned wait_seq = 0, unsigned* gave_up = nullptr);
-// k0 on the side stream beside FC1 of the previous pass: persistent blocks (<= max_blocks) that take their groups from a ticket word (one
-// device int, zero between launches) and raise their wave priority when still at work boost_ticks (100 MHz; 0 = never) after their start
-void launch_tile_side(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, const Workspace& ws, int n_flags, hipStream_t s,
-                      int max_blocks, int* ticket, unsigned boost_ticks);
 // k1: xs/xm/xl -> feat (fc1_plan 2: -> featb, every feature as two fp16 pieces in the 16-bit MFMA's operand order)
 void launch_trunk(const Workspace& ws, const DeviceWeights& w, int n, bool resi, hipStream_t s, int fc1_plan = 0);
 // k1 with the CTU-load stage folded in (A/B form, experiments build: ethcnn_trunk.hip); needs small_pass_ok-style 16-byte alignment

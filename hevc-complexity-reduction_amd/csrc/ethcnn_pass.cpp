@@ -166,15 +166,6 @@ int run_pass(ethcnn_ctx* c, const uint8_t* d_luma, const FrameGeom& g, long ctu0
         HIPCHK(c, hipMemsetAsync(w.flags, 0, (size_t)sync_words((int)nchunks) * sizeof(int), s_tile));
     } else {
         StageTimer t(c, ETHCNN_STAGE_TILE, n, s_tile);
-        // experiments build: ETHCNN_TILE_SIDE=0 keeps round 5's side-stream form (groups by blockIdx, no priority boost); ETHCNN_TILE_BOOST_PCT
-        // = when a block raises its priority, in per cent of the pass's expected FC1 time (default 70; 0 = never)
-        static const int side_form = [] { const char* e = dev_env("ETHCNN_TILE_SIDE"); return e ? std::atoi(e) : 1; }();
-        static const int boost_pct = [] { const char* e = dev_env("ETHCNN_TILE_BOOST_PCT"); return e ? std::atoi(e) : 70; }();
-        if (side_tile && side_form && c->d_tile_ticket) {
-            // FC1 of the pass beside which this launch runs takes ~16.5 ns per CTU (1.68 ms at 102,000): 1.65 ticks of the 100 MHz clock
-            const unsigned boost = c->fc1_plan == 0 ? (unsigned)((double)n * 1.65 * boost_pct / 100.0) : 0u;
-            launch_tile_side(d_luma, g, ctu0, n, w, sync_words((int)nchunks), s_tile, c->tile_blocks, c->d_tile_ticket, boost);
-        } else
         launch_tile(d_luma, g, ctu0, n, w, sync_words((int)nchunks), s_tile, side_tile ? c->tile_blocks : 0,
                     side_tile ? nullptr : c->tile_wait_rows, c->rows_seq, c->h_done + 1);  // (streamed input: a single main-stream pass)
     }

@@ -38,65 +38,6 @@ __global__ __launch_bounds__(256) void k0_tile_slab(const uint8_t* __restrict__ 
     }  // groups of this block
 }
 
-// The same stage as it runs on the side stream BESIDE FC1 of the previous pass (one persistent block per CU, FC1's waves at a higher wave
-// priority: the stage lives in FC1's issue gaps and takes about as long as FC1 itself).  profiles/r06_step_gaps.txt: the next trunk then waits
-// for it 48 us per C3 step on average (up to 265): with groups dealt out by blockIdx (b, b + 256, ...) the launch ends when its unluckiest
-// CU does (launch time 1.72 ms +- 0.47).  Round 6: (a) groups beyond a block's first come from a TICKET counter, so a block on a busy CU
-// simply takes fewer of them; (b) a block still at work `boost_ticks` (100 MHz) after it started raises its wave priority above FC1's:
-// the stage's remainder (the whole of it is 0.18 ms alone) then finishes inside FC1's last quarter instead of behind the gate kernel.
-// ticket: one device word, zero between launches (the block that draws the last ticket hands it back as zero).
-template <bool FAST>
-__global__ __launch_bounds__(256) void k0_tile_side(const uint8_t* __restrict__ luma, int width, int height, long pitch,
-                                                    long frame_stride, int cw, int nctu, long ctu0, int n_total,
-                                                    uint4* __restrict__ XS, uint4* __restrict__ XM,
-                                                    uint4* __restrict__ XL, int* __restrict__ gate_flags, int n_flags,
-                                                    int* __restrict__ ticket, unsigned boost_ticks) {
-    __shared__ uint32_t tile[16 * kSlabCtuPitch];
-    __shared__ int s_grp;
-    if (blockIdx.x == 0)
-        for (int i = threadIdx.x; i < n_flags; i += 256) gate_flags[i] = 0;
-    const int ngroups = (n_total + 15) >> 4;
-    unsigned long long t0;
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
-    bool boosted = boost_ticks == 0;
-    int grp = blockIdx.x;  // (gridDim.x <= ngroups: every block has a first group)
-#pragma unroll 1
-    for (;;) {
-        tile_group<FAST, false, false>(tile, luma, width, height, pitch, frame_stride, cw, nctu, ctu0, n_total, grp, XS, XM, XL);
-        if (threadIdx.x == 0) s_grp = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        const int raw = s_grp;
-        __syncthreads();
-        grp = (int)gridDim.x + raw;
-        if (grp >= ngroups) {  // ngroups - gridDim.x tickets stand for groups, the gridDim.x behind them are the blocks' leaving draws
-            if (threadIdx.x == 0 && raw == ngroups - 1) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-        }
-        if (!boosted) {
-            unsigned long long t;
-            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-            if (t - t0 > boost_ticks) {
-                __builtin_amdgcn_s_setprio(3);
-                boosted = true;
-            }
-        }
-    }
-}
-
-void launch_tile_side(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, const Workspace& ws, int n_flags, hipStream_t s,
-                      int max_blocks, int* ticket, unsigned boost_ticks) {
-    const int groups = (n + 15) / 16;
-    const int sb = groups < max_blocks ? groups : max_blocks;
-    const bool fast = (g.width % 16 == 0) && (g.pitch % 16 == 0) && (g.frame_stride % 16 == 0) &&
-                      (reinterpret_cast<uintptr_t>(d_luma) % 16 == 0);
-    if (fast)
-        hipLaunchKernelGGL((k0_tile_side<true>), dim3(sb), dim3(256), 0, s, d_luma, g.width, g.height, g.pitch, g.frame_stride, g.cw, g.nctu,
-                           ctu0, n, ws.xs, ws.xm, ws.xl, ws.flags, n_flags, ticket, boost_ticks);
-    else
-        hipLaunchKernelGGL((k0_tile_side<false>), dim3(sb), dim3(256), 0, s, d_luma, g.width, g.height, g.pitch, g.frame_stride, g.cw, g.nctu,
-                           ctu0, n, ws.xs, ws.xm, ws.xl, ws.flags, n_flags, ticket, boost_ticks);
-}
-
 void launch_tile(const uint8_t* d_luma, const FrameGeom& g, long ctu0, int n, const Workspace& ws, int n_flags,
                  hipStream_t s, int max_blocks, const unsigned* wait_rows, unsigned wait_seq, unsigned* gave_up) {
     const int blocks = (n + 15) / 16;
