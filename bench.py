@@ -304,6 +304,8 @@ def main():
                          "frac": fc1_tflops / PEAK_F32_MFMA_TFLOPS, **pmc_traffic(args.workload),
                          "avg_launch_ms": fc1_ms, "launches_timed": st["timed"]["fc1"], "ctus_per_launch": ctus_per_launch,
                          "flop_per_ctu": FC1_FLOP_PER_CTU,
+                         "profile": "profiles/r06_kernel_stats_by_grid_%s.csv: row k_fc1_* of this workload's grid size (rocprofv3 kernel trace of this "
+                                    "command with --no-other-configs --no-fast-plan)" % args.workload,
                          "note": "rank 0's launches, timed inside the measured region, i.e. with the next step's CTU-load stage "
                                  "running beside them; alone on the GPU the same launch takes stages_ms_per_step.fc1"},
             "stages_ms_per_step": {k: v / 3.0 for k, v in st_all["ms"].items()},
